@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def cfg():
+    from onepose_st_amd.config import default_config
+    return default_config()
+
+
+@pytest.fixture(scope="session")
+def sd(cfg):
+    from onepose_st_amd.synthetic import make_synthetic_state_dict
+    return make_synthetic_state_dict(seed=0, config=cfg)

@@ -1,0 +1,119 @@
+"""The oracle (CPU restatement) against goldens captured from the reference itself.
+
+Floats: rtol 1e-4 / atol 1e-5 (the reference's own batched-vs-single noise is 6e-6,
+SURVEY section 8c); indices exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import onepose_oracle as orc
+from onepose_st_amd.synthetic import make_synthetic_inputs
+
+
+def cs(t):
+    d = t.detach().double()
+    return np.array([d.sum().item(), (d * d).sum().item(), d.abs().max().item()])
+
+
+def close_cs(a, b, rtol=2e-5):
+    # sums of ~1e6 fp32 values: compare relative to the l2 mass
+    scale = max(1.0, abs(b[1]) ** 0.5)
+    assert abs(a[0] - b[0]) <= rtol * scale * 10, (a, b)
+    assert abs(a[1] - b[1]) <= rtol * max(1.0, abs(b[1])), (a, b)
+    assert abs(a[2] - b[2]) <= 1e-4 * max(1.0, abs(b[2])), (a, b)
+
+
+def _inputs(sd, cfg, case):
+    if case == "c1":
+        return make_synthetic_inputs(sd, n_points=1000, image_hw=(240, 320), n_plant=600, seed=1, config=cfg)
+    i0 = make_synthetic_inputs(sd, n_points=333, image_hw=(96, 136), n_plant=120, seed=3, config=cfg, frame=0)
+    i1 = make_synthetic_inputs(sd, n_points=333, image_hw=(96, 136), n_plant=120, seed=3, config=cfg, frame=1)
+    both = {k: torch.cat([i0[k], i1[k]], 0) for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db", "feat_c", "feat_f")}
+    both["image_hw"] = i0["image_hw"]
+    return both
+
+
+@pytest.mark.parametrize("case,fname", [("c1", "c1_feature_boundary.npz"), ("b2", "b2_ragged_feature_boundary.npz")])
+def test_oracle_matches_reference_golden(sd, cfg, golden_dir, case, fname):
+    g = np.load(os.path.join(golden_dir, fname))
+    inp = _inputs(sd, cfg, case)
+    # the seeded generator still produces the inputs the goldens were made from
+    for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db", "feat_c", "feat_f"):
+        np.testing.assert_allclose(cs(inp[k]), g["in_" + k], rtol=1e-12, atol=1e-9)
+    trace = {}
+    with torch.no_grad():
+        out = orc.forward_from_features(sd, cfg, inp, inp["feat_c"], inp["feat_f"], inp["image_hw"], trace)
+    close_cs(cs(trace["q2d_in"]), g["pe_out_cs"])
+    close_cs(cs(trace["d3_in"].transpose(1, 2)), g["kpt_out_cs"])
+    np.testing.assert_allclose(trace["q2d_in"][0][:4, :8].numpy(), g["pe_out_probe"], rtol=1e-5, atol=1e-6)
+    for li, (d3, d2) in enumerate(trace["coarse_layers"]):
+        close_cs(cs(d2), g[f"coarse{li}_2d_cs"])
+        close_cs(cs(d3), g[f"coarse{li}_3d_cs"])
+        np.testing.assert_allclose(d2[0][:4, :8].numpy(), g[f"coarse{li}_2d_probe"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(d3[0][:4, :8].numpy(), g[f"coarse{li}_3d_probe"], rtol=1e-4, atol=1e-5)
+    conf = out["conf_matrix"]
+    np.testing.assert_allclose(conf.max(dim=2)[0][0].numpy(), g["conf_rowmax"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(conf.max(dim=1)[0][0].numpy(), g["conf_colmax"], rtol=1e-4, atol=1e-6)
+    for k in ("b_ids", "i_ids", "j_ids", "m_bids"):
+        assert out[k].dtype == torch.int64
+        np.testing.assert_array_equal(out[k].numpy(), g[k])
+    assert out["gt_mask"].dtype == torch.bool and not out["gt_mask"].any()
+    for k in ("mconf", "mkpts_3d_db", "mkpts_query_c", "mkpts_query_f"):
+        assert out[k].dtype == torch.float32
+        np.testing.assert_allclose(out[k].numpy(), g[k], rtol=1e-4, atol=2e-5, err_msg=k)
+    # expec_f = (x, y, std): std = sum sqrt(clamp(E[g^2]-E[g]^2, 1e-10)) cancels catastrophically for
+    # peaked heatmaps (d std = d var / 2 std), so the std column gets an absolute tolerance of 1e-3.
+    np.testing.assert_allclose(out["expec_f"][:, :2].numpy(), g["expec_f"][:, :2], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(out["expec_f"][:, 2].numpy(), g["expec_f"][:, 2], rtol=1e-3, atol=1e-3)
+    close_cs(cs(trace["fine_f3_in"]), g["fine_in_f3_cs"])
+    close_cs(cs(trace["fine_win_in"]), g["fine_in_win_cs"])
+    close_cs(cs(trace["fine_win_out"]), g["fine1_win_cs"])
+    close_cs(cs(trace["fine_f3_out"]), g["fine1_f3_cs"])
+    # the planted matches are recovered (sanity of the generator, not of the oracle)
+    got = set(zip(out["i_ids"][out["b_ids"] == 0].tolist(), out["j_ids"][out["b_ids"] == 0].tolist()))
+    planted = set(zip(g["planted_i"].tolist(), g["planted_j"].tolist()))
+    assert len(got & planted) >= 0.9 * len(got)
+
+
+def test_oracle_full_forward_empty_matches(sd, cfg, golden_dir):
+    """Backbone + K=0 path (fine_preprocess.py:34-37, fine_matching.py:46-55)."""
+    g = np.load(os.path.join(golden_dir, "full_forward_empty.npz"))
+    img = torch.rand(1, 1, 64, 96, generator=torch.Generator().manual_seed(5))
+    np.testing.assert_allclose(cs(img), g["image_cs"], rtol=1e-12)
+    obj = make_synthetic_inputs(sd, n_points=200, image_hw=(64, 96), n_plant=0, seed=4, config=cfg)
+    data = {"query_image": img, "keypoints3d": obj["keypoints3d"], "descriptors3d_db": obj["descriptors3d_db"],
+            "descriptors3d_coarse_db": obj["descriptors3d_coarse_db"]}
+    with torch.no_grad():
+        fc, ff = orc.backbone_8_2(sd, img)
+        out = orc.forward(sd, cfg, data)
+    close_cs(cs(fc), g["feat_c_cs"], rtol=1e-4)
+    close_cs(cs(ff), g["feat_f_cs"], rtol=1e-4)
+    np.testing.assert_allclose(fc[0, :4, 0, :8].numpy(), g["feat_c_probe"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out["conf_matrix"].max(dim=2)[0][0].numpy(), g["conf_rowmax"], rtol=1e-4, atol=1e-7)
+    assert len(out["i_ids"]) == int(g["K"][0]) == 0
+    for k in ("mconf", "mkpts_3d_db", "mkpts_query_c", "expec_f", "mkpts_query_f"):
+        assert tuple(out[k].shape) == tuple(g[k + "_shape"]), k
+
+
+def test_position_table_quirk():
+    """div_term = exp(-(0,2,4,...)) because of the floor division (row a1)."""
+    pe = orc.position_table(256)[0]
+    assert pe.shape == (256, 256, 256)
+    x = torch.arange(1, 257).float()
+    np.testing.assert_allclose(pe[0, 0].numpy(), torch.sin(x).numpy(), rtol=0, atol=0)          # i=0: div=1
+    np.testing.assert_allclose(pe[5, 3].numpy(), torch.cos(x * float(np.exp(np.float32(-2.0)))).numpy(), atol=1e-6)
+    np.testing.assert_allclose(pe[2, :, 7].numpy(), torch.sin(x).numpy(), atol=0)               # y channel
+
+
+def test_border_mask_quirk():
+    """only top rows / left columns are removed (coarse_matching.py:19-20 slice -b:0 is empty)."""
+    N, h, w = 6, 6, 7
+    conf = torch.zeros(1, N, h * w)
+    cells = [(0, 3), (3, 0), (5, 3), (3, 6), (2, 2), (1, 4)]     # top, left, bottom, right, inside, row1
+    for i, (y, x) in enumerate(cells):
+        conf[0, i, y * w + x] = 0.5 + 0.01 * i
+    out = orc.coarse_match_select(conf, (h, w), (h * 8, w * 8), torch.zeros(1, N, 3), 0.1, 2)
+    assert out["i_ids"].tolist() == [2, 3, 4]
+    assert out["mkpts_query_c"].tolist() == [[24.0, 40.0], [48.0, 24.0], [16.0, 16.0]]
