@@ -1,0 +1,90 @@
+/* libonepose_hip.so -- C ABI of the MI355X (gfx950) implementation of the OnePose++ 2D-3D matching hot path.
+ *
+ * The reference (mizeller/OnePose_ST) has no FFI/plugin boundary: the path sits behind a Python nn.Module
+ * (src/models/OnePosePlus/OnePosePlusModel.py:24-203).  This header is the boundary a maintainer binds with
+ * ctypes; each entry point replaces the reference sub-module named in its comment.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless it says "host"; plain pointers and sizes only
+ *   - float = IEEE f32, ids = int64 (torch.long), all tensors dense row-major in the stated shape
+ *   - `stream` is a hipStream_t (NULL = default stream); calls only enqueue work, never synchronise,
+ *     never allocate: callers pass workspaces sized by the *_workspace_floats() helpers
+ *   - return 0 on success; -1 invalid argument; otherwise the hipError_t.  ophip_last_error() (host
+ *     string, thread local) describes the last failure.
+ *   - packed weight blocks are produced by onepose_st_amd/packing.py (layout documented there and in
+ *     csrc/tile.h): W[out][in] in MFMA fragment order [out/32][in/8][64 lanes][4].
+ */
+#ifndef ONEPOSE_HIP_H
+#define ONEPOSE_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int ophip_abi_version(void);
+const char* ophip_last_error(void);
+/* host query: CU count, LDS bytes per block, gcn arch name of the current device */
+int ophip_device_info(int* cu_count, int* lds_per_block, char* arch, int arch_len);
+
+/* Measurement hook (bench.py): select one kernel by name ("attn_apply", "kv_reduce", "kv_sum", "sim_stats",
+ * "stat_combine", "conf", "colmax", "select", "fine_refine", "pe_add_transpose", "kpt_stats", "kpt_encode"; "" = off).
+ * While selected, every launch of that kernel is bracketed by a hipEvent pair on its launch stream (at most 8192
+ * launches between reads).  ophip_timing_read() synchronises those events, returns the launch count and the summed
+ * device time, and clears the log. */
+int ophip_timing_select(const char* kernel_name);
+int ophip_timing_read(int* launches, double* total_ms);
+
+/* a1 -- PositionEncodingSine.forward + rearrange 'n c h w -> n (h w) c'
+ * (utils/position_encoding.py:37-42, OnePosePlusModel.py:135-140).
+ * out[b][m][c] = feat[b][c][m] + pe_nlc[m][c];  pe_nlc may be NULL (positional encoding disabled). */
+int ophip_pe_add_transpose(const float* feat_nchw, const float* pe_nlc, float* out_nlc, int B, int C, int M, void* stream);
+
+/* [B][C][L] -> [B][L][C]  (the einsum 'bdn->bnd' of transformer.py:145 when keypoint encoding is disabled) */
+int ophip_transpose_cl(const float* in_bcl, float* out_blc, int B, int C, int L, void* stream);
+
+/* a2 + a3 -- normalize_3d_keypoints + KeypointEncoding_linear.forward, emitted token-major
+ * (utils/normalize.py:17-28, utils/position_encoding.py:54-79, transformer.py:145).
+ * keypoints3d [B][N][3] (batch stride kpts_bstride floats; 0 = shared object block),
+ * desc_bcn [B][256][N] (batch stride desc_bstride), stats: scratch of 4*B+4 floats,
+ * out_bnc [B][N][256].  wpack: keypoint-encoder block of packing.py. */
+int ophip_kpt_encode(const float* keypoints3d, long long kpts_bstride, const float* desc_bcn, long long desc_bstride,
+                     const float* wpack, float* stats, float* out_bnc, int B, int N, void* stream);
+
+/* a4-a6 -- one LoFTREncoderLayer applied to both streams of the coarse encoder (d_model 256, 8 heads)
+ * (loftr_module/transformer.py:65-94 and :146-159, loftr_module/linear_attention.py:29-61).
+ * x3d [B][L3d][256], x2d [B][L2d][256] -> y3d, y2d (must not alias the inputs: both streams of a layer read
+ * the pre-update tensors).  is_cross: 0 = "self", 1 = "cross".  workspace: ophip_encoder_workspace_floats(). */
+size_t ophip_encoder_workspace_floats(int B, int L3d, int L2d);
+int ophip_encoder_layer(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
+                        const float* wpack, int is_cross, float* workspace, void* stream);
+
+/* a7 + a8 -- CoarseMatching.forward + get_coarse_match, inference branch
+ * (utils/coarse_matching.py:76-123, :125-242, mask_border :10-20).
+ * feat3d [B][N][256], feat2d [B][M][256] (encoder outputs), M = hc * wc.
+ * conf [B][N][M] receives the dual-softmax confidence matrix (data["conf_matrix"]).
+ * Outputs (capacity B*N entries each, ascending (b, i)): b_ids/i_ids/j_ids int64, mconf, mkpts3d [.][3]
+ * (= keypoints3d[b, i]), mkpts_c [.][2] (= (j % wc, j / wc) * scale); *count = K.
+ * temperature is passed as double so that (float)(temperature + 1e-4) matches the reference's scalar. */
+size_t ophip_coarse_workspace_floats(int B, int N, int M);
+int ophip_coarse_match(const float* feat3d, const float* feat2d, const float* keypoints3d, long long kpts_bstride,
+                       int B, int N, int M, int wc, double temperature, float thr, int border_rm, float scale,
+                       float* conf, float* workspace, long long* b_ids, long long* i_ids, long long* j_ids,
+                       float* mconf, float* mkpts3d, float* mkpts_c, int* count, void* stream);
+
+/* a9 + a10 + a11 -- FinePreprocess + fine LocalFeatureTransformer (d_model 128) + FineMatching
+ * (loftr_module/fine_preprocess.py:32-55, loftr_module/transformer.py:133-171, utils/fine_matching.py:28-110).
+ * feat_f: fine feature map addressed by strides in floats (NCHW or channels-last), hf x wf.
+ * desc3d_f [B][128][N] (strides ds_b, ds_c).  Matches come from ophip_coarse_match (device count, no host sync);
+ * the grid covers max_matches, surplus workgroups exit.  expec_f [.][3] = (x, y, std), mkpts_f [.][2].
+ * dbg_win [.][25][128] / dbg_f3 [.][128] (both or neither; NULL in production) receive the fine-encoder outputs. */
+int ophip_fine_refine(const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x, int hf, int wf,
+                      const float* desc3d_f, long long ds_b, long long ds_c,
+                      const long long* b_ids, const long long* i_ids, const long long* j_ids, const int* count, int max_matches,
+                      const float* mkpts_c, const float* wpack, int nlayers, unsigned cross_bits, int encoder_enable,
+                      int wc, int stride, float fine_scale, float* expec_f, float* mkpts_f,
+                      float* dbg_win, float* dbg_f3, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,84 @@
+// C-ABI plumbing: version, error reporting, device queries.  See include/onepose_hip.h.
+#include "tile.h"
+#include <stdio.h>
+#include <string.h>
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+int ophip_fail(hipError_t e, const char* where) {
+    snprintf(g_err, sizeof(g_err), "%s: HIP error %d (%s)", where, (int)e, hipGetErrorString(e));
+    return (int)e;
+}
+
+int ophip_bad_arg(const char* where, const char* what) {
+    snprintf(g_err, sizeof(g_err), "%s: invalid argument: %s", where, what);
+    return -1;
+}
+
+// ---- per-kernel event timing ---------------------------------------------------------------------
+namespace {
+constexpr int kMaxEvents = 8192;
+char g_sel[64] = "";
+hipEvent_t* g_start = nullptr;
+hipEvent_t* g_stop = nullptr;
+int g_used = 0;
+}
+
+ophip_timed::ophip_timed(const char* name, hipStream_t s) : slot(-1), stream(s) {
+    if (g_sel[0] == 0 || strcmp(name, g_sel) != 0 || g_used >= kMaxEvents) return;
+    slot = g_used++;
+    (void)hipEventRecord(g_start[slot], stream);
+}
+ophip_timed::~ophip_timed() {
+    if (slot >= 0) (void)hipEventRecord(g_stop[slot], stream);
+}
+
+extern "C" int ophip_timing_select(const char* kernel_name) {
+    if (!kernel_name || strlen(kernel_name) >= sizeof(g_sel)) return ophip_bad_arg(__func__, "kernel name");
+    if (!g_start && kernel_name[0]) {
+        g_start = new hipEvent_t[kMaxEvents];
+        g_stop = new hipEvent_t[kMaxEvents];
+        for (int i = 0; i < kMaxEvents; ++i) {
+            hipError_t e = hipEventCreate(&g_start[i]);
+            if (e == hipSuccess) e = hipEventCreate(&g_stop[i]);
+            if (e != hipSuccess) return ophip_fail(e, __func__);
+        }
+    }
+    strcpy(g_sel, kernel_name);
+    g_used = 0;
+    return 0;
+}
+
+extern "C" int ophip_timing_read(int* launches, double* total_ms) {
+    double tot = 0.0;
+    for (int i = 0; i < g_used; ++i) {
+        hipError_t e = hipEventSynchronize(g_stop[i]);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, g_start[i], g_stop[i]);
+        if (e != hipSuccess) return ophip_fail(e, __func__);
+        tot += ms;
+    }
+    if (launches) *launches = g_used;
+    if (total_ms) *total_ms = tot;
+    g_used = 0;
+    return 0;
+}
+
+extern "C" int ophip_abi_version(void) { return 1; }
+
+extern "C" const char* ophip_last_error(void) { return g_err; }
+
+extern "C" int ophip_device_info(int* cu_count, int* lds_per_block, char* arch, int arch_len) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return ophip_fail(e, __func__);
+    hipDeviceProp_t p;
+    e = hipGetDeviceProperties(&p, dev);
+    if (e != hipSuccess) return ophip_fail(e, __func__);
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (lds_per_block) *lds_per_block = (int)p.sharedMemPerBlock;
+    if (arch && arch_len > 0) { strncpy(arch, p.gcnArchName, arch_len - 1); arch[arch_len - 1] = 0; }
+    return 0;
+}

@@ -1,0 +1,464 @@
+// Coarse matching: N x M dual-softmax confidence matrix + mutual-nearest filter + ordered compaction.
+// Reference: utils/coarse_matching.py:76-123 (forward: sim = <A/sqrt(C), Bq/sqrt(C)> / (T + 1e-4),
+// conf = softmax(sim, dim=1) * softmax(sim, dim=2)) and :125-242 (get_coarse_match, inference branch).
+//
+// Launch chain (all f32, deterministic -- no float atomics, every cross-workgroup reduction is a
+// fixed-order combine of per-tile partials):
+//   sim_stats     128x128 tiles of S = A Bq^T / (256 T') on v_mfma_f32_32x32x2_f32, LDS-staged K chunks;
+//                 writes S into the conf buffer and per-tile (max, sum exp) for rows and columns
+//   stat_combine  online-softmax merge of the partials -> row (max, sum), column (max, sum)
+//   conf          in-place S -> conf, coalesced 16 B/lane streaming (HBM-bound); per row the best
+//                 (value, lowest j, tie count) and per column the best value, as partials
+//   colmax        column maxima from the row-block partials
+//   select        threshold (strict >), border removal (top/left only: the reference's `-b:0` slices are
+//                 empty), mutual test, first-true-j semantics on exact ties, compaction in ascending (b, i)
+#include "tile.h"
+#include <math.h>
+
+namespace {
+
+constexpr int C = 256;
+constexpr int TM = 128, TN = 128, KC = 32, LDT = KC + OPHIP_PAD;
+
+struct SimArgs {
+    const float* a;      // [B][N][C]
+    const float* bq;     // [B][M][C]
+    float* conf;         // [B][N][M]
+    float* rowpart;      // [B][ntc][N][2]
+    float* colpart;      // [B][ntr][M][2]
+    int N, M, ntr, ntc;
+    float temp;          // temperature + 1e-4
+};
+
+__device__ __forceinline__ void merge_ms(float& m, float& e, float m2, float e2) {
+    const float mm = fmaxf(m, m2);
+    if (mm == -INFINITY) { m = mm; e = 0.f; return; }
+    e = e * expf(m - mm) + e2 * expf(m2 - mm);
+    m = mm;
+}
+
+__device__ __forceinline__ float half_max(float v) {     // over the 32 lanes that share lane>>5
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void sim_stats_kernel(SimArgs p) {
+    __shared__ __attribute__((aligned(16))) float At[TM * LDT];
+    __shared__ __attribute__((aligned(16))) float Bt[TN * LDT];
+    __shared__ float rowst[2][TM][2];
+    __shared__ float colst[2][TN][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
+    const int j0 = blockIdx.x * TN, i0 = blockIdx.y * TM, b = blockIdx.z;
+    const float* A = p.a + (size_t)b * p.N * C;
+    const float* Bq = p.bq + (size_t)b * p.M * C;
+
+    f32x4 ra[4], rb[4];
+    auto prefetch = [&](int kc) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + 256 * u, row = idx >> 3, c4 = idx & 7;
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            ra[u] = (i0 + row < p.N) ? *reinterpret_cast<const f32x4*>(A + (size_t)(i0 + row) * C + kc * KC + 4 * c4) : z;
+            rb[u] = (j0 + row < p.M) ? *reinterpret_cast<const f32x4*>(Bq + (size_t)(j0 + row) * C + kc * KC + 4 * c4) : z;
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + 256 * u, row = idx >> 3, c4 = idx & 7;
+            // feat / sqrt(C): 1/16 is a power of two, so (a/16).(b/16) == (a.b)/256 bit for bit
+            *reinterpret_cast<f32x4*>(At + row * LDT + 4 * c4) = ra[u] * 0.0625f;
+            *reinterpret_cast<f32x4*>(Bt + row * LDT + 4 * c4) = rb[u] * 0.0625f;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = zero16();
+
+    prefetch(0);
+    stage();
+    __syncthreads();
+    constexpr int NKC = C / KC;
+    for (int kc = 0; kc < NKC; ++kc) {
+        if (kc + 1 < NKC) prefetch(kc + 1);
+#pragma unroll
+        for (int kb = 0; kb < KC / 8; ++kb) {
+            f32x4 fa[2], fb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                fa[t] = *reinterpret_cast<const f32x4*>(At + (64 * wr + 32 * t + r) * LDT + 8 * kb + 4 * h);
+                fb[t] = *reinterpret_cast<const f32x4*>(Bt + (64 * wc + 32 * t + r) * LDT + 8 * kb + 4 * h);
+            }
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) acc[x][y] = mfma4(fa[x], fb[y], acc[x][y]);
+        }
+        __syncthreads();
+        if (kc + 1 < NKC) {
+            stage();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: S, row / column (max, sum exp) of this tile -------------------------------
+    float* conf = p.conf + (size_t)b * p.N * p.M;
+    bool jv[2];
+#pragma unroll
+    for (int y = 0; y < 2; ++y) jv[y] = (j0 + 64 * wc + 32 * y + r) < p.M;
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int lrow = 64 * wr + 32 * x + acc_row(reg, h);
+            const int i = i0 + lrow;
+            float v[2];
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const float s = acc[x][y][reg] / p.temp;
+                acc[x][y][reg] = s;
+                if (i < p.N && jv[y]) conf[(size_t)i * p.M + j0 + 64 * wc + 32 * y + r] = s;
+                v[y] = jv[y] ? s : -INFINITY;
+            }
+            const float m = half_max(fmaxf(v[0], v[1]));
+            float e = 0.f;
+            if (m != -INFINITY) e = expf(v[0] - m) + expf(v[1] - m);
+            e = half_sum(e);
+            if (r == 0) { rowst[wc][lrow][0] = m; rowst[wc][lrow][1] = e; }
+        }
+    }
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const bool iv = (i0 + 64 * wr + 32 * x + acc_row(reg, h)) < p.N;
+                m = fmaxf(m, iv ? acc[x][y][reg] : -INFINITY);
+            }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float e = 0.f;
+        if (m != -INFINITY) {
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const bool iv = (i0 + 64 * wr + 32 * x + acc_row(reg, h)) < p.N;
+                    e += iv ? expf(acc[x][y][reg] - m) : 0.f;
+                }
+        }
+        e += __shfl_xor(e, 32, 64);
+        if (h == 0) { colst[wr][64 * wc + 32 * y + r][0] = m; colst[wr][64 * wc + 32 * y + r][1] = e; }
+    }
+    __syncthreads();
+    if (tid < TM) {
+        float m = rowst[0][tid][0], e = rowst[0][tid][1];
+        merge_ms(m, e, rowst[1][tid][0], rowst[1][tid][1]);
+        if (i0 + tid < p.N) {
+            float* o = p.rowpart + (((size_t)b * p.ntc + blockIdx.x) * p.N + i0 + tid) * 2;
+            o[0] = m; o[1] = e;
+        }
+    } else {
+        const int c = tid - TM;
+        float m = colst[0][c][0], e = colst[0][c][1];
+        merge_ms(m, e, colst[1][c][0], colst[1][c][1]);
+        if (j0 + c < p.M) {
+            float* o = p.colpart + (((size_t)b * p.ntr + blockIdx.y) * p.M + j0 + c) * 2;
+            o[0] = m; o[1] = e;
+        }
+    }
+}
+
+struct CombineArgs {
+    const float *rowpart, *colpart;
+    float *rowstat, *colstat;     // [B][N][2], [B][M][2]
+    int N, M, ntr, ntc;
+};
+
+__global__ __launch_bounds__(256) void stat_combine_kernel(CombineArgs p) {
+    const int idx = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (idx < p.N) {
+        float m = -INFINITY, e = 0.f;
+        for (int t = 0; t < p.ntc; ++t) {
+            const float* q = p.rowpart + (((size_t)b * p.ntc + t) * p.N + idx) * 2;
+            merge_ms(m, e, q[0], q[1]);
+        }
+        p.rowstat[((size_t)b * p.N + idx) * 2] = m;
+        p.rowstat[((size_t)b * p.N + idx) * 2 + 1] = e;
+    } else if (idx < p.N + p.M) {
+        const int j = idx - p.N;
+        float m = -INFINITY, e = 0.f;
+        for (int t = 0; t < p.ntr; ++t) {
+            const float* q = p.colpart + (((size_t)b * p.ntr + t) * p.M + j) * 2;
+            merge_ms(m, e, q[0], q[1]);
+        }
+        p.colstat[((size_t)b * p.M + j) * 2] = m;
+        p.colstat[((size_t)b * p.M + j) * 2 + 1] = e;
+    }
+}
+
+struct ConfArgs {
+    float* conf;
+    const float *rowstat, *colstat;
+    float* rowbest;      // [B][nspan][N][3]  (value, j as float bits, tie count as float bits)
+    float* colbest;      // [B][nrb][M]
+    int N, M, nspan, spanw, nrb;
+};
+
+constexpr int CONF_ROWS = 32;
+constexpr int CONF_U = 4;          // float4 groups per thread per row  => span <= 4096 columns
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
+    __shared__ float red_v[4][CONF_ROWS];
+    __shared__ int red_j[4][CONF_ROWS];
+    __shared__ int red_c[4][CONF_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int span = blockIdx.x, rb = blockIdx.y, b = blockIdx.z;
+    const int jb = span * p.spanw, je = min(p.M, jb + p.spanw);
+    const int i0 = rb * CONF_ROWS;
+    float* conf = p.conf + (size_t)b * p.N * p.M;
+    const float* cst = p.colstat + (size_t)b * p.M * 2;
+    const float* rst = p.rowstat + (size_t)b * p.N * 2;
+
+    float cm[CONF_U][4], cs[CONF_U][4], cbest[CONF_U][4];
+#pragma unroll
+    for (int u = 0; u < CONF_U; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = jb + 4 * tid + 1024 * u + e;
+            cm[u][e] = (j < je) ? cst[2 * j] : 0.f;
+            cs[u][e] = (j < je) ? cst[2 * j + 1] : 1.f;
+            cbest[u][e] = 0.f;
+        }
+    const int nrows = min(CONF_ROWS, p.N - i0);
+    for (int rr = 0; rr < nrows; ++rr) {
+        const int i = i0 + rr;
+        const float rm = rst[2 * i], rs = rst[2 * i + 1];
+        float* row = conf + (size_t)i * p.M;
+        float bv = -1.f;
+        int bj = 0x7fffffff, bc = 0;
+#pragma unroll
+        for (int u = 0; u < CONF_U; ++u) {
+            const int jq = jb + 4 * tid + 1024 * u;
+            if (jq >= je) continue;
+            float s[4];
+            if (VEC) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(row + jq);
+                s[0] = v[0]; s[1] = v[1]; s[2] = v[2]; s[3] = v[3];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[e] = (jq + e < je) ? row[jq + e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // softmax over the 3D axis (dim=1, column stats) times softmax over the 2D axis (dim=2, row stats)
+                const float pc = expf(s[e] - cm[u][e]) / cs[u][e];
+                const float pr = expf(s[e] - rm) / rs;
+                const float c = pc * pr;
+                s[e] = c;
+                if (jq + e < je) {
+                    cbest[u][e] = fmaxf(cbest[u][e], c);
+                    if (c > bv) { bv = c; bj = jq + e; bc = 1; }
+                    else if (c == bv) { bc += 1; bj = min(bj, jq + e); }
+                }
+            }
+            if (VEC) {
+                f32x4 v = {s[0], s[1], s[2], s[3]};
+                *reinterpret_cast<f32x4*>(row + jq) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (jq + e < je) row[jq + e] = s[e];
+            }
+        }
+        // wave reduce: max value, lowest j among the maxima, number of maxima
+        const float wv = wave_max(bv);
+        int cj = (bv == wv) ? bj : 0x7fffffff;
+        int cc = (bv == wv) ? bc : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            cj = min(cj, __shfl_xor(cj, o, 64));
+            cc += __shfl_xor(cc, o, 64);
+        }
+        if (lane == 0) { red_v[wave][rr] = wv; red_j[wave][rr] = cj; red_c[wave][rr] = cc; }
+    }
+    __syncthreads();
+    if (tid < nrows) {
+        float v = red_v[0][tid];
+        int j = red_j[0][tid], c = red_c[0][tid];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float v2 = red_v[w][tid];
+            if (v2 > v) { v = v2; j = red_j[w][tid]; c = red_c[w][tid]; }
+            else if (v2 == v) { j = min(j, red_j[w][tid]); c += red_c[w][tid]; }
+        }
+        float* o = p.rowbest + (((size_t)b * p.nspan + span) * p.N + i0 + tid) * 3;
+        o[0] = v; o[1] = __int_as_float(j); o[2] = __int_as_float(c);
+    }
+    float* cb = p.colbest + ((size_t)b * p.nrb + rb) * p.M;
+#pragma unroll
+    for (int u = 0; u < CONF_U; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = jb + 4 * tid + 1024 * u + e;
+            if (j < je) cb[j] = cbest[u][e];
+        }
+}
+
+struct ColmaxArgs {
+    const float* colbest;
+    float* colmax;       // [B][M]
+    int M, nrb;
+};
+
+__global__ __launch_bounds__(256) void colmax_kernel(ColmaxArgs p) {
+    const int j = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (j >= p.M) return;
+    float m = 0.f;
+    for (int t = 0; t < p.nrb; ++t) m = fmaxf(m, p.colbest[((size_t)b * p.nrb + t) * p.M + j]);
+    p.colmax[(size_t)b * p.M + j] = m;
+}
+
+struct SelectArgs {
+    const float* conf;
+    const float* rowbest;
+    const float* colmax;
+    const float* kpts;          // [B][N][3]
+    long long kpts_bs;          // batch stride of kpts in floats (0 for a shared object block)
+    int B, N, M, nspan, wc, border;
+    float thr, scale;
+    long long* b_ids; long long* i_ids; long long* j_ids;
+    float* mconf; float* mk3d; float* mkq;
+    int* count;
+};
+
+__global__ __launch_bounds__(1024) void select_kernel(SelectArgs p) {
+    __shared__ int wcount[16];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int b = 0; b < p.B; ++b) {
+        const float* conf = p.conf + (size_t)b * p.N * p.M;
+        const float* cmx = p.colmax + (size_t)b * p.M;
+        for (int ib = 0; ib < p.N; ib += 1024) {
+            const int i = ib + tid;
+            bool ok = false;
+            int j = 0;
+            float v = 0.f;
+            if (i < p.N) {
+                int c = 0;
+                v = -1.f; j = 0x7fffffff;
+                for (int sp = 0; sp < p.nspan; ++sp) {
+                    const float* q = p.rowbest + (((size_t)b * p.nspan + sp) * p.N + i) * 3;
+                    const float v2 = q[0];
+                    const int j2 = __float_as_int(q[1]), c2 = __float_as_int(q[2]);
+                    if (v2 > v) { v = v2; j = j2; c = c2; }
+                    else if (v2 == v) { j = min(j, j2); c += c2; }
+                }
+                auto passes = [&](int jj) {
+                    return (jj / p.wc >= p.border) && (jj % p.wc >= p.border) && (v == cmx[jj]);
+                };
+                if (v > p.thr) {
+                    ok = passes(j);
+                    if (!ok && c > 1) {
+                        // exact tie of the row maximum: the reference takes the first j whose mask is true
+                        const float* row = conf + (size_t)i * p.M;
+                        for (int jj = j + 1; jj < p.M; ++jj)
+                            if (row[jj] == v && passes(jj)) { j = jj; ok = true; break; }
+                    }
+                }
+            }
+            const unsigned long long mask = __ballot(ok);
+            const int wpre = __popcll(mask & ((1ull << lane) - 1ull));
+            if (lane == 0) wcount[wave] = __popcll(mask);
+            __syncthreads();
+            int off = base_s, total = 0;
+            for (int w = 0; w < 16; ++w) {
+                if (w < wave) off += wcount[w];
+                total += wcount[w];
+            }
+            if (ok) {
+                const int pos = off + wpre;
+                p.b_ids[pos] = b; p.i_ids[pos] = i; p.j_ids[pos] = j;
+                p.mconf[pos] = v;
+                const float* kp = p.kpts + (size_t)b * p.kpts_bs + (size_t)i * 3;
+                p.mk3d[3 * pos] = kp[0]; p.mk3d[3 * pos + 1] = kp[1]; p.mk3d[3 * pos + 2] = kp[2];
+                p.mkq[2 * pos] = (float)(j % p.wc) * p.scale;
+                p.mkq[2 * pos + 1] = (float)(j / p.wc) * p.scale;
+            }
+            __syncthreads();
+            if (tid == 0) base_s += total;
+            __syncthreads();
+        }
+    }
+    if (tid == 0) *p.count = base_s;
+}
+
+inline int conf_nspan(int M) { return (M + 4095) / 4096; }
+inline int conf_spanw(int M) { const int ns = conf_nspan(M); return (((M + ns - 1) / ns) + 3) / 4 * 4; }
+
+}  // namespace
+
+extern "C" size_t ophip_coarse_workspace_floats(int B, int N, int M) {
+    const size_t ntr = (N + TM - 1) / TM, ntc = (M + TN - 1) / TN, nrb = (N + CONF_ROWS - 1) / CONF_ROWS;
+    size_t f = 0;
+    f += (size_t)B * ntc * N * 2;          // rowpart
+    f += (size_t)B * ntr * M * 2;          // colpart
+    f += (size_t)B * N * 2 + (size_t)B * M * 2;     // rowstat, colstat
+    f += (size_t)B * conf_nspan(M) * N * 3;         // rowbest
+    f += (size_t)B * nrb * M;              // colbest
+    f += (size_t)B * M;                    // colmax
+    return f + 64;
+}
+
+extern "C" int ophip_coarse_match(const float* feat3d, const float* feat2d, const float* keypoints3d, long long kpts_bstride,
+                                  int B, int N, int M, int wc, double temperature, float thr, int border_rm, float scale,
+                                  float* conf, float* workspace, long long* b_ids, long long* i_ids, long long* j_ids,
+                                  float* mconf, float* mkpts3d, float* mkpts_c, int* count, void* stream_) {
+    if (!feat3d || !feat2d || !keypoints3d || !conf || !workspace || !b_ids || !i_ids || !j_ids || !mconf || !mkpts3d || !mkpts_c || !count)
+        return ophip_bad_arg(__func__, "null pointer");
+    if (B < 1 || N < 1 || M < 1 || wc < 1 || M % wc != 0) return ophip_bad_arg(__func__, "bad sizes (need M == hc * wc)");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int ntr = (N + TM - 1) / TM, ntc = (M + TN - 1) / TN, nrb = (N + CONF_ROWS - 1) / CONF_ROWS;
+    const int nspan = conf_nspan(M), spanw = conf_spanw(M);
+    float* rowpart = workspace;
+    float* colpart = rowpart + (size_t)B * ntc * N * 2;
+    float* rowstat = colpart + (size_t)B * ntr * M * 2;
+    float* colstat = rowstat + (size_t)B * N * 2;
+    float* rowbest = colstat + (size_t)B * M * 2;
+    float* colbest = rowbest + (size_t)B * nspan * N * 3;
+    float* colmax = colbest + (size_t)B * nrb * M;
+
+    SimArgs sa{feat3d, feat2d, conf, rowpart, colpart, N, M, ntr, ntc, (float)(temperature + 1e-4)};
+    OPHIP_LAUNCH("sim_stats", stream, sim_stats_kernel, dim3(ntc, ntr, B), dim3(256), 0, stream, sa);
+    OPHIP_CHECK_LAUNCH();
+    CombineArgs ca{rowpart, colpart, rowstat, colstat, N, M, ntr, ntc};
+    OPHIP_LAUNCH("stat_combine", stream, stat_combine_kernel, dim3((N + M + 255) / 256, B), dim3(256), 0, stream, ca);
+    OPHIP_CHECK_LAUNCH();
+    ConfArgs fa{conf, rowstat, colstat, rowbest, colbest, N, M, nspan, spanw, nrb};
+    if (M % 4 == 0)
+        OPHIP_LAUNCH("conf", stream, conf_kernel<true>, dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
+    else
+        OPHIP_LAUNCH("conf", stream, conf_kernel<false>, dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
+    OPHIP_CHECK_LAUNCH();
+    ColmaxArgs ma{colbest, colmax, M, nrb};
+    OPHIP_LAUNCH("colmax", stream, colmax_kernel, dim3((M + 255) / 256, B), dim3(256), 0, stream, ma);
+    OPHIP_CHECK_LAUNCH();
+    SelectArgs se{conf, rowbest, colmax, keypoints3d, kpts_bstride, B, N, M, nspan, wc, border_rm, thr, scale,
+                  b_ids, i_ids, j_ids, mconf, mkpts3d, mkpts_c, count};
+    OPHIP_LAUNCH("select", stream, select_kernel, dim3(1), dim3(1024), 0, stream, se);
+    OPHIP_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,239 @@
+// Encoder inputs: positional-encoding add + NCHW->NLC transpose of the coarse feature map, and the
+// 3D keypoint encoding (normalise -> MLP 3->32->64->128->256 with per-point feature norm -> add to the
+// coarse 3D descriptors, emitted token-major).
+// Reference: utils/position_encoding.py:37-42 + OnePosePlusModel.py:135-140 (a1),
+// utils/normalize.py:17-28 (a2), utils/position_encoding.py:54-79 (a3).
+#include "tile.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// out[b][m][c] = feat[b][c][m] + pe[m][c]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pe_add_transpose_kernel(const float* __restrict__ feat, const float* __restrict__ pe,
+                                                               float* __restrict__ out, int Cc, int M) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int m0 = blockIdx.x * 32, c0 = blockIdx.y * 32, b = blockIdx.z;
+    const float* f = feat + (size_t)b * Cc * M;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, m = m0 + tx;
+        tile[ty + 8 * k][tx] = (c < Cc && m < M) ? f[(size_t)c * M + m] : 0.f;
+    }
+    __syncthreads();
+    float* o = out + (size_t)b * M * Cc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int m = m0 + ty + 8 * k, c = c0 + tx;
+        if (m < M && c < Cc) o[(size_t)m * Cc + c] = tile[tx][ty + 8 * k] + (pe ? pe[(size_t)m * Cc + c] : 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stats[4*b .. 4*b+2] = mean of keypoints3d[b];  stats[4*B] = 0.6 * max extent of batch element 0
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kpt_stats_kernel(const float* __restrict__ kpts, long long bs, float* __restrict__ stats, int B, int N) {
+    __shared__ float red[4][9];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* k = kpts + (size_t)b * bs;
+    float s[3] = {0.f, 0.f, 0.f}, mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = tid; i < N; i += 256) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float v = k[(size_t)i * 3 + d];
+            s[d] += v; mn[d] = fminf(mn[d], v); mx[d] = fmaxf(mx[d], v);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        s[d] = wave_sum(s[d]);
+        mx[d] = wave_max(mx[d]);
+        mn[d] = -wave_max(-mn[d]);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { red[wave][d] = s[d]; red[wave][3 + d] = mn[d]; red[wave][6 + d] = mx[d]; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float ext = 0.f;
+        for (int d = 0; d < 3; ++d) {
+            const float sum = (red[0][d] + red[1][d]) + (red[2][d] + red[3][d]);
+            stats[4 * b + d] = sum / (float)N;
+            const float lo = fminf(fminf(red[0][3 + d], red[1][3 + d]), fminf(red[2][3 + d], red[3][3 + d]));
+            const float hi = fmaxf(fmaxf(red[0][6 + d], red[1][6 + d]), fmaxf(red[2][6 + d], red[3][6 + d]));
+            ext = fmaxf(ext, hi - lo);
+        }
+        stats[4 * b + 3] = 0.f;
+        if (b == 0) stats[4 * B] = ext * 0.6f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// keypoint encoder: 32 points per workgroup, MLP tiles on MFMA, per-point norm in LDS
+// ---------------------------------------------------------------------------------------------
+constexpr int KD = 256;                    // descriptor_dim
+constexpr int L0 = 8 + OPHIP_PAD, L1 = 32 + OPHIP_PAD, L2 = 64 + OPHIP_PAD, L3 = 128 + OPHIP_PAD, LO = KD + OPHIP_PAD;
+constexpr int LD_D = 33;
+
+struct KptArgs {
+    const float* kpts; long long kbs;     // [B][N][3]
+    const float* stats;                   // centres + scaling
+    const float* desc; long long dbs;     // [B][256][N]
+    const f32x4 *w1, *w2, *w3, *w4;       // packed
+    const float *b1, *b2, *b3, *b4;
+    float* out;                           // [B][N][256]
+    int B, N;
+};
+
+__global__ __launch_bounds__(256) void kpt_encode_kernel(KptArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* A0 = smem;                       // [32][L0]
+    float* A1 = A0 + 32 * L0;               // [32][L1]
+    float* A2 = A1 + 32 * L1;               // [32][L2]
+    float* A3 = A2 + 32 * L2;               // [32][L3]
+    float* Dt = A3 + 32 * L3;               // [256][33] descriptor tile, channel-major
+    float* Ot = Dt + KD * LD_D;             // [32][LO]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 32, b = blockIdx.y;
+    const float scaling = p.stats[4 * p.B];
+    // normalised keypoints, zero-padded to K = 8
+    if (tid < 32 * 8) {
+        const int row = tid >> 3, d = tid & 7;
+        float v = 0.f;
+        if (d < 3 && n0 + row < p.N) v = (p.kpts[(size_t)b * p.kbs + (size_t)(n0 + row) * 3 + d] - p.stats[4 * b + d]) / scaling;
+        A0[row * L0 + d] = v;
+    }
+    // descriptor tile: coalesced along n
+    const float* dsc = p.desc + (size_t)b * p.dbs;
+    for (int i = tid; i < KD * 32; i += 256) {
+        const int c = i >> 5, n = i & 31;
+        Dt[c * LD_D + n] = (n0 + n < p.N) ? dsc[(size_t)c * p.N + n0 + n] : 0.f;
+    }
+    __syncthreads();
+    // 3 -> 32
+    if (wave == 0) {
+        f32x16 acc[1] = {zero16()};
+        gemm_lds_x_packed<1>(acc, A0 + r * L0 + 4 * h, 1, p.w1 + lane, 64);
+        const float bias = p.b1[r];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) acc[0][reg] += bias;
+        acc_to_lds(acc[0], A1, L1, 0, lane);
+    }
+    __syncthreads();
+    rows_layernorm<32, false, true>(A1, L1, nullptr, nullptr, 1e-5f, wave, lane);
+    __syncthreads();
+    // 32 -> 64
+    if (wave < 2) {
+        f32x16 acc[1] = {zero16()};
+        gemm_lds_x_packed<1>(acc, A1 + r * L1 + 4 * h, 4, p.w2 + (size_t)wave * 4 * 64 + lane, 4 * 64);
+        const float bias = p.b2[32 * wave + r];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) acc[0][reg] += bias;
+        acc_to_lds(acc[0], A2, L2, 32 * wave, lane);
+    }
+    __syncthreads();
+    rows_layernorm<64, false, true>(A2, L2, nullptr, nullptr, 1e-5f, wave, lane);
+    __syncthreads();
+    // 64 -> 128
+    {
+        f32x16 acc[1] = {zero16()};
+        gemm_lds_x_packed<1>(acc, A2 + r * L2 + 4 * h, 8, p.w3 + (size_t)wave * 8 * 64 + lane, 8 * 64);
+        const float bias = p.b3[32 * wave + r];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) acc[0][reg] += bias;
+        acc_to_lds(acc[0], A3, L3, 32 * wave, lane);
+    }
+    __syncthreads();
+    rows_layernorm<128, false, true>(A3, L3, nullptr, nullptr, 1e-5f, wave, lane);
+    __syncthreads();
+    // 128 -> 256, + bias, + descriptors
+    {
+        f32x16 acc[2] = {zero16(), zero16()};
+        gemm_lds_x_packed<2>(acc, A3 + r * L3 + 4 * h, 16, p.w4 + (size_t)(2 * wave) * 16 * 64 + lane, 16 * 64);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int c = 64 * wave + 32 * t + r;
+            const float bias = p.b4[c];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = acc_row(reg, h);
+                Ot[row * LO + c] = Dt[c * LD_D + row] + (acc[t][reg] + bias);
+            }
+        }
+    }
+    __syncthreads();
+    float* o = p.out + (size_t)b * p.N * KD;
+    for (int rr = 0; rr < 8; ++rr) {
+        const int row = 8 * wave + rr;
+        if (n0 + row < p.N)
+            *reinterpret_cast<f32x4*>(o + (size_t)(n0 + row) * KD + 4 * lane) = *reinterpret_cast<const f32x4*>(Ot + row * LO + 4 * lane);
+    }
+}
+
+// plain [B][C][L] -> [B][L][C] (keypoint encoding disabled: the encoder still wants token-major input)
+__global__ __launch_bounds__(256) void transpose_cl_kernel(const float* __restrict__ in, float* __restrict__ out, int Cc, int L) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int l0 = blockIdx.x * 32, c0 = blockIdx.y * 32, b = blockIdx.z;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, l = l0 + tx;
+        tile[ty + 8 * k][tx] = (c < Cc && l < L) ? in[((size_t)b * Cc + c) * L + l] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int l = l0 + ty + 8 * k, c = c0 + tx;
+        if (l < L && c < Cc) out[((size_t)b * L + l) * Cc + c] = tile[tx][ty + 8 * k];
+    }
+}
+
+}  // namespace
+
+extern "C" int ophip_pe_add_transpose(const float* feat_nchw, const float* pe_nlc, float* out_nlc, int B, int C, int M, void* stream) {
+    if (!feat_nchw || !out_nlc) return ophip_bad_arg(__func__, "null pointer");
+    if (B < 1 || C < 1 || M < 1) return ophip_bad_arg(__func__, "bad sizes");
+    OPHIP_LAUNCH("pe_add_transpose", (hipStream_t)stream, pe_add_transpose_kernel, dim3((M + 31) / 32, (C + 31) / 32, B), dim3(256), 0, (hipStream_t)stream,
+                       feat_nchw, pe_nlc, out_nlc, C, M);
+    OPHIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ophip_transpose_cl(const float* in_bcl, float* out_blc, int B, int C, int L, void* stream) {
+    if (!in_bcl || !out_blc) return ophip_bad_arg(__func__, "null pointer");
+    OPHIP_LAUNCH("transpose_cl", (hipStream_t)stream, transpose_cl_kernel, dim3((L + 31) / 32, (C + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, in_bcl, out_blc, C, L);
+    OPHIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ophip_kpt_encode(const float* keypoints3d, long long kpts_bstride, const float* desc_bcn, long long desc_bstride,
+                                const float* wpack, float* stats, float* out_bnc, int B, int N, void* stream_) {
+    if (!keypoints3d || !desc_bcn || !wpack || !stats || !out_bnc) return ophip_bad_arg(__func__, "null pointer");
+    if (B < 1 || N < 1) return ophip_bad_arg(__func__, "bad sizes");
+    hipStream_t stream = (hipStream_t)stream_;
+    OPHIP_LAUNCH("kpt_stats", stream, kpt_stats_kernel, dim3(B), dim3(256), 0, stream, keypoints3d, kpts_bstride, stats, B, N);
+    OPHIP_CHECK_LAUNCH();
+    // packed block (floats): W1[32x8] | W2[64x32] | W3[128x64] | W4[256x128] | b1 | b2 | b3 | b4
+    KptArgs a;
+    a.kpts = keypoints3d; a.kbs = kpts_bstride; a.stats = stats; a.desc = desc_bcn; a.dbs = desc_bstride;
+    const float* w = wpack;
+    a.w1 = reinterpret_cast<const f32x4*>(w); w += 32 * 8;
+    a.w2 = reinterpret_cast<const f32x4*>(w); w += 64 * 32;
+    a.w3 = reinterpret_cast<const f32x4*>(w); w += 128 * 64;
+    a.w4 = reinterpret_cast<const f32x4*>(w); w += 256 * 128;
+    a.b1 = w; a.b2 = w + 32; a.b3 = w + 96; a.b4 = w + 224;
+    a.out = out_bnc; a.B = B; a.N = N;
+    const size_t lds = (size_t)(32 * (L0 + L1 + L2 + L3 + LO) + KD * LD_D) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kpt_encode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return ophip_fail(e, "hipFuncSetAttribute(kpt_encode)");
+        attr_set = true;
+    }
+    OPHIP_LAUNCH("kpt_encode", stream, kpt_encode_kernel, dim3((N + 31) / 32, B), dim3(256), lds, stream, a);
+    OPHIP_CHECK_LAUNCH();
+    return 0;
+}

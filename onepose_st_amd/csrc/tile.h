@@ -1,0 +1,155 @@
+// Shared device-side building blocks for the gfx950 (CDNA4) kernels of the 2D-3D matcher.
+//
+// Every contraction in the hot path is a chain of "32 tokens x K  times  K x 32 features" tiles
+// on the exact-f32 matrix instruction v_mfma_f32_32x32x2_f32 (64-lane wavefront, f32 in, f32
+// accumulate, bit-for-bit an fmaf chain -- MI355X guide, "FP32-input MFMA").  Lane maps used
+// below (lane l, r = l & 31, h = l >> 5):
+//     A operand:  A[i = r][k = h]            B operand:  B[k = h][j = r]
+//     C/D:        D[row = (reg&3) + 8*(reg>>2) + 4*h][col = r],  reg = 0..15
+//
+// A "fragment" is 16 bytes per lane = 4 consecutive k values of one row, covering 8 k per
+// fragment pair (h = 0 takes k 0..3, h = 1 takes k 4..7 of the 8-block); fragment element j feeds
+// the j-th MFMA of the block.  With this choice
+//   * activations are read from a row-major [token][feature] LDS image with one ds_read_b128,
+//   * weights W[out][in] are pre-packed on the host into fragment order
+//       [out_tile = out/32][kb = in/8][lane = 32*h + (out%32)][j] = W[out][8*kb + 4*h + j]
+//     so that a wave's load of one fragment is 1 KiB contiguous (global_load_dwordx4),
+//   * an accumulator tile *is already* a fragment stack for a product that contracts over its
+//     row index (regs 4s..4s+3 of a lane are rows 8s + 4h + j): used for K^T V and for using
+//     KV as the B operand of phi(Q) KV without touching LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define OPHIP_WAVE 64
+#define OPHIP_TOK 32            // tokens (rows) per workgroup tile
+#define OPHIP_PAD 4             // LDS row padding in floats (16 B): ds_read_b128 conflict-free
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// row of accumulator register `reg` for lane-half h
+__device__ __forceinline__ constexpr int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+__device__ __forceinline__ f32x16 mfma4(const f32x4 a, const f32x4 b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], c, 0, 0, 0);
+    return c;
+}
+
+// acc[t] += A(32 x 8*kblocks, from LDS) * Wpacked(tile t)          (one wave)
+//   lds_a   : this lane's row base inside the LDS image: &img[(lane&31)*lda + 4*(lane>>5)]
+//   wfrag   : packed weights, pointing at [first tile of this wave][kb0][lane]
+//   tstride : distance between consecutive output tiles in f32x4 units (= KB_total * 64)
+template <int NT>
+__device__ __forceinline__ void gemm_lds_x_packed(f32x16 (&acc)[NT], const float* lds_a, int kblocks,
+                                                  const f32x4* __restrict__ wfrag, int tstride) {
+    f32x4 bcur[NT], bnext[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bcur[t] = wfrag[(size_t)t * tstride];
+    for (int kb = 0; kb < kblocks; ++kb) {
+        const int kn = (kb + 1 < kblocks) ? kb + 1 : kb;      // last iteration re-reads (harmless)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bnext[t] = wfrag[(size_t)t * tstride + (size_t)kn * 64];
+        const f32x4 a = *reinterpret_cast<const f32x4*>(lds_a + 8 * kb);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = mfma4(a, bcur[t], acc[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bcur[t] = bnext[t];
+    }
+}
+
+// write an accumulator tile into a row-major LDS image: img[row][col0 + (lane&31)]
+__device__ __forceinline__ void acc_to_lds(const f32x16& acc, float* img, int ld, int col0, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) img[acc_row(reg, h) * ld + col0 + r] = acc[reg];
+}
+
+// phi(x) = elu(x) + 1 with the reference's arithmetic: (exp(x) - 1) + 1 on the negative side
+// (torch.nn.functional.elu(x) + 1, linear_attention.py:10-11)
+__device__ __forceinline__ float elu_plus_one(float x) { return x > 0.f ? x + 1.0f : (expf(x) - 1.0f) + 1.0f; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Row-wise LayerNorm over an LDS image [32][C] (row stride ld).  Wave w of 4 normalises rows
+// 8w..8w+7; two-pass (mean, then centred second moment), biased variance, eps inside the sqrt.
+// AFFINE: y = xhat * gamma + beta.  RELU: max(y, 0) (the keypoint encoder's IN + ReLU).
+template <int C, bool AFFINE, bool RELU>
+__device__ __forceinline__ void rows_layernorm(float* img, int ld, const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, float eps, int wave, int lane) {
+    constexpr int PER = (C + 63) / 64;       // elements per lane
+    for (int rr = 0; rr < 8; ++rr) {
+        float* row = img + (8 * wave + rr) * ld;
+        float v[PER];
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int c = lane + 64 * e;
+            v[e] = (c < C) ? row[c] : 0.f;
+            s += v[e];
+        }
+        const float mean = wave_sum(s) * (1.0f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int c = lane + 64 * e;
+            const float d = (c < C) ? v[e] - mean : 0.f;
+            q += d * d;
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + eps);
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int c = lane + 64 * e;
+            if (c < C) {
+                float y = (v[e] - mean) * rstd;
+                if (AFFINE) y = y * gamma[c] + beta[c];
+                if (RELU) y = fmaxf(y, 0.f);
+                row[c] = y;
+            }
+        }
+    }
+}
+
+#define OPHIP_CHECK_LAUNCH()                         \
+    do {                                             \
+        hipError_t e__ = hipGetLastError();          \
+        if (e__ != hipSuccess) return ophip_fail(e__, __func__); \
+    } while (0)
+
+int ophip_fail(hipError_t e, const char* where);
+int ophip_bad_arg(const char* where, const char* what);
+
+// Optional per-kernel HIP-event timing (bench.py's roofline leg): when `name` is the kernel selected with
+// ophip_timing_select(), the scope records an event pair around the launch on the launch stream.
+struct ophip_timed {
+    ophip_timed(const char* name, hipStream_t s);
+    ~ophip_timed();
+    int slot;
+    hipStream_t stream;
+};
+
+// launch + optional event bracket; NAME is the string ophip_timing_select() matches
+#define OPHIP_LAUNCH(NAME, STREAM, ...)                         \
+    do {                                                        \
+        ophip_timed t__(NAME, (STREAM));                        \
+        hipLaunchKernelGGL(__VA_ARGS__);                        \
+    } while (0)

@@ -1,0 +1,112 @@
+"""ctypes binding of ``libonepose_hip.so`` (include/onepose_hip.h).
+
+The product path has no CPU fallback: if the shared library cannot be loaded, or a
+tensor is not a contiguous float32/int64 CUDA(HIP) tensor, this module raises.
+PyTorch is used for device memory and streams only; every kernel is reached through
+the C ABI with raw device pointers.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libonepose_hip.so")
+_lib = None
+
+c_f = ctypes.c_void_p      # device float*
+c_i = ctypes.c_int
+c_ll = ctypes.c_longlong
+
+_SIGNATURES = {
+    "ophip_abi_version": (c_i, []),
+    "ophip_last_error": (ctypes.c_char_p, []),
+    "ophip_device_info": (c_i, [ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.c_char_p, c_i]),
+    "ophip_timing_select": (c_i, [ctypes.c_char_p]),
+    "ophip_timing_read": (c_i, [ctypes.POINTER(c_i), ctypes.POINTER(ctypes.c_double)]),
+    "ophip_pe_add_transpose": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_void_p]),
+    "ophip_transpose_cl": (c_i, [c_f, c_f, c_i, c_i, c_i, ctypes.c_void_p]),
+    "ophip_kpt_encode": (c_i, [c_f, c_ll, c_f, c_ll, c_f, c_f, c_f, c_i, c_i, ctypes.c_void_p]),
+    "ophip_encoder_workspace_floats": (ctypes.c_size_t, [c_i, c_i, c_i]),
+    "ophip_encoder_layer": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_i, c_f, ctypes.c_void_p]),
+    "ophip_coarse_workspace_floats": (ctypes.c_size_t, [c_i, c_i, c_i]),
+    "ophip_coarse_match": (c_i, [c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_i, ctypes.c_double, ctypes.c_float, c_i, ctypes.c_float,
+                                 c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, ctypes.c_void_p]),
+    "ophip_fine_refine": (c_i, [c_f, c_ll, c_ll, c_ll, c_ll, c_i, c_i, c_f, c_ll, c_ll, c_f, c_f, c_f, c_f, c_i,
+                                c_f, c_f, c_i, ctypes.c_uint, c_i, c_i, c_i, ctypes.c_float, c_f, c_f, c_f, c_f, ctypes.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises ``HipLibraryError`` when the
+    library is missing -- build it with ``python -c 'import __graft_entry__ as g; g.build()'``."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise HipLibraryError(f"{_LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build())")
+    lib = ctypes.CDLL(_LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    if lib.ophip_abi_version() != 1:
+        raise HipLibraryError("libonepose_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, name: str):
+    if rc != 0:
+        msg = load().ophip_last_error().decode(errors="replace")
+        if rc == -1:
+            raise ValueError(f"{name}: {msg}")
+        raise RuntimeError(f"{name} failed (rc={rc}): {msg}")
+
+
+def ptr(t: torch.Tensor | None, dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipLibraryError("the HIP path needs device tensors (no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"expected {dtype}, got {t.dtype}")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_handle():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name: str, *args):
+    rc = getattr(load(), name)(*args)
+    _check(rc, name)
+
+
+def device_info() -> dict:
+    cu, lds = c_i(0), c_i(0)
+    buf = ctypes.create_string_buffer(64)
+    call("ophip_device_info", ctypes.byref(cu), ctypes.byref(lds), buf, 64)
+    return {"cu_count": cu.value, "lds_per_block": lds.value, "arch": buf.value.decode()}
+
+
+def timing_select(kernel_name: str):
+    """Bracket every launch of ``kernel_name`` with HIP events ("" switches timing off)."""
+    call("ophip_timing_select", kernel_name.encode())
+
+
+def timing_read():
+    """-> (launches, total device milliseconds) since the last select/read."""
+    n, ms = c_i(0), ctypes.c_double(0.0)
+    call("ophip_timing_read", ctypes.byref(n), ctypes.byref(ms))
+    return n.value, ms.value

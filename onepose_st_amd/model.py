@@ -1,0 +1,294 @@
+"""Drop-in ``OnePosePlus_model`` whose hot path runs on hand-written gfx950 kernels.
+
+Mirrors the reference interface (``src/models/OnePosePlus/OnePosePlusModel.py:24-203``):
+
+* ``OnePosePlus_model(config, profiler=None, debug=False)`` with the ``model.OnePosePlus``
+  config block; unsupported values raise ``NotImplementedError`` / ``ValueError`` as the
+  reference does.
+* the same ``state_dict`` key layout (195 tensors), so ``build_model`` /
+  ``load_state_dict(strict=True)`` of a reference checkpoint works
+  (``src/inference/inference_OnePosePlus.py:30-40``).
+* ``model(data) -> None`` mutating ``data`` with exactly the keys, dtypes and shapes the
+  reference writes.
+
+The ``nn`` sub-modules below only *hold parameters* under the reference's names; the
+arithmetic of rows a1-a11 is done by ``libonepose_hip.so`` through its C ABI
+(``include/onepose_hip.h``).  The ResNet-FPN backbone stays on PyTorch-ROCm
+(SURVEY.md section 8f-1).  There is no CPU fallback: calling the model without the HIP
+library or with CPU tensors raises.
+"""
+from __future__ import annotations
+
+import contextlib
+import ctypes
+import math
+
+import torch
+import torch.nn as nn
+
+from . import hip, host_math, packing
+from .backbone import build_backbone
+from .config import encoder_layer_names, validate_config
+
+
+class _LayerParams(nn.Module):
+    """Parameter holder with the key layout of ``LoFTREncoderLayer`` (transformer.py:29-52)."""
+
+    def __init__(self, d):
+        super().__init__()
+        self.q_proj = nn.Linear(d, d, bias=False)
+        self.k_proj = nn.Linear(d, d, bias=False)
+        self.v_proj = nn.Linear(d, d, bias=False)
+        self.merge = nn.Linear(d, d, bias=False)
+        self.mlp = nn.Sequential(nn.Linear(2 * d, 2 * d, bias=False), nn.Identity(), nn.Linear(2 * d, d, bias=False))
+        self.norm1 = nn.LayerNorm(d)
+        self.norm2 = nn.LayerNorm(d)
+
+
+class _EncoderParams(nn.Module):
+    """``LocalFeatureTransformer`` parameter holder (transformer.py:100-131)."""
+
+    def __init__(self, enc_cfg):
+        super().__init__()
+        self.layer_names = encoder_layer_names(enc_cfg)
+        self.d_model, self.nhead = enc_cfg["d_model"], enc_cfg["nhead"]
+        self.layers = nn.ModuleList([_LayerParams(self.d_model) for _ in self.layer_names])
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+
+class _KeypointEncoderParams(nn.Module):
+    """``KeypointEncoding_linear`` parameter holder: Linear at indices 0, 3, 6, 9
+    (position_encoding.py:62-79; the norm / ReLU slots carry no parameters)."""
+
+    def __init__(self, inp_dim, feature_dim, layers):
+        super().__init__()
+        chans = [inp_dim] + list(layers) + [feature_dim]
+        mods = []
+        for i in range(1, len(chans)):
+            mods.append(nn.Linear(chans[i - 1], chans[i], bias=True))
+            if i < len(chans) - 1:
+                mods += [nn.Identity(), nn.Identity()]
+        self.encoder = nn.Sequential(*mods)
+        nn.init.constant_(self.encoder[-1].bias, 0.0)
+
+
+class _NullProfiler:
+    @contextlib.contextmanager
+    def record_function(self, name):
+        yield
+
+
+class OnePosePlus_model(nn.Module):
+    def __init__(self, config, profiler=None, debug=False):
+        super().__init__()
+        validate_config(config)
+        self.config = config
+        self.profiler = profiler or _NullProfiler()
+        self.debug = debug
+        cc, cf = config["loftr_coarse"], config["loftr_fine"]
+        if cc["d_model"] != 256 or cc["nhead"] != 8:
+            raise NotImplementedError("HIP coarse encoder is specialised for d_model=256, nhead=8")
+        if cf["d_model"] != 128 or cf["nhead"] != 8 or cf["window_size"] != 5:
+            raise NotImplementedError("HIP fine stage is specialised for d_model=128, nhead=8, window 5")
+
+        self.backbone = build_backbone(config["loftr_backbone"])
+        self.kpt_3d_pos_encoding = None
+        if config["keypoints_encoding"]["enable"]:
+            ke = config["keypoints_encoding"]
+            if ke["descriptor_dim"] != 256 or list(ke["keypoints_encoder"]) != [32, 64, 128]:
+                raise NotImplementedError("HIP keypoint encoder is specialised for 3->32->64->128->256")
+            self.kpt_3d_pos_encoding = _KeypointEncoderParams(3, ke["descriptor_dim"], ke["keypoints_encoder"])
+        self.loftr_coarse = _EncoderParams(cc)
+        self.loftr_fine = _EncoderParams(cf)
+        self._pe_enable = bool(config["positional_encoding"]["enable"])
+        self._pe_shape = tuple(config["positional_encoding"]["pos_emb_shape"])
+        self._packed = None          # (key, dict of device weight blocks)
+        self._pe_cache = {}          # (h, w, device) -> [M, C] device table
+
+        pretrained = config["loftr_backbone"]["pretrained"]
+        if pretrained is not None:
+            # OnePosePlusModel.py:78-93: take the `backbone.*` entries of a LoFTR checkpoint
+            ckpt = torch.load(pretrained, map_location="cpu", weights_only=True)["state_dict"]
+            sub = {k[k.find("backbone") + len("backbone") + 1:]: v for k, v in ckpt.items() if "backbone" in k}
+            self.backbone.load_state_dict(sub)
+            if config["loftr_backbone"]["pretrained_fix"]:
+                for p in self.backbone.parameters():
+                    p.requires_grad = False
+
+    # ------------------------------------------------------------------------------------------
+    # device-side weight blocks (re-packed when parameters change or move)
+    # ------------------------------------------------------------------------------------------
+    def _weights(self, device):
+        params = [p for n, p in self.named_parameters() if not n.startswith("backbone.")]
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
+        if self._packed is not None and self._packed[0] == key:
+            return self._packed[1]
+        sd = {k: v for k, v in self.state_dict().items() if not k.startswith("backbone.")}
+        blocks = {
+            "coarse": [packing.pack_coarse_layer(sd, f"loftr_coarse.layers.{i}.").to(device)
+                       for i in range(len(self.loftr_coarse.layer_names))],
+            "fine": torch.cat([packing.pack_fine_layer(sd, f"loftr_fine.layers.{i}.")
+                               for i in range(len(self.loftr_fine.layer_names))]).to(device),
+        }
+        if self.kpt_3d_pos_encoding is not None:
+            blocks["kpt"] = packing.pack_keypoint_encoder(sd).to(device)
+        self._packed = (key, blocks)
+        return blocks
+
+    def _pe_table(self, h, w, device):
+        k = (h, w, str(device))
+        if k not in self._pe_cache:
+            C = self.config["loftr_coarse"]["d_model"]
+            pe = host_math.sinusoid_table(C, h, w, self._pe_shape)              # [C, h, w]
+            self._pe_cache[k] = pe.flatten(1).t().contiguous().to(device)        # [M, C]
+        return self._pe_cache[k]
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, data):
+        """Same contract as the reference ``forward`` (OnePosePlusModel.py:95-203)."""
+        if self.training:
+            raise NotImplementedError("the HIP path implements inference; call .eval() (training padding "
+                                      "of coarse_matching.py:177-217 is out of scope)")
+        if "query_image_mask" in data or "query_image_scale" in data or "mask0" in data:
+            raise NotImplementedError("query_image_mask / query_image_scale are not supported (img_pad: False path)")
+        data.update({"bs": data["query_image"].size(0), "q_hw_i": data["query_image"].shape[2:]})
+        with torch.no_grad():
+            feat_c, feat_f = self.backbone(data["query_image"])
+        self.forward_features(data, feat_c, feat_f)
+
+    @torch.no_grad()
+    def forward_features(self, data, feat_c, feat_f, image_hw=None, want_fine_debug=False):
+        """The north_star path: everything after the backbone.  ``feat_c [B,256,H/8,W/8]``,
+        ``feat_f [B,128,H/2,W/2]`` (any strides); fills ``data`` like :meth:`forward`."""
+        if not feat_c.is_cuda:
+            raise hip.HipLibraryError("OnePosePlus_model runs on the HIP device only (no CPU fallback): move the "
+                                      "model and its inputs to 'cuda'")
+        hip.load()
+        lib_call, P, S = hip.call, hip.ptr, hip.stream_handle()
+        cfg = self.config
+        dev = feat_c.device
+        if image_hw is not None:
+            data.update({"bs": feat_c.size(0), "q_hw_i": torch.Size(image_hw)})
+        B, C, hc, wc = feat_c.shape
+        hf, wf = feat_f.shape[2:]
+        M = hc * wc
+        data.update({"q_hw_c": feat_c.shape[2:], "q_hw_f": feat_f.shape[2:]})
+        W = self._weights(dev)
+        kpts = data["keypoints3d"]
+        desc_fine = data["descriptors3d_db"]
+        desc_in = data["descriptors3d_coarse_db"] if "descriptors3d_coarse_db" in data else desc_fine
+        N = kpts.shape[1]
+        f32 = dict(device=dev, dtype=torch.float32)
+
+        def dense(t):
+            return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+        def bstride(t):          # batch stride in elements; expanded (shared) object blocks give 0
+            return 0 if t.shape[0] == 1 or t.stride(0) == 0 else t.stride(0)
+
+        def per_frame(t):        # [B or 1, ...] dense per frame, without materialising an expand()
+            if t.stride(0) == 0 and t.shape[0] > 1:
+                t = t[:1]
+            return dense(t)
+
+        kpts_d, desc_in_d, desc_fine_d = per_frame(kpts), per_frame(desc_in), per_frame(desc_fine)
+        for t, name in ((kpts_d, "keypoints3d"), (desc_in_d, "descriptors3d"), (desc_fine_d, "descriptors3d_db")):
+            if t.shape[0] not in (1, B):
+                raise ValueError(f"{name}: batch {t.shape[0]} does not match the query batch {B}")
+
+        # ---- a1: positional encoding + flatten ------------------------------------------------
+        x2d = torch.empty(B, M, C, **f32)
+        pe = self._pe_table(hc, wc, dev) if self._pe_enable else None
+        lib_call("ophip_pe_add_transpose", P(dense(feat_c)), P(pe), P(x2d), B, C, M, S)
+        # ---- a2 + a3: keypoint encoding ---------------------------------------------------------
+        x3d = torch.empty(B, N, C, **f32)
+        if self.kpt_3d_pos_encoding is not None:
+            stats = torch.empty(4 * B + 4, **f32)
+            lib_call("ophip_kpt_encode", P(kpts_d), bstride(kpts_d), P(desc_in_d), bstride(desc_in_d), P(W["kpt"]),
+                     P(stats), P(x3d), B, N, S)
+        else:
+            src = desc_in_d if desc_in_d.shape[0] == B else desc_in_d.expand(B, -1, -1).contiguous()
+            lib_call("ophip_transpose_cl", P(src), P(x3d), B, C, N, S)
+        # ---- a4-a6: coarse encoder ----------------------------------------------------------------
+        ws_floats = hip.load().ophip_encoder_workspace_floats(B, N, M)
+        ws = torch.empty(ws_floats, **f32)
+        y3d, y2d = torch.empty_like(x3d), torch.empty_like(x2d)
+        for li, name in enumerate(self.loftr_coarse.layer_names):
+            lib_call("ophip_encoder_layer", P(x3d), P(x2d), P(y3d), P(y2d), B, N, M, P(W["coarse"][li]),
+                     1 if name == "cross" else 0, P(ws), S)
+            x3d, y3d, x2d, y2d = y3d, x3d, y2d, x2d
+        if self.debug:
+            data["_feat3d_c"], data["_feat2d_c"] = x3d, x2d
+        # ---- a7 + a8: coarse matching -----------------------------------------------------------
+        cm = cfg["coarse_matching"]
+        cap = B * N
+        conf = torch.empty(B, N, M, **f32)
+        cws = torch.empty(hip.load().ophip_coarse_workspace_floats(B, N, M), **f32)
+        i64 = dict(device=dev, dtype=torch.int64)
+        b_ids, i_ids, j_ids = torch.empty(cap, **i64), torch.empty(cap, **i64), torch.empty(cap, **i64)
+        mconf, mk3d, mkc = torch.empty(cap, **f32), torch.empty(cap, 3, **f32), torch.empty(cap, 2, **f32)
+        count = torch.zeros(1, device=dev, dtype=torch.int32)
+        scale = data["q_hw_i"][0] / hc
+        with self.profiler.record_function("LoFTR/coarse-matching/get_coarse_match"):
+            lib_call("ophip_coarse_match", P(x3d), P(x2d), P(kpts_d), bstride(kpts_d), B, N, M, wc,
+                     float(cm["dual_softmax"]["temperature"]), float(cm["thr"]), int(cm["border_rm"]), float(scale),
+                     P(conf), P(cws), P(b_ids, torch.int64), P(i_ids, torch.int64), P(j_ids, torch.int64),
+                     P(mconf), P(mk3d), P(mkc), P(count, torch.int32), S)
+        data["conf_matrix"] = conf
+
+        fine_on = bool(cfg["fine_matching"]["enable"])
+        if fine_on:
+            # ---- a9-a11: fine refinement (grid sized by capacity, device-side count: no sync yet) ----
+            cf = cfg["loftr_fine"]
+            expec = torch.empty(cap, 3, **f32)
+            mkf = torch.empty(cap, 2, **f32)
+            dbg_w = torch.empty(cap, 25, 128, **f32) if want_fine_debug else None
+            dbg_3 = torch.empty(cap, 128, **f32) if want_fine_debug else None
+            names_f = self.loftr_fine.layer_names
+            cross_bits = sum(1 << i for i, n in enumerate(names_f) if n == "cross")
+            ff = feat_f if feat_f.dtype == torch.float32 else feat_f.float()
+            stride = hf // hc
+            fine_scale = (cf["window_size"] // 2) * (data["q_hw_i"][0] / hf)
+            max_matches = min(cap, B * min(N, M) + 64)      # mutual matches are one per row and (barring exact ties) per column
+            lib_call("ophip_fine_refine", P(ff), ff.stride(0), ff.stride(1), ff.stride(2), ff.stride(3), hf, wf,
+                     P(desc_fine_d), bstride(desc_fine_d), desc_fine_d.stride(1),
+                     P(b_ids, torch.int64), P(i_ids, torch.int64), P(j_ids, torch.int64), P(count, torch.int32), max_matches,
+                     P(mkc), P(W["fine"]), len(names_f), ctypes.c_uint(cross_bits), 1 if cf["enable"] else 0,
+                     wc, stride, float(fine_scale), P(expec), P(mkf), P(dbg_w), P(dbg_3), S)
+
+        K = int(count.item())                       # the one host sync of the frame
+        if fine_on and K > min(cap, B * min(N, M) + 64):
+            raise RuntimeError("more coarse matches than the fine grid covers (exact confidence ties); "
+                               "re-run with a larger grid is not implemented")
+        b_ids, i_ids, j_ids = b_ids[:K], i_ids[:K], j_ids[:K]
+        mconf, mk3d, mkc = mconf[:K], mk3d[:K], mkc[:K]
+        data.update({
+            "b_ids": b_ids, "i_ids": i_ids, "j_ids": j_ids,
+            "gt_mask": mconf == 0, "m_bids": b_ids.clone(),
+            "mkpts_3d_db": mk3d, "mkpts_query_c": mkc, "mconf": mconf,
+        })
+        if not fine_on:
+            data.update({"mkpts_3d_db": data["mkpts_3d_db"], "mkpts_query_f": data["mkpts_query_c"]})
+            return
+        data.update({"W": cfg["loftr_fine"]["window_size"]})
+        if K == 0:
+            data.update({"expec_f": torch.empty(0, 3, device=dev), "mkpts_3d_db": mk3d, "mkpts_query_f": mkc})
+            return
+        data.update({"expec_f": expec[:K], "mkpts_3d_db": mk3d, "mkpts_query_f": mkf[:K]})
+        if want_fine_debug:
+            data["_fine_win"], data["_fine_f3"] = dbg_w[:K], dbg_3[:K]
+
+
+def build_model(model_configs, ckpt_path) -> OnePosePlus_model:
+    """``src/inference/inference_OnePosePlus.py:30-40``: strip the ``matcher.`` prefix, strict
+    load, eval.  The checkpoint is read with ``weights_only=True`` (nothing from the file is
+    executed)."""
+    model = OnePosePlus_model(model_configs)
+    state_dict = torch.load(ckpt_path, map_location="cpu", weights_only=True)["state_dict"]
+    for k in list(state_dict.keys()):
+        state_dict[k.replace("matcher.", "")] = state_dict.pop(k)
+    model.load_state_dict(state_dict, strict=True)
+    model.eval()
+    return model

@@ -1,0 +1,72 @@
+"""Host-side packing of the reference ``state_dict`` into the HIP kernels' weight blocks.
+
+Fragment order (csrc/tile.h): a ``Linear`` weight ``W[out][in]`` (torch layout,
+``y = x W^T``) becomes ``[out/32][in/8][lane = 32*h + out%32][j] = W[out][8*kb + 4*h + j]``
+so that one wave's load of a 32x8 weight fragment is 1 KiB contiguous and each lane
+holds the B operand of four consecutive ``v_mfma_f32_32x32x2_f32``.
+
+Blocks (all float32, concatenated flat):
+
+* coarse layer (d=256), ``ophip_encoder_layer``:
+  ``Wq | Wkv | Wm | W0 | W2 | norm1.w norm1.b norm2.w norm2.b`` where ``Wkv`` stacks, per
+  wave w = 0..3, ``Wk[64w:64w+64]`` then ``Wv[64w:64w+64]`` (a wave owns heads 2w, 2w+1).
+* fine layer (d=128), ``ophip_fine_refine``: ``Wqkv | Wm | W0 | W2 | ln`` where ``Wqkv``
+  stacks per wave ``Wq[32w:32w+32] | Wk[32w:32w+32] | Wv[32w:32w+32]``.
+* keypoint encoder, ``ophip_kpt_encode``: ``W1 (K padded 3->8) | W2 | W3 | W4 | b1 b2 b3 b4``.
+
+State-dict keys follow the reference (SURVEY.md section 8b;
+``loftr_module/transformer.py:29-52``, ``utils/position_encoding.py:62-79``).
+"""
+from __future__ import annotations
+
+import torch
+
+
+def pack_linear(w: torch.Tensor) -> torch.Tensor:
+    """``[out, in]`` -> flat fragment order; ``out % 32 == 0`` and ``in % 8 == 0``."""
+    out_f, in_f = w.shape
+    if out_f % 32 or in_f % 8:
+        raise ValueError(f"pack_linear: shape {tuple(w.shape)} is not a multiple of (32, 8)")
+    w = w.detach().to(torch.float32).cpu().contiguous()
+    return w.view(out_f // 32, 32, in_f // 8, 2, 4).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+
+
+def _ln(sd, p):
+    return [sd[p + k].detach().float().cpu().reshape(-1) for k in ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias")]
+
+
+def pack_coarse_layer(sd: dict, prefix: str) -> torch.Tensor:
+    """``prefix`` like ``"loftr_coarse.layers.0."``; d_model 256, 8 heads."""
+    wk, wv = sd[prefix + "k_proj.weight"], sd[prefix + "v_proj.weight"]
+    if tuple(wk.shape) != (256, 256):
+        raise ValueError("coarse encoder kernels are specialised for d_model = 256")
+    wkv = torch.cat([torch.cat([wk[64 * w:64 * w + 64], wv[64 * w:64 * w + 64]], 0) for w in range(4)], 0)
+    parts = [pack_linear(sd[prefix + "q_proj.weight"]), pack_linear(wkv), pack_linear(sd[prefix + "merge.weight"]),
+             pack_linear(sd[prefix + "mlp.0.weight"]), pack_linear(sd[prefix + "mlp.2.weight"])] + _ln(sd, prefix)
+    out = torch.cat(parts)
+    assert out.numel() == 10 * 256 * 256 + 4 * 256
+    return out
+
+
+def pack_fine_layer(sd: dict, prefix: str) -> torch.Tensor:
+    """``prefix`` like ``"loftr_fine.layers.0."``; d_model 128, 8 heads."""
+    wq, wk, wv = (sd[prefix + n + ".weight"] for n in ("q_proj", "k_proj", "v_proj"))
+    if tuple(wq.shape) != (128, 128):
+        raise ValueError("fine encoder kernel is specialised for d_model = 128")
+    wqkv = torch.cat([torch.cat([m[32 * w:32 * w + 32] for m in (wq, wk, wv)], 0) for w in range(4)], 0)
+    parts = [pack_linear(wqkv), pack_linear(sd[prefix + "merge.weight"]), pack_linear(sd[prefix + "mlp.0.weight"]),
+             pack_linear(sd[prefix + "mlp.2.weight"])] + _ln(sd, prefix)
+    out = torch.cat(parts)
+    assert out.numel() == 10 * 128 * 128 + 4 * 128
+    return out
+
+
+def pack_keypoint_encoder(sd: dict, prefix: str = "kpt_3d_pos_encoding.encoder.") -> torch.Tensor:
+    ids = sorted({int(k[len(prefix):].split(".")[0]) for k in sd if k.startswith(prefix)})
+    ws = [sd[f"{prefix}{i}.weight"].detach().float().cpu() for i in ids]
+    bs = [sd[f"{prefix}{i}.bias"].detach().float().cpu().reshape(-1) for i in ids]
+    if [tuple(w.shape) for w in ws] != [(32, 3), (64, 32), (128, 64), (256, 128)]:
+        raise NotImplementedError("keypoint encoder kernel is specialised for 3->32->64->128->256")
+    w1 = torch.zeros(32, 8)
+    w1[:, :3] = ws[0]
+    return torch.cat([pack_linear(w1), pack_linear(ws[1]), pack_linear(ws[2]), pack_linear(ws[3])] + bs)
