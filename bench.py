@@ -1,0 +1,219 @@
+"""Benchmark of the 2D-3D matching hot path (BASELINE.json metric: query frames/sec @ 7k x 4800, d256).
+
+    python bench.py --gpus N --steps K --warmup W [--batch B] [--workload c2|c1|c4] [--no-cpu-baseline]
+
+One process per GPU (``torch.distributed.run`` for N > 1, RCCL).  A *step* is one pass of the hot path over
+one batch of ``--batch`` frames (default 1) whose inputs are already resident in HBM: backbone-output feature
+maps of a frame (``feat_c [B,256,60,80]``, ``feat_f [B,128,240,320]``) + the shared 3D object block -> match
+indices, confidences and sub-pixel keypoints (rows a1-a11 of SURVEY.md section 8a; the ResNet backbone and PnP
+are outside the timed region).  Frames shard across ranks with no data-path collective: rank 0
+builds weights + the 3D object block and broadcasts them once (RCCL) before the timed region; every rank then
+matches its own frames ("scaling": "weak").
+
+Rank 0 prints ONE JSON line with the driver's contract fields plus
+  "roofline"      dominant kernel (attn_apply: fused Q-proj + linear attention + merge + MLP + 2 LayerNorms),
+                  algorithmic FLOPs per launch / average launch duration from HIP events recorded around every
+                  launch of that kernel inside the timed region, against the dense f32 MFMA peak
+  "cpu_baseline"  the oracle (CPU restatement of the reference, torch fp32) timed on this box's host cores on a
+                  bounded sample of the same workload (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from onepose_st_amd import hip  # noqa: E402
+from onepose_st_amd.config import default_config  # noqa: E402
+from onepose_st_amd.model import OnePosePlus_model  # noqa: E402
+from onepose_st_amd.synthetic import CONFIG_SIZES, make_synthetic_inputs, make_synthetic_state_dict  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32 matrix peak (v_mfma_f32_32x32x2_f32)
+OBJ_KEYS = ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db")
+
+
+def attn_apply_flops(n_tokens: int, C: int = 256, D: int = 32) -> float:
+    """Algorithmic FLOPs of one attn_apply launch: per token q_proj 2C^2 + merge 2C^2 + mlp0 2(2C)(2C) +
+    mlp2 2(2C)C = 16 C^2, plus phi(Q) KV: 2 C D  (SURVEY.md section 8a row a5)."""
+    return float(n_tokens) * (16.0 * C * C + 2.0 * C * D)
+
+
+def broadcast_object_block(sd: dict, obj: dict, rank: int, world: int, dev):
+    """One RCCL broadcast of (weights, 3D object block) from rank 0 -- the only collective of the job."""
+    import torch.distributed as dist
+
+    names = sorted(sd) + list(OBJ_KEYS)
+    tensors = [sd[k] for k in sorted(sd)] + [obj[k] for k in OBJ_KEYS]
+    flat = torch.cat([t.reshape(-1).float() for t in tensors]).to(dev)
+    if rank != 0:
+        flat.zero_()
+    dist.broadcast(flat, src=0)
+    out, off = {}, 0
+    for name, t in zip(names, tensors):
+        n = t.numel()
+        out[name] = flat[off:off + n].view(t.shape).to(t.dtype)
+        off += n
+    return {k: out[k].cpu() for k in sorted(sd)}, {k: out[k] for k in OBJ_KEYS}, flat.numel() * 4
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1, help="frames per step")
+    ap.add_argument("--workload", default="c2", choices=sorted(CONFIG_SIZES))
+    ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames per rank (cycled)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    hip.load()
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = default_config()
+    n_points, image_hw, n_plant = CONFIG_SIZES[args.workload]
+    H, W = image_hw
+    M = (H // 8) * (W // 8)
+    B = args.batch
+
+    # ---- weights + the shared 3D object block: built on rank 0, broadcast once ----------------------
+    sd = make_synthetic_state_dict(0, cfg)
+    first = make_synthetic_inputs(sd, n_points, image_hw, n_plant, seed=1, config=cfg, frame=0)
+    bcast_bytes = 0
+    if world > 1:
+        sd, obj, bcast_bytes = broadcast_object_block(sd, first, rank, world, dev)
+    else:
+        obj = {k: first[k].to(dev) for k in OBJ_KEYS}
+    model = OnePosePlus_model(cfg).eval()
+    model.load_state_dict(sd, strict=True)
+    model.to(dev)
+
+    # ---- this rank's frames (frame ids are disjoint across ranks) --------------------------------
+    frames = []
+    for f in range(args.frames):
+        fid = rank * args.frames + f
+        inp = first if fid == 0 else make_synthetic_inputs(sd, n_points, image_hw, n_plant, seed=1, config=cfg, frame=fid)
+        frames.append((inp["feat_c"].to(dev), inp["feat_f"].to(dev)))
+    batches = []
+    for s in range(args.frames):
+        idx = [(s + k) % args.frames for k in range(B)]
+        batches.append((torch.cat([frames[i][0] for i in idx]), torch.cat([frames[i][1] for i in idx])))
+    obj_b = {k: v.expand(B, *v.shape[1:]) for k, v in obj.items()}
+
+    def step(i):
+        fc, ff = batches[i % len(batches)]
+        data = dict(obj_b)
+        model.forward_features(data, fc, ff, image_hw)
+        return data
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        last = step(i)
+    n_matches = int(last["i_ids"].numel()) if args.warmup else -1
+
+    hip.timing_select("attn_apply")
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    sync_all()
+    dt = time.perf_counter() - t0
+    launches, kern_ms = hip.timing_read()
+    hip.timing_select("")
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    frames_total = world * args.steps * B
+    value = frames_total / dt
+    avg_ms = kern_ms / max(launches, 1)
+    flops = attn_apply_flops(B * (n_points + M))
+    achieved = flops / (avg_ms * 1e-3) / 1e12 if launches else 0.0
+
+    result = {
+        "metric": "query frames/sec (2D-3D match+PnP) @ 7k x 4800 d256; 1/2/4/8 GPU",
+        "value": value,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.workload}: {n_points} 3D points x {M} 2D cells ({H}x{W} image), d256 coarse / d128 fine, "
+                        f"{n_plant} planted matches per frame, {B} frame(s) per step, feature-boundary inputs resident in HBM",
+            "frames_per_step": B,
+            "matches_per_frame": n_matches // max(B, 1),
+            "timed_region": "rows a1-a11 (PE, keypoint encoding, 6-layer coarse encoder, dual-softmax + mutual-NN incl. the "
+                            "N x M conf_matrix write, fine refinement); backbone and host PnP outside",
+            "parallelism": f"frames sharded over {world} rank(s), one RCCL broadcast of weights + 3D block ({bcast_bytes} B)",
+        },
+        "roofline": {
+            "kernel": "attn_apply_kernel",
+            "bound": "mfma",
+            "achieved": achieved,
+            "peak": F32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+            "traffic": None,
+            "launches": launches,
+            "avg_launch_ms": avg_ms,
+            "flops_per_launch": flops,
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import onepose_oracle as orc          # cpu_baseline leg only
+
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        with torch.no_grad():
+            orc.forward_from_features(sd, cfg, first, first["feat_c"], first["feat_f"], image_hw)     # warm-up
+            n, t0c = 0, time.perf_counter()
+            while n < 8 and (time.perf_counter() - t0c) < args.cpu_seconds:
+                orc.forward_from_features(sd, cfg, first, first["feat_c"], first["feat_f"], image_hw)
+                n += 1
+            dtc = time.perf_counter() - t0c
+        result["cpu_baseline"] = {
+            "value": n / dtc, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} frame(s) of the same {args.workload} workload (feature boundary, B=1) after 1 warm-up, torch fp32 "
+                      f"CPU oracle, {cores} threads",
+        }
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
