@@ -33,34 +33,36 @@ sys.path.insert(0, REPO)
 from onepose_st_amd import hip  # noqa: E402
 from onepose_st_amd.config import default_config  # noqa: E402
 from onepose_st_amd.model import OnePosePlus_model  # noqa: E402
+from onepose_st_amd.sharding import OBJECT_KEYS as OBJ_KEYS, broadcast_object_block, frame_chunk  # noqa: E402
 from onepose_st_amd.synthetic import CONFIG_SIZES, make_synthetic_inputs, make_synthetic_state_dict  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32 matrix peak (v_mfma_f32_32x32x2_f32)
-OBJ_KEYS = ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db")
+
+
+def host_cores() -> int:
+    """CPU threads this job may really use: the cgroup CPU quota or the affinity mask, not the machine's core
+    count (a GPU box exposes 256 logical CPUs but a one-GPU job owns a 16-core share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, min(n, int(os.environ.get("OPHIP_CPU_THREADS", "16"))))
 
 
 def attn_apply_flops(n_tokens: int, C: int = 256, D: int = 32) -> float:
     """Algorithmic FLOPs of one attn_apply launch: per token q_proj 2C^2 + merge 2C^2 + mlp0 2(2C)(2C) +
     mlp2 2(2C)C = 16 C^2, plus phi(Q) KV: 2 C D  (SURVEY.md section 8a row a5)."""
     return float(n_tokens) * (16.0 * C * C + 2.0 * C * D)
-
-
-def broadcast_object_block(sd: dict, obj: dict, rank: int, world: int, dev):
-    """One RCCL broadcast of (weights, 3D object block) from rank 0 -- the only collective of the job."""
-    import torch.distributed as dist
-
-    names = sorted(sd) + list(OBJ_KEYS)
-    tensors = [sd[k] for k in sorted(sd)] + [obj[k] for k in OBJ_KEYS]
-    flat = torch.cat([t.reshape(-1).float() for t in tensors]).to(dev)
-    if rank != 0:
-        flat.zero_()
-    dist.broadcast(flat, src=0)
-    out, off = {}, 0
-    for name, t in zip(names, tensors):
-        n = t.numel()
-        out[name] = flat[off:off + n].view(t.shape).to(t.dtype)
-        off += n
-    return {k: out[k].cpu() for k in sorted(sd)}, {k: out[k] for k in OBJ_KEYS}, flat.numel() * 4
 
 
 def main():
@@ -98,7 +100,7 @@ def main():
     first = make_synthetic_inputs(sd, n_points, image_hw, n_plant, seed=1, config=cfg, frame=0)
     bcast_bytes = 0
     if world > 1:
-        sd, obj, bcast_bytes = broadcast_object_block(sd, first, rank, world, dev)
+        sd, obj, bcast_bytes = broadcast_object_block(sd, first, dev)
     else:
         obj = {k: first[k].to(dev) for k in OBJ_KEYS}
     model = OnePosePlus_model(cfg).eval()
@@ -107,8 +109,7 @@ def main():
 
     # ---- this rank's frames (frame ids are disjoint across ranks) --------------------------------
     frames = []
-    for f in range(args.frames):
-        fid = rank * args.frames + f
+    for fid in frame_chunk(world * args.frames, rank, world):
         inp = first if fid == 0 else make_synthetic_inputs(sd, n_points, image_hw, n_plant, seed=1, config=cfg, frame=fid)
         frames.append((inp["feat_c"].to(dev), inp["feat_f"].to(dev)))
     batches = []
@@ -194,7 +195,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import onepose_oracle as orc          # cpu_baseline leg only
 
-        cores = os.cpu_count() or 1
+        cores = host_cores()
         torch.set_num_threads(cores)
         with torch.no_grad():
             orc.forward_from_features(sd, cfg, first, first["feat_c"], first["feat_f"], image_hw)     # warm-up

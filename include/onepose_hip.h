@@ -27,7 +27,7 @@ const char* ophip_last_error(void);
 int ophip_device_info(int* cu_count, int* lds_per_block, char* arch, int arch_len);
 
 /* Measurement hook (bench.py): select one kernel by name ("attn_apply", "kv_reduce", "kv_sum", "sim_stats",
- * "stat_combine", "conf", "colmax", "select", "fine_refine", "pe_add_transpose", "kpt_stats", "kpt_encode"; "" = off).
+ * "stat_combine", "conf", "select", "fine_refine", "pe_add_transpose", "kpt_stats", "kpt_encode"; "" = off).
  * While selected, every launch of that kernel is bracketed by a hipEvent pair on its launch stream (at most 8192
  * launches between reads).  ophip_timing_read() synchronises those events, returns the launch count and the summed
  * device time, and clears the log. */

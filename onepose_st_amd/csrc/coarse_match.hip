@@ -8,8 +8,8 @@
 //                 writes S into the conf buffer and per-tile (max, sum exp) for rows and columns
 //   stat_combine  online-softmax merge of the partials -> row (max, sum), column (max, sum)
 //   conf          in-place S -> conf, coalesced 16 B/lane streaming (HBM-bound); per row the best
-//                 (value, lowest j, tie count) and per column the best value, as partials
-//   colmax        column maxima from the row-block partials
+//                 (value, lowest j, tie count) as partials; column maxima by integer atomicMax on the
+//                 float bits (max is order independent => still deterministic)
 //   select        threshold (strict >), border removal (top/left only: the reference's `-b:0` slices are
 //                 empty), mutual test, first-true-j semantics on exact ties, compaction in ascending (b, i)
 #include "tile.h"
@@ -183,40 +183,50 @@ __global__ __launch_bounds__(256) void sim_stats_kernel(SimArgs p) {
 struct CombineArgs {
     const float *rowpart, *colpart;
     float *rowstat, *colstat;     // [B][N][2], [B][M][2]
+    unsigned* colmax_bits;        // [B][M], cleared here for the conf pass's atomicMax
     int N, M, ntr, ntc;
 };
 
+// 8 lanes per row / column: lane q merges partials q, q+8, ... in order, then the 8 are merged by an xor
+// butterfly whose operand order is fixed (lower lane first), so the result is deterministic.
 __global__ __launch_bounds__(256) void stat_combine_kernel(CombineArgs p) {
-    const int idx = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (idx < p.N) {
-        float m = -INFINITY, e = 0.f;
-        for (int t = 0; t < p.ntc; ++t) {
-            const float* q = p.rowpart + (((size_t)b * p.ntc + t) * p.N + idx) * 2;
-            merge_ms(m, e, q[0], q[1]);
+    const int gid = blockIdx.x * 32 + (threadIdx.x >> 3), q = threadIdx.x & 7, b = blockIdx.y;
+    const bool is_row = gid < p.N;
+    const int idx = is_row ? gid : gid - p.N;
+    const bool live = gid < p.N + p.M;
+    const int np = is_row ? p.ntc : p.ntr, len = is_row ? p.N : p.M;
+    const float* part = is_row ? p.rowpart : p.colpart;
+    float m = -INFINITY, e = 0.f;
+    if (live)
+        for (int t = q; t < np; t += 8) {
+            const float* v = part + (((size_t)b * np + t) * len + idx) * 2;
+            merge_ms(m, e, v[0], v[1]);
         }
-        p.rowstat[((size_t)b * p.N + idx) * 2] = m;
-        p.rowstat[((size_t)b * p.N + idx) * 2 + 1] = e;
-    } else if (idx < p.N + p.M) {
-        const int j = idx - p.N;
-        float m = -INFINITY, e = 0.f;
-        for (int t = 0; t < p.ntr; ++t) {
-            const float* q = p.colpart + (((size_t)b * p.ntr + t) * p.M + j) * 2;
-            merge_ms(m, e, q[0], q[1]);
-        }
-        p.colstat[((size_t)b * p.M + j) * 2] = m;
-        p.colstat[((size_t)b * p.M + j) * 2 + 1] = e;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        const float m2 = __shfl_xor(m, o, 64), e2 = __shfl_xor(e, o, 64);
+        float ma = m, ea = e, mb = m2, eb = e2;
+        if (q & o) { ma = m2; ea = e2; mb = m; eb = e; }     // lower lane's value first on both sides
+        merge_ms(ma, ea, mb, eb);
+        m = ma; e = ea;
+    }
+    if (live && q == 0) {
+        float* o = (is_row ? p.rowstat : p.colstat) + ((size_t)b * len + idx) * 2;
+        o[0] = m; o[1] = e;
+        if (!is_row) p.colmax_bits[(size_t)b * p.M + idx] = 0u;
     }
 }
 
 struct ConfArgs {
     float* conf;
     const float *rowstat, *colstat;
-    float* rowbest;      // [B][nspan][N][3]  (value, j as float bits, tie count as float bits)
-    float* colbest;      // [B][nrb][M]
+    float* rowbest;          // [B][nspan][N][3]  (value, j as float bits, tie count as float bits)
+    unsigned* colmax_bits;   // [B][M] column maxima as float bits (conf >= 0, so unsigned order == float order)
     int N, M, nspan, spanw, nrb;
 };
 
-constexpr int CONF_ROWS = 32;
+constexpr int CONF_ROWS = 16;      // rows per workgroup
+constexpr int CONF_RB = 4;         // rows in flight per thread (independent 16 B loads)
 constexpr int CONF_U = 4;          // float4 groups per thread per row  => span <= 4096 columns
 
 template <bool VEC>
@@ -232,66 +242,82 @@ __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
     const float* cst = p.colstat + (size_t)b * p.M * 2;
     const float* rst = p.rowstat + (size_t)b * p.N * 2;
 
-    float cm[CONF_U][4], cs[CONF_U][4], cbest[CONF_U][4];
+    float cm[CONF_U][4], cinv[CONF_U][4], cbest[CONF_U][4];
 #pragma unroll
     for (int u = 0; u < CONF_U; ++u)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int j = jb + 4 * tid + 1024 * u + e;
             cm[u][e] = (j < je) ? cst[2 * j] : 0.f;
-            cs[u][e] = (j < je) ? cst[2 * j + 1] : 1.f;
+            cinv[u][e] = (j < je) ? 1.0f / cst[2 * j + 1] : 1.f;
             cbest[u][e] = 0.f;
         }
     const int nrows = min(CONF_ROWS, p.N - i0);
-    for (int rr = 0; rr < nrows; ++rr) {
-        const int i = i0 + rr;
-        const float rm = rst[2 * i], rs = rst[2 * i + 1];
-        float* row = conf + (size_t)i * p.M;
-        float bv = -1.f;
-        int bj = 0x7fffffff, bc = 0;
+    for (int r0 = 0; r0 < nrows; r0 += CONF_RB) {
+        // issue the loads of up to CONF_RB rows before touching any of them
+        float s[CONF_RB][CONF_U][4];
 #pragma unroll
-        for (int u = 0; u < CONF_U; ++u) {
-            const int jq = jb + 4 * tid + 1024 * u;
-            if (jq >= je) continue;
-            float s[4];
-            if (VEC) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(row + jq);
-                s[0] = v[0]; s[1] = v[1]; s[2] = v[2]; s[3] = v[3];
-            } else {
+        for (int q = 0; q < CONF_RB; ++q) {
+            const int rr = min(r0 + q, nrows - 1);
+            const float* row = conf + (size_t)(i0 + rr) * p.M;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) s[e] = (jq + e < je) ? row[jq + e] : 0.f;
-            }
+            for (int u = 0; u < CONF_U; ++u) {
+                const int jq = jb + 4 * tid + 1024 * u;
+                if (VEC) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (jq < je) v = *reinterpret_cast<const f32x4*>(row + jq);
+                    s[q][u][0] = v[0]; s[q][u][1] = v[1]; s[q][u][2] = v[2]; s[q][u][3] = v[3];
+                } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                // softmax over the 3D axis (dim=1, column stats) times softmax over the 2D axis (dim=2, row stats)
-                const float pc = expf(s[e] - cm[u][e]) / cs[u][e];
-                const float pr = expf(s[e] - rm) / rs;
-                const float c = pc * pr;
-                s[e] = c;
-                if (jq + e < je) {
-                    cbest[u][e] = fmaxf(cbest[u][e], c);
-                    if (c > bv) { bv = c; bj = jq + e; bc = 1; }
-                    else if (c == bv) { bc += 1; bj = min(bj, jq + e); }
+                    for (int e = 0; e < 4; ++e) s[q][u][e] = (jq + e < je) ? row[jq + e] : 0.f;
                 }
             }
-            if (VEC) {
-                f32x4 v = {s[0], s[1], s[2], s[3]};
-                *reinterpret_cast<f32x4*>(row + jq) = v;
-            } else {
+        }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (jq + e < je) row[jq + e] = s[e];
+        for (int q = 0; q < CONF_RB; ++q) {
+            const int rr = r0 + q;
+            if (rr < nrows) {
+                const int i = i0 + rr;
+                const float rm = rst[2 * i], rinv = 1.0f / rst[2 * i + 1];
+                float* row = conf + (size_t)i * p.M;
+                float bv = -1.f;
+                int bj = 0x7fffffff, bc = 0;
+#pragma unroll
+                for (int u = 0; u < CONF_U; ++u) {
+                    const int jq = jb + 4 * tid + 1024 * u;
+                    if (jq < je) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            // softmax over the 3D axis (dim=1: column stats) times softmax over the 2D axis (dim=2: row stats)
+                            const float c = (expf(s[q][u][e] - cm[u][e]) * cinv[u][e]) * (expf(s[q][u][e] - rm) * rinv);
+                            s[q][u][e] = c;
+                            if (jq + e < je) {
+                                cbest[u][e] = fmaxf(cbest[u][e], c);
+                                if (c > bv) { bv = c; bj = jq + e; bc = 1; }
+                                else if (c == bv) { bc += 1; bj = min(bj, jq + e); }
+                            }
+                        }
+                        if (VEC) {
+                            f32x4 v = {s[q][u][0], s[q][u][1], s[q][u][2], s[q][u][3]};
+                            *reinterpret_cast<f32x4*>(row + jq) = v;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (jq + e < je) row[jq + e] = s[q][u][e];
+                        }
+                    }
+                }
+                // wave reduce: max value, lowest j among the maxima, number of maxima
+                const float wv = wave_max(bv);
+                int cj = (bv == wv) ? bj : 0x7fffffff;
+                int cc = (bv == wv) ? bc : 0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    cj = min(cj, __shfl_xor(cj, o, 64));
+                    cc += __shfl_xor(cc, o, 64);
+                }
+                if (lane == 0) { red_v[wave][rr] = wv; red_j[wave][rr] = cj; red_c[wave][rr] = cc; }
             }
         }
-        // wave reduce: max value, lowest j among the maxima, number of maxima
-        const float wv = wave_max(bv);
-        int cj = (bv == wv) ? bj : 0x7fffffff;
-        int cc = (bv == wv) ? bc : 0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            cj = min(cj, __shfl_xor(cj, o, 64));
-            cc += __shfl_xor(cc, o, 64);
-        }
-        if (lane == 0) { red_v[wave][rr] = wv; red_j[wave][rr] = cj; red_c[wave][rr] = cc; }
     }
     __syncthreads();
     if (tid < nrows) {
@@ -306,28 +332,15 @@ __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
         float* o = p.rowbest + (((size_t)b * p.nspan + span) * p.N + i0 + tid) * 3;
         o[0] = v; o[1] = __int_as_float(j); o[2] = __int_as_float(c);
     }
-    float* cb = p.colbest + ((size_t)b * p.nrb + rb) * p.M;
+    // column maxima: max is order independent, so an integer atomicMax on the float bits is deterministic
+    unsigned* cb = p.colmax_bits + (size_t)b * p.M;
 #pragma unroll
     for (int u = 0; u < CONF_U; ++u)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int j = jb + 4 * tid + 1024 * u + e;
-            if (j < je) cb[j] = cbest[u][e];
+            if (j < je && cbest[u][e] > 0.f) atomicMax(cb + j, __float_as_uint(cbest[u][e]));
         }
-}
-
-struct ColmaxArgs {
-    const float* colbest;
-    float* colmax;       // [B][M]
-    int M, nrb;
-};
-
-__global__ __launch_bounds__(256) void colmax_kernel(ColmaxArgs p) {
-    const int j = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (j >= p.M) return;
-    float m = 0.f;
-    for (int t = 0; t < p.nrb; ++t) m = fmaxf(m, p.colbest[((size_t)b * p.nrb + t) * p.M + j]);
-    p.colmax[(size_t)b * p.M + j] = m;
 }
 
 struct SelectArgs {
@@ -412,14 +425,13 @@ inline int conf_spanw(int M) { const int ns = conf_nspan(M); return (((M + ns - 
 }  // namespace
 
 extern "C" size_t ophip_coarse_workspace_floats(int B, int N, int M) {
-    const size_t ntr = (N + TM - 1) / TM, ntc = (M + TN - 1) / TN, nrb = (N + CONF_ROWS - 1) / CONF_ROWS;
+    const size_t ntr = (N + TM - 1) / TM, ntc = (M + TN - 1) / TN;
     size_t f = 0;
     f += (size_t)B * ntc * N * 2;          // rowpart
     f += (size_t)B * ntr * M * 2;          // colpart
     f += (size_t)B * N * 2 + (size_t)B * M * 2;     // rowstat, colstat
     f += (size_t)B * conf_nspan(M) * N * 3;         // rowbest
-    f += (size_t)B * nrb * M;              // colbest
-    f += (size_t)B * M;                    // colmax
+    f += (size_t)B * M;                    // colmax (float bits)
     return f + 64;
 }
 
@@ -438,23 +450,19 @@ extern "C" int ophip_coarse_match(const float* feat3d, const float* feat2d, cons
     float* rowstat = colpart + (size_t)B * ntr * M * 2;
     float* colstat = rowstat + (size_t)B * N * 2;
     float* rowbest = colstat + (size_t)B * M * 2;
-    float* colbest = rowbest + (size_t)B * nspan * N * 3;
-    float* colmax = colbest + (size_t)B * nrb * M;
+    float* colmax = rowbest + (size_t)B * nspan * N * 3;
 
     SimArgs sa{feat3d, feat2d, conf, rowpart, colpart, N, M, ntr, ntc, (float)(temperature + 1e-4)};
     OPHIP_LAUNCH("sim_stats", stream, sim_stats_kernel, dim3(ntc, ntr, B), dim3(256), 0, stream, sa);
     OPHIP_CHECK_LAUNCH();
-    CombineArgs ca{rowpart, colpart, rowstat, colstat, N, M, ntr, ntc};
-    OPHIP_LAUNCH("stat_combine", stream, stat_combine_kernel, dim3((N + M + 255) / 256, B), dim3(256), 0, stream, ca);
+    CombineArgs ca{rowpart, colpart, rowstat, colstat, reinterpret_cast<unsigned*>(colmax), N, M, ntr, ntc};
+    OPHIP_LAUNCH("stat_combine", stream, stat_combine_kernel, dim3((N + M + 31) / 32, B), dim3(256), 0, stream, ca);
     OPHIP_CHECK_LAUNCH();
-    ConfArgs fa{conf, rowstat, colstat, rowbest, colbest, N, M, nspan, spanw, nrb};
+    ConfArgs fa{conf, rowstat, colstat, rowbest, reinterpret_cast<unsigned*>(colmax), N, M, nspan, spanw, nrb};
     if (M % 4 == 0)
         OPHIP_LAUNCH("conf", stream, conf_kernel<true>, dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
     else
         OPHIP_LAUNCH("conf", stream, conf_kernel<false>, dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
-    OPHIP_CHECK_LAUNCH();
-    ColmaxArgs ma{colbest, colmax, M, nrb};
-    OPHIP_LAUNCH("colmax", stream, colmax_kernel, dim3((M + 255) / 256, B), dim3(256), 0, stream, ma);
     OPHIP_CHECK_LAUNCH();
     SelectArgs se{conf, rowbest, colmax, keypoints3d, kpts_bstride, B, N, M, nspan, wc, border_rm, thr, scale,
                   b_ids, i_ids, j_ids, mconf, mkpts3d, mkpts_c, count};

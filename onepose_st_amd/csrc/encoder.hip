@@ -94,18 +94,25 @@ struct KvSumArgs {
     int tiles[2];
 };
 
-__global__ __launch_bounds__(256) void kv_sum_kernel(KvSumArgs a) {
-    __shared__ float red[4][64];
+constexpr int KVS_G = 16;      // tile groups per output (1024 threads)
+
+__global__ __launch_bounds__(1024) void kv_sum_kernel(KvSumArgs a) {
+    __shared__ float red[KVS_G][64];
     const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int s = blockIdx.y & 1, b = blockIdx.y >> 1;
     const int ttot = a.tiles[0] + a.tiles[1];
     const int t0 = s ? a.tiles[0] : 0, nt = a.tiles[s];
     const float* p = a.partial + ((size_t)b * ttot + t0) * KV_FLOATS + blockIdx.x * 64 + o;
     float acc = 0.f;
-    for (int t = g; t < nt; t += 4) acc += p[(size_t)t * KV_FLOATS];
+    for (int t = g; t < nt; t += KVS_G) acc += p[(size_t)t * KV_FLOATS];
     red[g][o] = acc;
     __syncthreads();
-    if (g == 0) a.kv[((size_t)b * 2 + s) * KV_FLOATS + blockIdx.x * 64 + o] = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+    if (g == 0) {
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < KVS_G; ++q) tot += red[q][o];       // fixed order
+        a.kv[((size_t)b * 2 + s) * KV_FLOATS + blockIdx.x * 64 + o] = tot;
+    }
 }
 
 struct AttnArgs {
@@ -258,7 +265,7 @@ extern "C" int ophip_encoder_layer(const float* x3d, const float* x2d, float* y3
 
     KvSumArgs sa;
     sa.partial = partial; sa.kv = kv; sa.tiles[0] = t3; sa.tiles[1] = t2;
-    OPHIP_LAUNCH("kv_sum", stream, kv_sum_kernel, dim3(KV_FLOATS / 64, 2 * B), dim3(256), 0, stream, sa);
+    OPHIP_LAUNCH("kv_sum", stream, kv_sum_kernel, dim3(KV_FLOATS / 64, 2 * B), dim3(1024), 0, stream, sa);
     OPHIP_CHECK_LAUNCH();
 
     AttnArgs aa;
