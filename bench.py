@@ -36,7 +36,9 @@ from onepose_st_amd.model import OnePosePlus_model  # noqa: E402
 from onepose_st_amd.sharding import OBJECT_KEYS as OBJ_KEYS, broadcast_object_block, frame_chunk  # noqa: E402
 from onepose_st_amd.synthetic import CONFIG_SIZES, make_synthetic_inputs, make_synthetic_state_dict  # noqa: E402
 
-F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32 matrix peak (v_mfma_f32_32x32x2_f32)
+# MI355X_MICROARCH.md dense matrix peaks: f32 (v_mfma_f32_32x32x2_f32) 157.3 TFLOP/s; bf16 (v_mfma_f32_32x32x16_bf16) 2.5 PFLOP/s.
+# Split-bf16 issues 3 bf16 MFMAs per algorithmic product and is priced against the bf16 peak with 1x algorithmic FLOPs.
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}
 
 
 def host_cores() -> int:
@@ -73,6 +75,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="frames per step")
     ap.add_argument("--workload", default="c2", choices=sorted(CONFIG_SIZES))
     ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames per rank (cycled)")
+    ap.add_argument("--precision", default=os.environ.get("OPHIP_PRECISION", "f32"), choices=["f32", "bf16x3", "bf16"],
+                    help="matrix arithmetic of the encoder kernels (see DESIGN.md section 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
@@ -90,6 +94,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     cfg = default_config()
+    cfg["hip_precision"] = args.precision
     n_points, image_hw, n_plant = CONFIG_SIZES[args.workload]
     H, W = image_hw
     M = (H // 8) * (W // 8)
@@ -167,7 +172,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA, f32 accumulate)", "bf16": "bf16 (f32 accumulate)"}[args.precision],
         "data": "synthetic",
         "config": {
             "workload": f"{args.workload}: {n_points} 3D points x {M} 2D cells ({H}x{W} image), d256 coarse / d128 fine, "
@@ -182,9 +187,9 @@ def main():
             "kernel": "attn_apply_kernel",
             "bound": "mfma",
             "achieved": achieved,
-            "peak": F32_MFMA_PEAK_TFLOPS,
+            "peak": MFMA_PEAK_TFLOPS[args.precision],
             "unit": "TFLOP/s",
-            "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+            "frac": achieved / MFMA_PEAK_TFLOPS[args.precision],
             "traffic": None,
             "launches": launches,
             "avg_launch_ms": avg_ms,

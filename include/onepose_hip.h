@@ -58,6 +58,14 @@ size_t ophip_encoder_workspace_floats(int B, int L3d, int L2d);
 int ophip_encoder_layer(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
                         const float* wpack, int is_cross, float* workspace, void* stream);
 
+/* Same layer on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, f32 accumulate).  nsplit = 1: plain bf16 operands;
+ * nsplit = 3: split-bf16 (x = hi + lo, three MFMAs per product, ~f32-grade results).  wpack: packing.pack_coarse_layer_bf16
+ * (ophip_encoder_bf16_wpack_bytes() bytes); workspace: ophip_encoder_bf16_workspace_bytes() bytes, 256-byte aligned. */
+size_t ophip_encoder_bf16_workspace_bytes(int B, int L3d, int L2d);
+size_t ophip_encoder_bf16_wpack_bytes(void);
+int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
+                             const void* wpack, int nsplit, int is_cross, void* workspace, void* stream);
+
 /* a7 + a8 -- CoarseMatching.forward + get_coarse_match, inference branch
  * (utils/coarse_matching.py:76-123, :125-242, mask_border :10-20).
  * feat3d [B][N][256], feat2d [B][M][256] (encoder outputs), M = hc * wc.

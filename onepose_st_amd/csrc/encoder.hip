@@ -39,7 +39,7 @@ __device__ __forceinline__ void load_x_tile(float* lds, const float* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void kv_reduce_kernel(KvReduceArgs a) {
+__global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void kv_reduce_kernel(KvReduceArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -128,7 +128,7 @@ struct AttnArgs {
     const float *g1, *b1, *g2, *b2;
 };
 
-__global__ __launch_bounds__(256) void attn_apply_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 1) void attn_apply_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X = smem;                         // [32][LDX] layer input tile
     float* P = X + OPHIP_TOK * LDX;          // [32][LDX] phi(Q) -> merge out -> mlp out

@@ -1,0 +1,420 @@
+// Coarse LoFTR encoder layer on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, f32 accumulate), plain or split-bf16
+// (tile_bf16.h).  Same three launches per layer and the same mathematics as csrc/encoder.hip (reference:
+// loftr_module/transformer.py:65-94,146-159, linear_attention.py:29-61); what changes is the mapping to the machine:
+//
+//   * a workgroup owns 64 tokens (two 32-token MFMA tiles): every weight fragment fetched from L2 feeds two tiles,
+//     and one launch at c2 is 185 workgroups = one resident wave of work on 256 CUs;
+//   * operands swap roles in attn_apply: A = packed weights, B = activations, so an accumulator holds
+//     D[feature][token] -- four consecutive features of one token per lane and register quad.  Epilogues therefore
+//     write 8-byte packed bf16 quads into the [token][feature] LDS planes, LayerNorm reduces over registers (plus a
+//     64-float cross-wave exchange), and phi(Q) never leaves registers: the Q accumulator is the B operand of
+//     KV^T . phi(Q)^T (accumulator-as-operand, k order fixed up in how kv_sum emits KV);
+//   * the MLP hidden layer is produced and consumed in four 128-feature chunks, so the three live tiles (x, msg/merge,
+//     hidden chunk) fit the 160 KiB LDS exactly in split mode (swizzled planes, no padding).
+#include "tile_bf16.h"
+
+namespace {
+
+constexpr int C = 256, NH = 8, TOK = 64;
+constexpr int ROWB = C * 2;                 // plane row pitch (bytes)
+constexpr int HROWB = 128 * 2;              // hidden-chunk plane row pitch
+constexpr int KB = C / 16, TS = KB * 64;            // K = 256: 16 k-blocks, fragments per tile
+constexpr int KB2 = 2 * C / 16, TS2 = KB2 * 64;     // K = 512
+constexpr int KV_PART_FLOATS = NH * 2 * 64 * 8 + NH * 32;       // 8448: KV fragments (f32) + Ksum
+constexpr int KV_FRAG_BYTES = NH * 2 * 2 * 64 * 16;             // [head][s][plane][lane][16 B] = 32768
+constexpr int KV_BLOCK_BYTES = KV_FRAG_BYTES + NH * 32 * 4;     // + Ksum f32 [head][h][16] = 33792
+constexpr int W_ELEMS = 10 * C * C;                             // bf16 elements per plane of a layer block
+
+struct KvRedArgs {
+    const float* x[2];
+    long long xbs[2];
+    int L[2];
+    int tiles[2];
+    const bf16x8 *w_hi, *w_lo;      // Wkv fragments
+    float* partial;                 // [B][tiles0 + tiles1][KV_PART_FLOATS]
+};
+
+template <int NS>
+__global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void kv_reduce_bf16_kernel(KvRedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PL = NS == 3 ? 2 : 1;
+    char* XH = smem;
+    char* XL = smem + (PL - 1) * TOK * ROWB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int s = tile >= a.tiles[0] ? 1 : 0;
+    const int lt = s ? tile - a.tiles[0] : tile;
+    const int L = a.L[s], tok0 = lt * TOK;
+    load_rows_to_planes<NS, C, TOK>(XH, XL, a.x[s] + (size_t)b * a.xbs[s], tok0, L, tid, 256);
+    __syncthreads();
+
+    // D[token][feature]: t = 0,1 -> K of heads 2w, 2w+1;  t = 2,3 -> V of the same heads
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) acc[t][tt] = zero16();
+    gemm_bf16<4, 2, NS, false, KB, 4>(acc, a.w_hi + (size_t)(4 * wave) * TS + lane, a.w_lo + (size_t)(4 * wave) * TS + lane, TS,
+                                      XH, XL, ROWB, 0, lane);
+    const float flen = (float)L;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const bool valid = tok0 + 32 * tt + acc_row(reg, h) < L;
+                acc[t][tt][reg] = valid ? elu_plus_one(acc[t][tt][reg]) : 0.f;
+                acc[2 + t][tt][reg] = acc[2 + t][tt][reg] / flen;
+            }
+    bf16x8 ones, zeros = zero_bf8();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    float* out = a.partial + ((size_t)b * (a.tiles[0] + a.tiles[1]) + tile) * KV_PART_FLOATS;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        f32x16 kv = zero16(), ks = zero16();
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                bf16x8 khi, klo, vhi, vlo;
+                acc_frag<NS>(acc[t][tt], st, khi, klo);
+                acc_frag<NS>(acc[2 + t][tt], st, vhi, vlo);
+                kv = mma_bf16<NS>(khi, klo, vhi, vlo, kv);        // KV[d][v] += sum_tok phi(K)[tok][d] V[tok][v]
+                ks = mma_bf16<NS>(khi, klo, ones, zeros, ks);     // Ksum[d] replicated over v
+            }
+        const int head = 2 * wave + t;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            float* o = out + ((size_t)(head * 2 + st) * 64 + lane) * 8;
+            f32x4 v0 = {kv[8 * st], kv[8 * st + 1], kv[8 * st + 2], kv[8 * st + 3]};
+            f32x4 v1 = {kv[8 * st + 4], kv[8 * st + 5], kv[8 * st + 6], kv[8 * st + 7]};
+            *reinterpret_cast<f32x4*>(o) = v0;
+            *reinterpret_cast<f32x4*>(o + 4) = v1;
+        }
+        if (r == 0) {
+            float* o = out + NH * 2 * 64 * 8 + head * 32 + h * 16;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) o[reg] = ks[reg];
+        }
+    }
+}
+
+struct KvSumBArgs {
+    const float* partial;
+    char* kv;              // [B][2][KV_BLOCK_BYTES]
+    int tiles[2];
+};
+
+constexpr int KVS_G = 16;
+
+// fixed-order sum of the per-tile partials; emits KV as (hi, lo) bf16 A-fragments and Ksum as f32
+__global__ __launch_bounds__(1024) void kv_sum_bf16_kernel(KvSumBArgs a) {
+    __shared__ float red[KVS_G][64];
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int s = blockIdx.y & 1, b = blockIdx.y >> 1;
+    const int ttot = a.tiles[0] + a.tiles[1];
+    const int t0 = s ? a.tiles[0] : 0, nt = a.tiles[s];
+    const int e = blockIdx.x * 64 + o;
+    const float* p = a.partial + ((size_t)b * ttot + t0) * KV_PART_FLOATS + e;
+    float acc = 0.f;
+    for (int t = g; t < nt; t += KVS_G) acc += p[(size_t)t * KV_PART_FLOATS];
+    red[g][o] = acc;
+    __syncthreads();
+    if (g == 0) {
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < KVS_G; ++q) tot += red[q][o];
+        char* blk = a.kv + ((size_t)b * 2 + s) * KV_BLOCK_BYTES;
+        if (e < NH * 2 * 64 * 8) {
+            const int j = e & 7, ln = (e >> 3) & 63, hs = e >> 9;      // hs = head * 2 + s
+            __bf16 hh, ll;
+            split_bf16(tot, hh, ll);
+            *reinterpret_cast<__bf16*>(blk + ((size_t)(hs * 2 + 0) * 64 + ln) * 16 + j * 2) = hh;
+            *reinterpret_cast<__bf16*>(blk + ((size_t)(hs * 2 + 1) * 64 + ln) * 16 + j * 2) = ll;
+        } else {
+            reinterpret_cast<float*>(blk + KV_FRAG_BYTES)[e - NH * 2 * 64 * 8] = tot;
+        }
+    }
+}
+
+struct AttnBArgs {
+    const float* x[2];
+    float* y[2];
+    long long xbs[2], ybs[2];
+    int L[2];
+    int tiles[2];
+    const char* kv[2];
+    long long kvbs;            // bytes
+    float srclen[2];
+    const bf16x8 *w_hi, *w_lo; // layer block planes (Wq | Wkv | Wm | W0 | W2)
+    const float* ln;           // g1 b1 g2 b2
+};
+
+// LayerNorm over the feature axis of D[feature][token] accumulators spread over the 4 waves (wave w: features
+// 64w..64w+63).  Two-pass; partial sums cross waves through `scratch` ([2][4][64] floats).  Contains 2 barriers.
+__device__ __forceinline__ void layernorm_featrow(f32x16 (&m)[2][2], const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  float* scratch, int wave, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    float mean[2], rstd[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) s += m[t][tt][reg];
+        s += __shfl_xor(s, 32, 64);
+        if (h == 0) scratch[wave * 64 + 32 * tt + r] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int tok = 32 * tt + r;
+        mean[tt] = ((scratch[tok] + scratch[64 + tok]) + (scratch[128 + tok] + scratch[192 + tok])) * (1.0f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float d = m[t][tt][reg] - mean[tt];
+                q += d * d;
+            }
+        q += __shfl_xor(q, 32, 64);
+        if (h == 0) scratch[256 + wave * 64 + tok] = q;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int tok = 32 * tt + r;
+        const float var = ((scratch[256 + tok] + scratch[320 + tok]) + (scratch[384 + tok] + scratch[448 + tok])) * (1.0f / C);
+        rstd[tt] = 1.0f / sqrtf(var + 1e-5f);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f0 = 64 * wave + 32 * t + 8 * g + 4 * h;
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(gamma + f0);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(beta + f0);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[t][tt][4 * g + j] = (m[t][tt][4 * g + j] - mean[tt]) * rstd[tt] * gv[j] + bv[j];
+        }
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 1) void attn_apply_bf16_kernel(AttnBArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PL = NS == 3 ? 2 : 1;
+    constexpr int XB = TOK * ROWB, HB = TOK * HROWB;
+    char* XH = smem;
+    char* XL = smem + (PL - 1) * XB;
+    char* YH = smem + PL * XB;
+    char* YL = YH + (PL - 1) * XB;
+    char* HH = smem + 2 * PL * XB;
+    char* HL = HH + (PL - 1) * HB;
+    float* scratch = reinterpret_cast<float*>(HH);          // LayerNorm exchange; H is idle whenever a LayerNorm runs
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int s = tile >= a.tiles[0] ? 1 : 0;
+    const int lt = s ? tile - a.tiles[0] : tile;
+    const int L = a.L[s], tok0 = lt * TOK;
+    const float* xg = a.x[s] + (size_t)b * a.xbs[s];
+    load_rows_to_planes<NS, C, TOK>(XH, XL, xg, tok0, L, tid, 256);
+    __syncthreads();
+
+    const bf16x8 *wq_hi = a.w_hi, *wq_lo = a.w_lo;
+    const bf16x8 *wm_hi = a.w_hi + 3 * C * C / 8, *wm_lo = a.w_lo + 3 * C * C / 8;
+    const bf16x8 *w0_hi = a.w_hi + 4 * C * C / 8, *w0_lo = a.w_lo + 4 * C * C / 8;
+    const bf16x8 *w2_hi = a.w_hi + 8 * C * C / 8, *w2_lo = a.w_lo + 8 * C * C / 8;
+
+    // ---- Q projection (this wave: heads 2w, 2w+1), phi, linear attention from registers -------------------
+    {
+        f32x16 q[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) q[t][tt] = zero16();
+        gemm_bf16<2, 2, NS, true, KB, 4>(q, wq_hi + (size_t)(2 * wave) * TS + lane, wq_lo + (size_t)(2 * wave) * TS + lane, TS, XH, XL, ROWB, 0, lane);
+        const char* kvb = a.kv[s] + (size_t)b * a.kvbs;
+        const float* ksum = reinterpret_cast<const float*>(kvb + KV_FRAG_BYTES);
+        const float S = a.srclen[s];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int head = 2 * wave + t;
+            bf16x8 kvh[2], kvl[2], ksh[2], ksl[2];
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                kvh[st] = *reinterpret_cast<const bf16x8*>(kvb + ((size_t)((head * 2 + st) * 2 + 0) * 64 + lane) * 16);
+                kvl[st] = (NS == 3) ? *reinterpret_cast<const bf16x8*>(kvb + ((size_t)((head * 2 + st) * 2 + 1) * 64 + lane) * 16) : zero_bf8();
+                const float* kp = ksum + head * 32 + h * 16 + 8 * st;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    __bf16 hh, ll;
+                    split_bf16(kp[j], hh, ll);
+                    ksh[st][j] = hh;
+                    ksl[st][j] = (NS == 3) ? ll : (__bf16)0.f;
+                }
+            }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) q[t][tt][reg] = elu_plus_one(q[t][tt][reg]);
+                f32x16 num = zero16(), den = zero16();
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    bf16x8 qh, ql;
+                    acc_frag<NS>(q[t][tt], st, qh, ql);
+                    num = mma_bf16<NS>(kvh[st], kvl[st], qh, ql, num);      // num^T[v][tok] = sum_d KV[d][v] phiQ[tok][d]
+                    den = mma_bf16<NS>(ksh[st], ksl[st], qh, ql, den);      // den[tok] replicated over v
+                }
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) num[reg] = num[reg] * (1.0f / (den[reg] + 1e-6f)) * S;
+                store_featrow_acc<NS>(num, YH, YL, ROWB, 32 * head, 32 * tt, lane);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- merge + LayerNorm 1 -> Y ----------------------------------------------------------------
+    {
+        f32x16 m[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) m[t][tt] = zero16();
+        gemm_bf16<2, 2, NS, true, KB, 4>(m, wm_hi + (size_t)(2 * wave) * TS + lane, wm_lo + (size_t)(2 * wave) * TS + lane, TS, YH, YL, ROWB, 0, lane);
+        layernorm_featrow(m, a.ln, a.ln + C, scratch, wave, lane);     // its first barrier also fences the reads of Y above
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) store_featrow_acc<NS>(m[t][tt], YH, YL, ROWB, 64 * wave + 32 * t, 32 * tt, lane);
+    }
+    __syncthreads();
+    // ---- MLP: hidden = relu([x, msg] W0^T) in four 128-feature chunks, o += hidden_chunk W2[:, chunk]^T ---------
+    f32x16 o[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) o[t][tt] = zero16();
+    for (int c = 0; c < 4; ++c) {
+        f32x16 hd[1][2] = {{zero16(), zero16()}};
+        const size_t wt = (size_t)(4 * c + wave) * TS2 + lane;
+        gemm_bf16<1, 2, NS, true, KB, 8>(hd, w0_hi + wt, w0_lo + wt, TS2, XH, XL, ROWB, 0, lane);
+        gemm_bf16<1, 2, NS, true, KB, 8>(hd, w0_hi + wt + (size_t)KB * 64, w0_lo + wt + (size_t)KB * 64, TS2, YH, YL, ROWB, 0, lane);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) hd[0][tt][reg] = fmaxf(hd[0][tt][reg], 0.f);
+            store_featrow_acc<NS>(hd[0][tt], HH, HL, HROWB, 32 * wave, 32 * tt, lane);
+        }
+        __syncthreads();
+        const size_t w2t = (size_t)(2 * wave) * TS2 + (size_t)(8 * c) * 64 + lane;
+        gemm_bf16<2, 2, NS, true, 8, 4>(o, w2_hi + w2t, w2_lo + w2t, TS2, HH, HL, HROWB, 0, lane);
+        __syncthreads();
+    }
+    layernorm_featrow(o, a.ln + 2 * C, a.ln + 3 * C, scratch, wave, lane);
+    // ---- stage LN2 output as f32 [64][256] over the (now dead) X / Y planes, then x + msg with whole-row stores ----
+    float* stage = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int row = 32 * tt + r;
+                const int ch = 16 * wave + 8 * t + 2 * g + h;          // 16-byte chunk of the f32 row
+                f32x4 v = {o[t][tt][4 * g], o[t][tt][4 * g + 1], o[t][tt][4 * g + 2], o[t][tt][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(stage) + row * (C * 4) + ((ch ^ (row & 15)) << 4)) = v;
+            }
+    __syncthreads();
+    float* yg = a.y[s] + (size_t)b * a.ybs[s];
+    for (int i = tid; i < TOK * (C / 4); i += 256) {
+        const int row = i / (C / 4), ch = i % (C / 4);
+        if (tok0 + row < L) {
+            const f32x4 mv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(stage) + row * (C * 4) + ((ch ^ (row & 15)) << 4));
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xg + (size_t)(tok0 + row) * C + 4 * ch);
+            *reinterpret_cast<f32x4*>(yg + (size_t)(tok0 + row) * C + 4 * ch) = xv + mv;
+        }
+    }
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes, const char* what) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return e == hipSuccess ? 0 : ophip_fail(e, what);
+}
+
+}  // namespace
+
+extern "C" size_t ophip_encoder_bf16_workspace_bytes(int B, int L3d, int L2d) {
+    const size_t tiles = (size_t)((L3d + TOK - 1) / TOK + (L2d + TOK - 1) / TOK);
+    return (size_t)B * tiles * KV_PART_FLOATS * 4 + (size_t)B * 2 * KV_BLOCK_BYTES + 256;
+}
+
+extern "C" size_t ophip_encoder_bf16_wpack_bytes(void) { return (size_t)2 * W_ELEMS * 2 + 4 * C * 4; }
+
+extern "C" int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
+                                        const void* wpack, int nsplit, int is_cross, void* workspace, void* stream_) {
+    if (!x3d || !x2d || !y3d || !y2d || !wpack || !workspace) return ophip_bad_arg(__func__, "null pointer");
+    if (B < 1 || L3d < 1 || L2d < 1) return ophip_bad_arg(__func__, "B, L3d, L2d must be >= 1");
+    if (nsplit != 1 && nsplit != 3) return ophip_bad_arg(__func__, "nsplit must be 1 (bf16) or 3 (split bf16)");
+    if (x3d == y3d || x2d == y2d) return ophip_bad_arg(__func__, "in-place layer is not supported (cross layers read the pre-update streams)");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int t3 = (L3d + TOK - 1) / TOK, t2 = (L2d + TOK - 1) / TOK;
+    float* partial = reinterpret_cast<float*>(workspace);
+    char* kv = reinterpret_cast<char*>(workspace) + (size_t)B * (t3 + t2) * KV_PART_FLOATS * 4;
+    kv += (256 - (reinterpret_cast<uintptr_t>(kv) & 255)) & 255;
+    // layer block: [hi plane: Wq | Wkv | Wm | W0 | W2][lo plane: same][g1 b1 g2 b2 f32]   (packing.pack_coarse_layer_bf16)
+    const bf16x8* w_hi = reinterpret_cast<const bf16x8*>(wpack);
+    const bf16x8* w_lo = w_hi + W_ELEMS / 8;
+    const float* ln = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wpack) + (size_t)2 * W_ELEMS * 2);
+    const int PL = nsplit == 3 ? 2 : 1;
+
+    KvRedArgs ka;
+    ka.x[0] = x3d; ka.x[1] = x2d;
+    ka.xbs[0] = (long long)L3d * C; ka.xbs[1] = (long long)L2d * C;
+    ka.L[0] = L3d; ka.L[1] = L2d; ka.tiles[0] = t3; ka.tiles[1] = t2;
+    ka.w_hi = w_hi + C * C / 8; ka.w_lo = w_lo + C * C / 8;
+    ka.partial = partial;
+    const size_t lds_kv = (size_t)PL * TOK * ROWB;
+    static bool attr_kv[2] = {false, false}, attr_at[2] = {false, false};
+    if (nsplit == 3) {
+        if (!attr_kv[1]) { if (int rc = set_lds(kv_reduce_bf16_kernel<3>, lds_kv, "hipFuncSetAttribute(kv_reduce_bf16)")) return rc; attr_kv[1] = true; }
+        OPHIP_LAUNCH("kv_reduce", stream, kv_reduce_bf16_kernel<3>, dim3(t3 + t2, B), dim3(256), lds_kv, stream, ka);
+    } else {
+        if (!attr_kv[0]) { if (int rc = set_lds(kv_reduce_bf16_kernel<1>, lds_kv, "hipFuncSetAttribute(kv_reduce_bf16)")) return rc; attr_kv[0] = true; }
+        OPHIP_LAUNCH("kv_reduce", stream, kv_reduce_bf16_kernel<1>, dim3(t3 + t2, B), dim3(256), lds_kv, stream, ka);
+    }
+    OPHIP_CHECK_LAUNCH();
+
+    KvSumBArgs sa;
+    sa.partial = partial; sa.kv = kv; sa.tiles[0] = t3; sa.tiles[1] = t2;
+    OPHIP_LAUNCH("kv_sum", stream, kv_sum_bf16_kernel, dim3(KV_PART_FLOATS / 64, 2 * B), dim3(1024), 0, stream, sa);
+    OPHIP_CHECK_LAUNCH();
+
+    AttnBArgs aa;
+    aa.x[0] = x3d; aa.x[1] = x2d; aa.y[0] = y3d; aa.y[1] = y2d;
+    aa.xbs[0] = aa.ybs[0] = (long long)L3d * C; aa.xbs[1] = aa.ybs[1] = (long long)L2d * C;
+    aa.L[0] = L3d; aa.L[1] = L2d; aa.tiles[0] = t3; aa.tiles[1] = t2;
+    aa.kv[0] = kv + (is_cross ? KV_BLOCK_BYTES : 0);
+    aa.kv[1] = kv + (is_cross ? 0 : KV_BLOCK_BYTES);
+    aa.kvbs = 2LL * KV_BLOCK_BYTES;
+    aa.srclen[0] = (float)(is_cross ? L2d : L3d);
+    aa.srclen[1] = (float)(is_cross ? L3d : L2d);
+    aa.w_hi = w_hi; aa.w_lo = w_lo; aa.ln = ln;
+    const size_t lds_at = (size_t)PL * (2 * TOK * ROWB + TOK * HROWB);
+    if (nsplit == 3) {
+        if (!attr_at[1]) { if (int rc = set_lds(attn_apply_bf16_kernel<3>, lds_at, "hipFuncSetAttribute(attn_apply_bf16)")) return rc; attr_at[1] = true; }
+        OPHIP_LAUNCH("attn_apply", stream, attn_apply_bf16_kernel<3>, dim3(t3 + t2, B), dim3(256), lds_at, stream, aa);
+    } else {
+        if (!attr_at[0]) { if (int rc = set_lds(attn_apply_bf16_kernel<1>, lds_at, "hipFuncSetAttribute(attn_apply_bf16)")) return rc; attr_at[0] = true; }
+        OPHIP_LAUNCH("attn_apply", stream, attn_apply_bf16_kernel<1>, dim3(t3 + t2, B), dim3(256), lds_at, stream, aa);
+    }
+    OPHIP_CHECK_LAUNCH();
+    return 0;
+}

@@ -40,7 +40,7 @@ __device__ __forceinline__ f32x4 frag_of(const f32x16& a, int kb) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void fine_refine_kernel(FineArgs p) {
+__global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void fine_refine_kernel(FineArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X = smem;                     // [32][LDF]
     float* P = X + 32 * LDF;             // [32][LDF]

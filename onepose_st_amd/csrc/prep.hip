@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void kpt_encode_kernel(KptArgs p) {
     // 3 -> 32
     if (wave == 0) {
         f32x16 acc[1] = {zero16()};
-        gemm_lds_x_packed<1>(acc, A0 + r * L0 + 4 * h, 1, p.w1 + lane, 64);
+        gemm_lds_x_packed<1, 1>(acc, A0 + r * L0 + 4 * h, 1, p.w1 + lane, 64);
         const float bias = p.b1[r];
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) acc[0][reg] += bias;

@@ -26,6 +26,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define OPHIP_WAVE 64
 #define OPHIP_TOK 32            // tokens (rows) per workgroup tile
+// Occupancy hint: these kernels are LDS-limited to N waves per SIMD; telling the compiler stops its max-occupancy
+// scheduler from trading the software prefetch (live registers) for occupancy the launch can never have.
+#define OPHIP_WAVES_PER_SIMD(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
 #define OPHIP_PAD 4             // LDS row padding in floats (16 B): ds_read_b128 conflict-free
 
 __device__ __forceinline__ f32x16 zero16() {
@@ -50,21 +53,28 @@ __device__ __forceinline__ f32x16 mfma4(const f32x4 a, const f32x4 b, f32x16 c) 
 //   lds_a   : this lane's row base inside the LDS image: &img[(lane&31)*lda + 4*(lane>>5)]
 //   wfrag   : packed weights, pointing at [first tile of this wave][kb0][lane]
 //   tstride : distance between consecutive output tiles in f32x4 units (= KB_total * 64)
-template <int NT>
+// Weight fragments stream L2 -> VGPR through a register ring PD k-blocks deep (compile-time slots) so that the L2
+// round trip hides behind the MFMAs even at one wave per SIMD; kblocks must be a multiple of PD.
+template <int NT, int PD = 4>
 __device__ __forceinline__ void gemm_lds_x_packed(f32x16 (&acc)[NT], const float* lds_a, int kblocks,
                                                   const f32x4* __restrict__ wfrag, int tstride) {
-    f32x4 bcur[NT], bnext[NT];
+    f32x4 ring[PD][NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) bcur[t] = wfrag[(size_t)t * tstride];
-    for (int kb = 0; kb < kblocks; ++kb) {
-        const int kn = (kb + 1 < kblocks) ? kb + 1 : kb;      // last iteration re-reads (harmless)
+    for (int p = 0; p < PD; ++p)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) bnext[t] = wfrag[(size_t)t * tstride + (size_t)kn * 64];
-        const f32x4 a = *reinterpret_cast<const f32x4*>(lds_a + 8 * kb);
+        for (int t = 0; t < NT; ++t) ring[p][t] = wfrag[(size_t)t * tstride + (size_t)p * 64];
+    for (int kb0 = 0; kb0 < kblocks; kb0 += PD) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = mfma4(a, bcur[t], acc[t]);
+        for (int p = 0; p < PD; ++p) {
+            const int kb = kb0 + p;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(lds_a + 8 * kb);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) bcur[t] = bnext[t];
+            for (int t = 0; t < NT; ++t) acc[t] = mfma4(a, ring[p][t], acc[t]);
+            const int kn = (kb + PD < kblocks) ? kb + PD : kblocks - 1;      // tail re-reads the last block (harmless)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) ring[p][t] = wfrag[(size_t)t * tstride + (size_t)kn * 64];
+            __builtin_amdgcn_sched_barrier(0);      // keep the refill here: the scheduler otherwise sinks it next to its use
+        }
     }
 }
 

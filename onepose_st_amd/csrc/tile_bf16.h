@@ -1,0 +1,157 @@
+// bf16 / split-bf16 MFMA building blocks (v_mfma_f32_32x32x16_bf16, f32 accumulate) for gfx950.
+//
+// Precision modes (template int NS):
+//   NS = 1  plain bf16 operands                                   (1 MFMA per fragment pair)
+//   NS = 3  split bf16: x = hi + lo (hi = bf16(x), lo = bf16(x - hi)), a.b ~= a_hi.b_hi + a_hi.b_lo + a_lo.b_hi
+//           (3 MFMAs; the dropped terms are ~2^-17 relative, i.e. ~f32-grade results at 3/16 of the cost of the
+//           exact-f32 matrix instruction, which runs at 1/16 of the bf16 rate on CDNA4)
+//
+// Lane maps of v_mfma_f32_32x32x16_bf16 (lane l, r = l & 31, h = l >> 5; 8 bf16 = 16 B per lane and operand):
+//     A[i = r][k = 8h + j]      B[k = 8h + j][j' = r]      D[row = (reg&3) + 8*(reg>>2) + 4h][col = r]
+//
+// LDS activation image: one plane per split part, row-major [token][feature] bf16, row pitch = 2 * features bytes,
+// 16-byte chunk c of row `row` lives at chunk (c ^ (row & 15)): ds_read_b128 of a fragment column is conflict free
+// (rows of a 16-lane group are distinct mod 16) without padding -- the planes of a 64-token tile use all 160 KiB.
+//
+// An accumulator tile can feed the next product that contracts over its ROW index without touching LDS: regs
+// 8s..8s+7 of a lane, converted to bf16, are the fragment of k-step s; the k order inside the step is permuted
+// (element j of lane-half h is row 16s + 8(j>>2) + 4h + (j&3)), so the other operand must be packed in that order.
+#pragma once
+#include "tile.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
+    hi = (__bf16)v;
+    lo = (__bf16)(v - (float)hi);
+}
+
+__device__ __forceinline__ bf16x8 zero_bf8() {
+    bf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.f;
+    return z;
+}
+
+// c += a * b with the split cross terms (small terms first)
+template <int NS>
+__device__ __forceinline__ f32x16 mma_bf16(const bf16x8& ahi, const bf16x8& alo, const bf16x8& bhi, const bf16x8& blo, f32x16 c) {
+    if (NS == 3) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, c, 0, 0, 0);
+    }
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, c, 0, 0, 0);
+}
+
+// byte offset of 16-byte chunk `chunk` of row `row` in a swizzled plane with row pitch `rowb`
+__device__ __forceinline__ int plane_off(int row, int chunk, int rowb) { return row * rowb + ((chunk ^ (row & 15)) << 4); }
+
+// registers 8s..8s+7 of an accumulator as a (hi, lo) fragment
+template <int NS>
+__device__ __forceinline__ void acc_frag(const f32x16& a, int s, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        __bf16 hh, ll;
+        split_bf16(a[8 * s + j], hh, ll);
+        hi[j] = hh;
+        lo[j] = (NS == 3) ? ll : (__bf16)0.f;
+    }
+}
+
+// GEMM of a packed weight matrix against an LDS activation tile.
+//   W_IS_A = true :  acc[t][tt] += W(tile t)[32 x K] . Act(token tile tt)[32 x K]^T   -> D[feature row][token col]
+//   W_IS_A = false:  acc[t][tt] += Act(tt)[32 x K] . W(t)[32 x K]^T                   -> D[token row][feature col]
+// whi/wlo point at [first tile of this wave][first k-block][lane]; tstride = fragments between tiles (= KB_total * 64).
+// act_hi/act_lo: swizzled planes; chunk0 = first 16-byte chunk of the activation row that k-block 0 reads.
+// Weight fragments stream L2 -> VGPR through a register ring PD k-blocks deep (compile-time slots): the kernels run
+// one wave per SIMD, so the ring is what hides the L2 round trip (~600 ns under load) behind the MFMAs.
+// KBLOCKS must be a multiple of PD.
+template <int NT, int TT, int NS, bool W_IS_A, int KBLOCKS, int PD>
+__device__ __forceinline__ void gemm_bf16(f32x16 (&acc)[NT][TT], const bf16x8* __restrict__ whi, const bf16x8* __restrict__ wlo,
+                                          int tstride, const char* act_hi, const char* act_lo, int rowb, int chunk0, int lane) {
+    static_assert(KBLOCKS % PD == 0, "k-blocks must be a multiple of the prefetch depth");
+    const int r = lane & 31, h = lane >> 5;
+    bf16x8 w_hi[PD][NT], w_lo[PD][NT];
+#pragma unroll
+    for (int p = 0; p < PD; ++p)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            w_hi[p][t] = whi[(size_t)t * tstride + (size_t)p * 64];
+            w_lo[p][t] = (NS == 3) ? wlo[(size_t)t * tstride + (size_t)p * 64] : zero_bf8();
+        }
+    for (int kb0 = 0; kb0 < KBLOCKS; kb0 += PD) {
+#pragma unroll
+        for (int p = 0; p < PD; ++p) {
+            const int kb = kb0 + p;
+            bf16x8 x_hi[TT], x_lo[TT];
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) {
+                const int off = plane_off(32 * tt + r, chunk0 + 2 * kb + h, rowb);
+                x_hi[tt] = *reinterpret_cast<const bf16x8*>(act_hi + off);
+                x_lo[tt] = (NS == 3) ? *reinterpret_cast<const bf16x8*>(act_lo + off) : zero_bf8();
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt)
+                    acc[t][tt] = W_IS_A ? mma_bf16<NS>(w_hi[p][t], w_lo[p][t], x_hi[tt], x_lo[tt], acc[t][tt])
+                                        : mma_bf16<NS>(x_hi[tt], x_lo[tt], w_hi[p][t], w_lo[p][t], acc[t][tt]);
+            // refill this ring slot with k-block kb + PD (the tail re-reads the last block: harmless, keeps the loop uniform)
+            const int kn = (kb + PD < KBLOCKS) ? kb + PD : KBLOCKS - 1;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                w_hi[p][t] = whi[(size_t)t * tstride + (size_t)kn * 64];
+                if (NS == 3) w_lo[p][t] = wlo[(size_t)t * tstride + (size_t)kn * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the refill here (see tile.h)
+        }
+    }
+}
+
+// Store a D[feature row][token col] accumulator into the planes: lane (token = tok0 + r, half h) owns features
+// feat0 + 8g + 4h + {0..3} in regs 4g..4g+3  ->  one 8-byte store per g and plane.
+template <int NS>
+__device__ __forceinline__ void store_featrow_acc(const f32x16& a, char* phi, char* plo, int rowb, int feat0, int tok0, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    const int row = tok0 + r;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        bf16x4 vh, vl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __bf16 hh, ll;
+            split_bf16(a[4 * g + j], hh, ll);
+            vh[j] = hh;
+            vl[j] = ll;
+        }
+        const int off = plane_off(row, (feat0 >> 3) + g, rowb) + 8 * h;
+        *reinterpret_cast<bf16x4*>(phi + off) = vh;
+        if (NS == 3) *reinterpret_cast<bf16x4*>(plo + off) = vl;
+    }
+}
+
+// global f32 rows -> swizzled (hi, lo) planes; T rows of C features, zero fill beyond L
+template <int NS, int C, int T>
+__device__ __forceinline__ void load_rows_to_planes(char* phi, char* plo, const float* __restrict__ x, int tok0, int L, int tid, int nthreads) {
+    constexpr int CH = C / 8;       // 16-byte bf16 chunks per row
+    for (int i = tid; i < T * CH; i += nthreads) {
+        const int row = i / CH, ch = i % CH;
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        if (tok0 + row < L) {
+            const float* src = x + (size_t)(tok0 + row) * C + 8 * ch;
+            v0 = *reinterpret_cast<const f32x4*>(src);
+            v1 = *reinterpret_cast<const f32x4*>(src + 4);
+        }
+        bf16x8 vh, vl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __bf16 hh, ll;
+            split_bf16(v0[j], hh, ll); vh[j] = hh; vl[j] = ll;
+            split_bf16(v1[j], hh, ll); vh[4 + j] = hh; vl[4 + j] = ll;
+        }
+        const int off = plane_off(row, ch, C * 2);
+        *reinterpret_cast<bf16x8*>(phi + off) = vh;
+        if (NS == 3) *reinterpret_cast<bf16x8*>(plo + off) = vl;
+    }
+}

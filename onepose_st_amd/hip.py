@@ -30,6 +30,9 @@ _SIGNATURES = {
     "ophip_kpt_encode": (c_i, [c_f, c_ll, c_f, c_ll, c_f, c_f, c_f, c_i, c_i, ctypes.c_void_p]),
     "ophip_encoder_workspace_floats": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "ophip_encoder_layer": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_i, c_f, ctypes.c_void_p]),
+    "ophip_encoder_bf16_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
+    "ophip_encoder_bf16_wpack_bytes": (ctypes.c_size_t, []),
+    "ophip_encoder_layer_bf16": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_i, c_i, c_f, ctypes.c_void_p]),
     "ophip_coarse_workspace_floats": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "ophip_coarse_match": (c_i, [c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_i, ctypes.c_double, ctypes.c_float, c_i, ctypes.c_float,
                                  c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, ctypes.c_void_p]),
@@ -75,11 +78,12 @@ def _check(rc: int, name: str):
 
 
 def ptr(t: torch.Tensor | None, dtype=torch.float32):
+    """Device pointer of a tensor of the given dtype (``dtype=None``: any, e.g. packed byte blocks)."""
     if t is None:
         return None
     if not t.is_cuda:
         raise HipLibraryError("the HIP path needs device tensors (no CPU fallback)")
-    if t.dtype != dtype:
+    if dtype is not None and t.dtype != dtype:
         raise TypeError(f"expected {dtype}, got {t.dtype}")
     return ctypes.c_void_p(t.data_ptr())
 

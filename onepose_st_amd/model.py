@@ -22,6 +22,7 @@ from __future__ import annotations
 import contextlib
 import ctypes
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -104,6 +105,10 @@ class OnePosePlus_model(nn.Module):
         self.loftr_fine = _EncoderParams(cf)
         self._pe_enable = bool(config["positional_encoding"]["enable"])
         self._pe_shape = tuple(config["positional_encoding"]["pos_emb_shape"])
+        # arithmetic of the coarse encoder: "f32" exact-f32 MFMA | "bf16x3" split-bf16 MFMA (~f32-grade) | "bf16"
+        self.precision = str(config.get("hip_precision", os.environ.get("OPHIP_PRECISION", "f32")))
+        if self.precision not in ("f32", "bf16x3", "bf16"):
+            raise ValueError(f"hip_precision {self.precision!r}: expected 'f32', 'bf16x3' or 'bf16'")
         self._packed = None          # (key, dict of device weight blocks)
         self._pe_cache = {}          # (h, w, device) -> [M, C] device table
 
@@ -122,7 +127,7 @@ class OnePosePlus_model(nn.Module):
     # ------------------------------------------------------------------------------------------
     def _weights(self, device):
         params = [p for n, p in self.named_parameters() if not n.startswith("backbone.")]
-        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
+        key = (str(device), self.precision) + tuple((p.data_ptr(), p._version) for p in params)
         if self._packed is not None and self._packed[0] == key:
             return self._packed[1]
         sd = {k: v for k, v in self.state_dict().items() if not k.startswith("backbone.")}
@@ -134,6 +139,9 @@ class OnePosePlus_model(nn.Module):
         }
         if self.kpt_3d_pos_encoding is not None:
             blocks["kpt"] = packing.pack_keypoint_encoder(sd).to(device)
+        if self.precision != "f32":
+            blocks["coarse_bf16"] = [packing.pack_coarse_layer_bf16(sd, f"loftr_coarse.layers.{i}.").to(device)
+                                     for i in range(len(self.loftr_coarse.layer_names))]
         self._packed = (key, blocks)
         return blocks
 
@@ -212,13 +220,20 @@ class OnePosePlus_model(nn.Module):
             src = desc_in_d if desc_in_d.shape[0] == B else desc_in_d.expand(B, -1, -1).contiguous()
             lib_call("ophip_transpose_cl", P(src), P(x3d), B, C, N, S)
         # ---- a4-a6: coarse encoder ----------------------------------------------------------------
-        ws_floats = hip.load().ophip_encoder_workspace_floats(B, N, M)
-        ws = torch.empty(ws_floats, **f32)
         y3d, y2d = torch.empty_like(x3d), torch.empty_like(x2d)
-        for li, name in enumerate(self.loftr_coarse.layer_names):
-            lib_call("ophip_encoder_layer", P(x3d), P(x2d), P(y3d), P(y2d), B, N, M, P(W["coarse"][li]),
-                     1 if name == "cross" else 0, P(ws), S)
-            x3d, y3d, x2d, y2d = y3d, x3d, y2d, x2d
+        if self.precision == "f32":
+            ws = torch.empty(hip.load().ophip_encoder_workspace_floats(B, N, M), **f32)
+            for li, name in enumerate(self.loftr_coarse.layer_names):
+                lib_call("ophip_encoder_layer", P(x3d), P(x2d), P(y3d), P(y2d), B, N, M, P(W["coarse"][li]),
+                         1 if name == "cross" else 0, P(ws), S)
+                x3d, y3d, x2d, y2d = y3d, x3d, y2d, x2d
+        else:
+            nsplit = 3 if self.precision == "bf16x3" else 1
+            ws = torch.empty(hip.load().ophip_encoder_bf16_workspace_bytes(B, N, M), device=dev, dtype=torch.uint8)
+            for li, name in enumerate(self.loftr_coarse.layer_names):
+                lib_call("ophip_encoder_layer_bf16", P(x3d), P(x2d), P(y3d), P(y2d), B, N, M, P(W["coarse_bf16"][li], None),
+                         nsplit, 1 if name == "cross" else 0, P(ws, None), S)
+                x3d, y3d, x2d, y2d = y3d, x3d, y2d, x2d
         if self.debug:
             data["_feat3d_c"], data["_feat2d_c"] = x3d, x2d
         # ---- a7 + a8: coarse matching -----------------------------------------------------------

@@ -70,3 +70,42 @@ def pack_keypoint_encoder(sd: dict, prefix: str = "kpt_3d_pos_encoding.encoder."
     w1 = torch.zeros(32, 8)
     w1[:, :3] = ws[0]
     return torch.cat([pack_linear(w1), pack_linear(ws[1]), pack_linear(ws[2]), pack_linear(ws[3])] + bs)
+
+
+# ----------------------------------------------------------------------------------------------
+# bf16 / split-bf16 blocks (csrc/tile_bf16.h): fragments of 8 bf16 per lane,
+#   [out/32][in/16][lane = 32*h + out%32][j] = W[out][16*kb + 8*h + j],  planes hi = bf16(W), lo = bf16(W - hi)
+# ----------------------------------------------------------------------------------------------
+
+def pack_linear_frag16(w: torch.Tensor) -> torch.Tensor:
+    """``[out, in]`` f32 -> f32 tensor in 16-k fragment order (``out % 32 == 0``, ``in % 16 == 0``)."""
+    out_f, in_f = w.shape
+    if out_f % 32 or in_f % 16:
+        raise ValueError(f"pack_linear_frag16: shape {tuple(w.shape)} is not a multiple of (32, 16)")
+    w = w.detach().to(torch.float32).cpu().contiguous()
+    return w.view(out_f // 32, 32, in_f // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+
+
+def split_planes(flat: torch.Tensor):
+    hi = flat.to(torch.bfloat16)
+    lo = (flat - hi.float()).to(torch.bfloat16)
+    return hi, lo
+
+
+def _bytes(*tensors) -> torch.Tensor:
+    return torch.cat([t.contiguous().view(torch.uint8).reshape(-1) for t in tensors])
+
+
+def pack_coarse_layer_bf16(sd: dict, prefix: str) -> torch.Tensor:
+    """uint8 block ``[hi: Wq | Wkv | Wm | W0 | W2][lo: same][norm1.w norm1.b norm2.w norm2.b f32]`` for
+    ``ophip_encoder_layer_bf16`` (Wkv in the per-wave row order of :func:`pack_coarse_layer`)."""
+    wk, wv = sd[prefix + "k_proj.weight"], sd[prefix + "v_proj.weight"]
+    if tuple(wk.shape) != (256, 256):
+        raise ValueError("coarse encoder kernels are specialised for d_model = 256")
+    wkv = torch.cat([torch.cat([wk[64 * w:64 * w + 64], wv[64 * w:64 * w + 64]], 0) for w in range(4)], 0)
+    flat = torch.cat([pack_linear_frag16(m) for m in (sd[prefix + "q_proj.weight"], wkv, sd[prefix + "merge.weight"],
+                                                     sd[prefix + "mlp.0.weight"], sd[prefix + "mlp.2.weight"])])
+    hi, lo = split_planes(flat)
+    out = _bytes(hi, lo, torch.cat(_ln(sd, prefix)))
+    assert out.numel() == 2 * 2 * 10 * 256 * 256 + 16 * 256
+    return out

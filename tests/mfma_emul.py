@@ -57,3 +57,72 @@ def acc_to_lds(acc, img, col0):
 
 def frag_of(acc, kb):
     return acc[:, 4 * kb:4 * kb + 4]
+
+
+# ------------------------------------------------------------------------------------------------
+# v_mfma_f32_32x32x16_bf16:  A[i = lane & 31][k = 8 (lane >> 5) + j],  B[k = 8 (lane >> 5) + j][col = lane & 31]
+# (values kept in float64 here: these emulations check index arithmetic, not rounding)
+# ------------------------------------------------------------------------------------------------
+
+def mfma_32x32x16(a8, b8, acc):
+    """a8, b8: [64][8] per-lane fragments; acc [64][16]"""
+    A = np.zeros((32, 16))
+    Bm = np.zeros((16, 32))
+    for l in range(64):
+        A[R[l], 8 * H[l]:8 * H[l] + 8] = a8[l]
+        Bm[8 * H[l]:8 * H[l] + 8, R[l]] = b8[l]
+    D = A @ Bm
+    return acc + D[ROWS, R[:, None]]
+
+
+def plane_off(row, chunk, rowb):
+    return row * rowb + ((chunk ^ (row & 15)) << 4)
+
+
+class Plane:
+    """a swizzled bf16 LDS plane addressed in bytes (2 bytes per element)"""
+
+    def __init__(self, rows, rowb):
+        self.rowb = rowb
+        self.mem = np.full(rows * rowb // 2, np.nan)
+
+    def write_elems(self, byte_off, vals):
+        assert byte_off % 2 == 0
+        self.mem[byte_off // 2:byte_off // 2 + len(vals)] = vals
+
+    def read16(self, byte_off):
+        assert byte_off % 16 == 0
+        return self.mem[byte_off // 2:byte_off // 2 + 8].copy()
+
+    def load_rows(self, x):
+        """load_rows_to_planes"""
+        T, Cc = x.shape
+        for row in range(T):
+            for ch in range(Cc // 8):
+                self.write_elems(plane_off(row, ch, self.rowb), x[row, 8 * ch:8 * ch + 8])
+
+
+def gemm_bf16(plane, wflat16, tile0, nt, ttn, tstride, kblocks, chunk0, w_is_a, kb0=0):
+    """tile_bf16.h gemm_bf16 with NS = 1 semantics on exact values; returns acc[t][tt]"""
+    w = wflat16.reshape(-1, 8)
+    acc = [[np.zeros((64, 16)) for _ in range(ttn)] for _ in range(nt)]
+    for kb in range(kblocks):
+        for tt in range(ttn):
+            x = np.stack([plane.read16(plane_off(32 * tt + R[l], chunk0 + 2 * kb + H[l], plane.rowb)) for l in range(64)])
+            for t in range(nt):
+                base = (tile0 + t) * tstride + (kb0 + kb) * 64
+                wf = w[base:base + 64]
+                acc[t][tt] = mfma_32x32x16(wf, x, acc[t][tt]) if w_is_a else mfma_32x32x16(x, wf, acc[t][tt])
+    return acc
+
+
+def acc_frag(acc, s):
+    return acc[:, 8 * s:8 * s + 8]
+
+
+def store_featrow_acc(acc, plane, feat0, tok0):
+    for l in range(64):
+        row = tok0 + R[l]
+        for g in range(4):
+            off = plane_off(row, (feat0 >> 3) + g, plane.rowb) + 8 * H[l]
+            plane.write_elems(off, acc[l, 4 * g:4 * g + 4])

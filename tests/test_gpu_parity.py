@@ -100,6 +100,33 @@ def test_encoder_layer(sd, dev, cross, B, L3, L2):
                  hip.ptr(ws), hip.stream_handle())
 
 
+@pytest.mark.parametrize("nsplit,rtol,atol", [(3, 3e-4, 1e-4), (1, 5e-2, 5e-2)])
+@pytest.mark.parametrize("cross", [0, 1])
+@pytest.mark.parametrize("B,L3,L2", [(1, 64, 32), (2, 70, 45), (1, 1000, 1200)])
+def test_encoder_layer_bf16(sd, dev, nsplit, rtol, atol, cross, B, L3, L2):
+    """bf16 matrix pipe: split-bf16 (nsplit 3) must track the f32 oracle to ~1e-4; plain bf16 (nsplit 1) is only
+    sanity-checked here (8-bit mantissas: ~1e-2 relative)."""
+    g = torch.Generator().manual_seed(2)
+    x3, x2 = torch.randn(B, L3, 256, generator=g), torch.randn(B, L2, 256, generator=g)
+    p = "loftr_coarse.layers.2."
+    if cross:
+        r2, r3 = orc.encoder_layer(sd, p, x2, x3, 8), orc.encoder_layer(sd, p, x3, x2, 8)
+    else:
+        r2, r3 = orc.encoder_layer(sd, p, x2, x2, 8), orc.encoder_layer(sd, p, x3, x3, 8)
+    w = packing.pack_coarse_layer_bf16(sd, p).to(dev)
+    assert w.numel() == hip.load().ophip_encoder_bf16_wpack_bytes()
+    ws = torch.empty(hip.load().ophip_encoder_bf16_workspace_bytes(B, L3, L2), dtype=torch.uint8, device=dev)
+    d3, d2 = x3.to(dev), x2.to(dev)
+    y3, y2 = torch.full_like(d3, float("nan")), torch.full_like(d2, float("nan"))
+    hip.call("ophip_encoder_layer_bf16", hip.ptr(d3), hip.ptr(d2), hip.ptr(y3), hip.ptr(y2), B, L3, L2, hip.ptr(w, None), nsplit, cross,
+             hip.ptr(ws, None), hip.stream_handle())
+    e3 = (y3.cpu() - r3).abs().max().item()
+    e2 = (y2.cpu() - r2).abs().max().item()
+    print(f"nsplit={nsplit} cross={cross} B={B} L=({L3},{L2}): max abs err 3D {e3:.3e} 2D {e2:.3e}")
+    close(y3, r3, rtol=rtol, atol=atol, msg="3D stream")
+    close(y2, r2, rtol=rtol, atol=atol, msg="2D stream")
+
+
 def _coarse_match(dev, f3, f2, kp, wc, thr=0.1, border=2, temp=0.08, scale=8.0):
     B, N, _ = f3.shape
     M = f2.shape[1]
@@ -308,6 +335,33 @@ def test_c2_full_size_against_oracle_and_properties(model, sd, cfg, dev):
     data2 = _run_features(model, inp, dev)
     for k in ("i_ids", "j_ids", "mconf", "mkpts_query_f", "expec_f", "conf_matrix"):
         assert torch.equal(data[k], data2[k]), k
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_c1_bf16_modes_against_reference_golden(sd, cfg, dev, golden_dir, precision):
+    """The bf16-pipe encoder inside the whole path, against the goldens captured from the reference.
+    split-bf16: indices bit-exact, floats at the f32 tolerances x5.  plain bf16: report the index mismatch count
+    (margin-free matches may flip) and check floats on the common matches at 5e-2."""
+    g = np.load(os.path.join(golden_dir, "c1_feature_boundary.npz"))
+    c = copy.deepcopy(cfg)
+    c["hip_precision"] = precision
+    m = OnePosePlus_model(c).eval()
+    m.load_state_dict(sd)
+    m.to(dev)
+    inp = make_synthetic_inputs(sd, n_points=1000, image_hw=(240, 320), n_plant=600, seed=1, config=cfg)
+    data = _run_features(m, inp, dev)
+    got = set(zip(data["i_ids"].tolist(), data["j_ids"].tolist()))
+    want = set(zip(g["i_ids"].tolist(), g["j_ids"].tolist()))
+    print(f"{precision}: K={len(got)} reference K={len(want)} symmetric difference={len(got ^ want)}")
+    if precision == "bf16x3":
+        assert got == want
+        np.testing.assert_array_equal(data["j_ids"].cpu().numpy(), g["j_ids"])
+        np.testing.assert_allclose(data["mconf"].cpu().numpy(), g["mconf"], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(data["mkpts_query_f"].cpu().numpy(), g["mkpts_query_f"], rtol=1e-4, atol=1e-3)
+    else:
+        assert len(got ^ want) <= 0.02 * len(want)
+        planted = set(zip(g["planted_i"].tolist(), g["planted_j"].tolist()))
+        assert (want & planted) <= got            # every planted (margin) match survives bf16
 
 
 def test_fine_disabled_and_encoder_disabled(sd, cfg, dev):
