@@ -34,6 +34,10 @@ int ophip_device_info(int* cu_count, int* lds_per_block, char* arch, int arch_le
 int ophip_timing_select(const char* kernel_name);
 int ophip_timing_read(int* launches, double* total_ms);
 
+/* Diagnostics only: while a device buffer (32 x uint64 per workgroup of the largest instrumented launch) is set, the
+ * fine_refine / attn_apply bf16 kernels record s_memtime at their phase boundaries into it.  NULL switches it off. */
+int ophip_debug_stamps(void* device_buffer);
+
 /* a1 -- PositionEncodingSine.forward + rearrange 'n c h w -> n (h w) c'
  * (utils/position_encoding.py:37-42, OnePosePlusModel.py:135-140).
  * out[b][m][c] = feat[b][c][m] + pe_nlc[m][c];  pe_nlc may be NULL (positional encoding disabled). */
@@ -72,12 +76,13 @@ int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, float* y3d, flo
  * conf [B][N][M] receives the dual-softmax confidence matrix (data["conf_matrix"]).
  * Outputs (capacity B*N entries each, ascending (b, i)): b_ids/i_ids/j_ids int64, mconf, mkpts3d [.][3]
  * (= keypoints3d[b, i]), mkpts_c [.][2] (= (j % wc, j / wc) * scale); *count = K.
- * temperature is passed as double so that (float)(temperature + 1e-4) matches the reference's scalar. */
+ * temperature is passed as double so that (float)(temperature + 1e-4) matches the reference's scalar.
+ * nsplit selects the arithmetic of the similarity GEMM: 0 exact f32 MFMA, 1 bf16, 3 split-bf16. */
 size_t ophip_coarse_workspace_floats(int B, int N, int M);
 int ophip_coarse_match(const float* feat3d, const float* feat2d, const float* keypoints3d, long long kpts_bstride,
                        int B, int N, int M, int wc, double temperature, float thr, int border_rm, float scale,
                        float* conf, float* workspace, long long* b_ids, long long* i_ids, long long* j_ids,
-                       float* mconf, float* mkpts3d, float* mkpts_c, int* count, void* stream);
+                       float* mconf, float* mkpts3d, float* mkpts_c, int* count, int nsplit, void* stream);
 
 /* a9 + a10 + a11 -- FinePreprocess + fine LocalFeatureTransformer (d_model 128) + FineMatching
  * (loftr_module/fine_preprocess.py:32-55, loftr_module/transformer.py:133-171, utils/fine_matching.py:28-110).
@@ -91,6 +96,16 @@ int ophip_fine_refine(const float* feat_f, long long fs_b, long long fs_c, long 
                       const float* mkpts_c, const float* wpack, int nlayers, unsigned cross_bits, int encoder_enable,
                       int wc, int stride, float fine_scale, float* expec_f, float* mkpts_f,
                       float* dbg_win, float* dbg_f3, void* stream);
+
+/* ophip_fine_refine on the bf16 matrix pipe (nsplit = 1 plain bf16, 3 split-bf16); two matches per workgroup.
+ * wpack: packing.pack_fine_layers_bf16 (ophip_fine_bf16_wpack_bytes(nlayers) bytes).  Other arguments as above. */
+size_t ophip_fine_bf16_wpack_bytes(int nlayers);
+int ophip_fine_refine_bf16(const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x, int hf, int wf,
+                           const float* desc3d_f, long long ds_b, long long ds_c,
+                           const long long* b_ids, const long long* i_ids, const long long* j_ids, const int* count, int max_matches,
+                           const float* mkpts_c, const void* wpack, int nlayers, unsigned cross_bits, int encoder_enable, int nsplit,
+                           int wc, int stride, float fine_scale, float* expec_f, float* mkpts_f,
+                           float* dbg_win, float* dbg_f3, void* stream);
 
 #ifdef __cplusplus
 }

@@ -66,6 +66,10 @@ extern "C" int ophip_timing_read(int* launches, double* total_ms) {
     return 0;
 }
 
+namespace { unsigned long long* g_stamps = nullptr; }
+extern "C" unsigned long long* ophip_stamp_buffer(void) { return g_stamps; }
+extern "C" int ophip_debug_stamps(void* device_buffer) { g_stamps = reinterpret_cast<unsigned long long*>(device_buffer); return 0; }
+
 extern "C" int ophip_abi_version(void) { return 1; }
 
 extern "C" const char* ophip_last_error(void) { return g_err; }

@@ -12,7 +12,7 @@
 //                 float bits (max is order independent => still deterministic)
 //   select        threshold (strict >), border removal (top/left only: the reference's `-b:0` slices are
 //                 empty), mutual test, first-true-j semantics on exact ties, compaction in ascending (b, i)
-#include "tile.h"
+#include "tile_bf16.h"
 #include <math.h>
 
 namespace {
@@ -46,6 +46,80 @@ __device__ __forceinline__ float half_sum(float v) {
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+
+// Shared epilogue of the similarity kernels: S = acc / T', row / column (max, sum exp) of this 128 x 128 tile.
+__device__ __forceinline__ void sim_epilogue(f32x16 (&acc)[2][2], const SimArgs& p, float (&rowst)[2][TM][2], float (&colst)[2][TN][2],
+                                             int tid, int i0, int j0, int b) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
+    // ---- epilogue: S, row / column (max, sum exp) of this tile -------------------------------
+    float* conf = p.conf + (size_t)b * p.N * p.M;
+    bool jv[2];
+#pragma unroll
+    for (int y = 0; y < 2; ++y) jv[y] = (j0 + 64 * wc + 32 * y + r) < p.M;
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int lrow = 64 * wr + 32 * x + acc_row(reg, h);
+            const int i = i0 + lrow;
+            float v[2];
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const float s = acc[x][y][reg] / p.temp;
+                acc[x][y][reg] = s;
+                if (i < p.N && jv[y]) conf[(size_t)i * p.M + j0 + 64 * wc + 32 * y + r] = s;
+                v[y] = jv[y] ? s : -INFINITY;
+            }
+            const float m = half_max(fmaxf(v[0], v[1]));
+            float e = 0.f;
+            if (m != -INFINITY) e = expf(v[0] - m) + expf(v[1] - m);
+            e = half_sum(e);
+            if (r == 0) { rowst[wc][lrow][0] = m; rowst[wc][lrow][1] = e; }
+        }
+    }
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const bool iv = (i0 + 64 * wr + 32 * x + acc_row(reg, h)) < p.N;
+                m = fmaxf(m, iv ? acc[x][y][reg] : -INFINITY);
+            }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float e = 0.f;
+        if (m != -INFINITY) {
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const bool iv = (i0 + 64 * wr + 32 * x + acc_row(reg, h)) < p.N;
+                    e += iv ? expf(acc[x][y][reg] - m) : 0.f;
+                }
+        }
+        e += __shfl_xor(e, 32, 64);
+        if (h == 0) { colst[wr][64 * wc + 32 * y + r][0] = m; colst[wr][64 * wc + 32 * y + r][1] = e; }
+    }
+    __syncthreads();
+    if (tid < TM) {
+        float m = rowst[0][tid][0], e = rowst[0][tid][1];
+        merge_ms(m, e, rowst[1][tid][0], rowst[1][tid][1]);
+        if (i0 + tid < p.N) {
+            float* o = p.rowpart + (((size_t)b * p.ntc + (j0 / TN)) * p.N + i0 + tid) * 2;
+            o[0] = m; o[1] = e;
+        }
+    } else {
+        const int c = tid - TM;
+        float m = colst[0][c][0], e = colst[0][c][1];
+        merge_ms(m, e, colst[1][c][0], colst[1][c][1]);
+        if (j0 + c < p.M) {
+            float* o = p.colpart + (((size_t)b * p.ntr + (i0 / TM)) * p.M + j0 + c) * 2;
+            o[0] = m; o[1] = e;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void sim_stats_kernel(SimArgs p) {
@@ -111,73 +185,103 @@ __global__ __launch_bounds__(256) void sim_stats_kernel(SimArgs p) {
         }
     }
 
-    // ---- epilogue: S, row / column (max, sum exp) of this tile -------------------------------
-    float* conf = p.conf + (size_t)b * p.N * p.M;
-    bool jv[2];
+    sim_epilogue(acc, p, rowst, colst, tid, i0, j0, b);
+}
+
+// Same tile on the bf16 matrix pipe.  K chunks of 64 features are staged as (hi, lo) bf16 planes with a 144-byte row
+// pitch (128 + 16: conflict-free ds_read_b128 for rows distinct mod 16); 72 KiB of LDS -> two workgroups per CU.
+constexpr int SKC = 64, SPITCH = SKC * 2 + 16;
+
+template <int NS>
+__global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_stats_bf16_kernel(SimArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PL = NS == 3 ? 2 : 1;
+    constexpr int PB = TM * SPITCH;                    // bytes per plane
+    char* AH = smem;
+    char* AL = smem + (PL - 1) * PB;
+    char* BH = smem + PL * PB;
+    char* BL = BH + (PL - 1) * PB;
+    __shared__ float rowst[2][TM][2];
+    __shared__ float colst[2][TN][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
+    const int j0 = blockIdx.x * TN, i0 = blockIdx.y * TM, b = blockIdx.z;
+    const float* A = p.a + (size_t)b * p.N * C;
+    const float* Bq = p.bq + (size_t)b * p.M * C;
+
+    f32x4 ra[4][2], rb[4][2];
+    auto prefetch = [&](int kc) {
 #pragma unroll
-    for (int y = 0; y < 2; ++y) jv[y] = (j0 + 64 * wc + 32 * y + r) < p.M;
-#pragma unroll
-    for (int x = 0; x < 2; ++x) {
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int lrow = 64 * wr + 32 * x + acc_row(reg, h);
-            const int i = i0 + lrow;
-            float v[2];
-#pragma unroll
-            for (int y = 0; y < 2; ++y) {
-                const float s = acc[x][y][reg] / p.temp;
-                acc[x][y][reg] = s;
-                if (i < p.N && jv[y]) conf[(size_t)i * p.M + j0 + 64 * wc + 32 * y + r] = s;
-                v[y] = jv[y] ? s : -INFINITY;
-            }
-            const float m = half_max(fmaxf(v[0], v[1]));
-            float e = 0.f;
-            if (m != -INFINITY) e = expf(v[0] - m) + expf(v[1] - m);
-            e = half_sum(e);
-            if (r == 0) { rowst[wc][lrow][0] = m; rowst[wc][lrow][1] = e; }
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + 256 * u, row = idx >> 3, c8 = idx & 7;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const float* sa = A + (size_t)(i0 + row) * C + kc * SKC + 8 * c8;
+            const float* sb = Bq + (size_t)(j0 + row) * C + kc * SKC + 8 * c8;
+            const bool va = i0 + row < p.N, vb = j0 + row < p.M;
+            ra[u][0] = va ? *reinterpret_cast<const f32x4*>(sa) : z;
+            ra[u][1] = va ? *reinterpret_cast<const f32x4*>(sa + 4) : z;
+            rb[u][0] = vb ? *reinterpret_cast<const f32x4*>(sb) : z;
+            rb[u][1] = vb ? *reinterpret_cast<const f32x4*>(sb + 4) : z;
         }
-    }
+    };
+    auto stage = [&]() {
 #pragma unroll
-    for (int y = 0; y < 2; ++y) {
-        float m = -INFINITY;
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + 256 * u, row = idx >> 3, c8 = idx & 7;
+            bf16x8 ah, al, bh, bl;
 #pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const bool iv = (i0 + 64 * wr + 32 * x + acc_row(reg, h)) < p.N;
-                m = fmaxf(m, iv ? acc[x][y][reg] : -INFINITY);
+            for (int j = 0; j < 8; ++j) {
+                __bf16 hh, ll;
+                split_bf16(ra[u][j >> 2][j & 3] * 0.0625f, hh, ll);     // feat / sqrt(C), exact power of two
+                ah[j] = hh; al[j] = ll;
+                split_bf16(rb[u][j >> 2][j & 3] * 0.0625f, hh, ll);
+                bh[j] = hh; bl[j] = ll;
             }
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        float e = 0.f;
-        if (m != -INFINITY) {
+            const int off = row * SPITCH + 16 * c8;
+            *reinterpret_cast<bf16x8*>(AH + off) = ah;
+            *reinterpret_cast<bf16x8*>(BH + off) = bh;
+            if (NS == 3) {
+                *reinterpret_cast<bf16x8*>(AL + off) = al;
+                *reinterpret_cast<bf16x8*>(BL + off) = bl;
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = zero16();
+    prefetch(0);
+    stage();
+    __syncthreads();
+    constexpr int NKC = C / SKC;
+    for (int kc = 0; kc < NKC; ++kc) {
+        if (kc + 1 < NKC) prefetch(kc + 1);
+#pragma unroll
+        for (int kb = 0; kb < SKC / 16; ++kb) {
+            bf16x8 fah[2], fal[2], fbh[2], fbl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int oa = (64 * wr + 32 * t + r) * SPITCH + 16 * (2 * kb + h);
+                const int ob = (64 * wc + 32 * t + r) * SPITCH + 16 * (2 * kb + h);
+                fah[t] = *reinterpret_cast<const bf16x8*>(AH + oa);
+                fbh[t] = *reinterpret_cast<const bf16x8*>(BH + ob);
+                fal[t] = (NS == 3) ? *reinterpret_cast<const bf16x8*>(AL + oa) : zero_bf8();
+                fbl[t] = (NS == 3) ? *reinterpret_cast<const bf16x8*>(BL + ob) : zero_bf8();
+            }
 #pragma unroll
             for (int x = 0; x < 2; ++x)
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const bool iv = (i0 + 64 * wr + 32 * x + acc_row(reg, h)) < p.N;
-                    e += iv ? expf(acc[x][y][reg] - m) : 0.f;
-                }
+                for (int y = 0; y < 2; ++y) acc[x][y] = mma_bf16<NS>(fah[x], fal[x], fbh[y], fbl[y], acc[x][y]);
         }
-        e += __shfl_xor(e, 32, 64);
-        if (h == 0) { colst[wr][64 * wc + 32 * y + r][0] = m; colst[wr][64 * wc + 32 * y + r][1] = e; }
-    }
-    __syncthreads();
-    if (tid < TM) {
-        float m = rowst[0][tid][0], e = rowst[0][tid][1];
-        merge_ms(m, e, rowst[1][tid][0], rowst[1][tid][1]);
-        if (i0 + tid < p.N) {
-            float* o = p.rowpart + (((size_t)b * p.ntc + blockIdx.x) * p.N + i0 + tid) * 2;
-            o[0] = m; o[1] = e;
-        }
-    } else {
-        const int c = tid - TM;
-        float m = colst[0][c][0], e = colst[0][c][1];
-        merge_ms(m, e, colst[1][c][0], colst[1][c][1]);
-        if (j0 + c < p.M) {
-            float* o = p.colpart + (((size_t)b * p.ntr + blockIdx.y) * p.M + j0 + c) * 2;
-            o[0] = m; o[1] = e;
+        __syncthreads();
+        if (kc + 1 < NKC) {
+            stage();
+            __syncthreads();
         }
     }
+    sim_epilogue(acc, p, rowst, colst, tid, i0, j0, b);
 }
 
 struct CombineArgs {
@@ -438,10 +542,11 @@ extern "C" size_t ophip_coarse_workspace_floats(int B, int N, int M) {
 extern "C" int ophip_coarse_match(const float* feat3d, const float* feat2d, const float* keypoints3d, long long kpts_bstride,
                                   int B, int N, int M, int wc, double temperature, float thr, int border_rm, float scale,
                                   float* conf, float* workspace, long long* b_ids, long long* i_ids, long long* j_ids,
-                                  float* mconf, float* mkpts3d, float* mkpts_c, int* count, void* stream_) {
+                                  float* mconf, float* mkpts3d, float* mkpts_c, int* count, int nsplit, void* stream_) {
     if (!feat3d || !feat2d || !keypoints3d || !conf || !workspace || !b_ids || !i_ids || !j_ids || !mconf || !mkpts3d || !mkpts_c || !count)
         return ophip_bad_arg(__func__, "null pointer");
     if (B < 1 || N < 1 || M < 1 || wc < 1 || M % wc != 0) return ophip_bad_arg(__func__, "bad sizes (need M == hc * wc)");
+    if (nsplit != 0 && nsplit != 1 && nsplit != 3) return ophip_bad_arg(__func__, "nsplit must be 0 (exact f32), 1 (bf16) or 3 (split bf16)");
     hipStream_t stream = (hipStream_t)stream_;
     const int ntr = (N + TM - 1) / TM, ntc = (M + TN - 1) / TN, nrb = (N + CONF_ROWS - 1) / CONF_ROWS;
     const int nspan = conf_nspan(M), spanw = conf_spanw(M);
@@ -453,7 +558,22 @@ extern "C" int ophip_coarse_match(const float* feat3d, const float* feat2d, cons
     float* colmax = rowbest + (size_t)B * nspan * N * 3;
 
     SimArgs sa{feat3d, feat2d, conf, rowpart, colpart, N, M, ntr, ntc, (float)(temperature + 1e-4)};
-    OPHIP_LAUNCH("sim_stats", stream, sim_stats_kernel, dim3(ntc, ntr, B), dim3(256), 0, stream, sa);
+    if (nsplit == 0) {
+        OPHIP_LAUNCH("sim_stats", stream, sim_stats_kernel, dim3(ntc, ntr, B), dim3(256), 0, stream, sa);
+    } else {
+        const size_t lds = (size_t)(nsplit == 3 ? 4 : 2) * TM * SPITCH;
+        static bool attr[2] = {false, false};
+        if (nsplit == 3) {
+            if (!attr[1]) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sim_stats_bf16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return ophip_fail(e, "hipFuncSetAttribute(sim_stats_bf16)");
+                attr[1] = true;
+            }
+            OPHIP_LAUNCH("sim_stats", stream, sim_stats_bf16_kernel<3>, dim3(ntc, ntr, B), dim3(256), lds, stream, sa);
+        } else {
+            OPHIP_LAUNCH("sim_stats", stream, sim_stats_bf16_kernel<1>, dim3(ntc, ntr, B), dim3(256), lds, stream, sa);
+        }
+    }
     OPHIP_CHECK_LAUNCH();
     CombineArgs ca{rowpart, colpart, rowstat, colstat, reinterpret_cast<unsigned*>(colmax), N, M, ntr, ntc};
     OPHIP_LAUNCH("stat_combine", stream, stat_combine_kernel, dim3((N + M + 31) / 32, B), dim3(256), 0, stream, ca);

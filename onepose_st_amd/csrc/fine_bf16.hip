@@ -1,0 +1,405 @@
+// Fine-level refinement on the bf16 matrix pipe (plain or split-bf16, tile_bf16.h); same mathematics as csrc/fine.hip
+// (reference: loftr_module/fine_preprocess.py:32-55, loftr_module/transformer.py:65-171 with the loftr_fine config,
+// utils/fine_matching.py:28-110).
+//
+// One workgroup (8 waves) refines TWO coarse matches (two 32-row token tiles: rows 0..24 window, row 25 the 3D token,
+// 26..31 padding); wave (tt, ft) owns feature tile ft of match tt, so the two matches' dependent chains share each SIMD
+// (2 waves/SIMD) and cover each other's MFMA->VALU latencies.  The per-match problem is tiny and latency bound: a
+// layer is four GEMM phases (Q|K|V, merge, MLP up, MLP down) whose weight rings are filled one phase AHEAD (tile_bf16.h
+// WRing), so no phase starts on a cold L2 round trip.  In-kernel stamps (ophip_debug_stamps) showed the register-only
+// attention block to be VALU bound, hence v_exp / v_rcp forms and one phi(Q) conversion shared by both source sets.
+//   * K, V are produced as D[token][feature] accumulators, Q as D[feature][token]; the per-match KV / Ksum tiles of both
+//     source sets (window, 3D token) and the products phi(Q) KV are formed accumulator-to-operand, entirely in
+//     registers (two 16-wide heads per 32-wide tile -> KV masked to its block diagonal);
+//   * the residual stream is kept in f32 registers across both layers; the LDS planes only feed the GEMMs;
+//   * a token attends to exactly one source set, so phi(Q) is masked per set on its token (lane) axis and both sets
+//     accumulate into one numerator / one denominator tile.
+#include "tile_bf16.h"
+
+namespace {
+
+constexpr int CF = 128, TOK = 64, WIN = 25, TOK3D = 25;
+constexpr int ROWB = CF * 2;              // X / Y plane pitch (256 B, 16 chunks)
+constexpr int HROWB = 2 * CF * 2;         // hidden plane pitch: 256 features (512 B)
+constexpr int KB = CF / 16, TS = KB * 64;              // K = 128
+constexpr int KB2 = 2 * CF / 16, TS2 = KB2 * 64;       // K = 256
+constexpr int W_ELEMS = 10 * CF * CF;                  // bf16 elements per plane and layer
+
+struct FineBArgs {
+    const float* feat_f; long long fs_b, fs_c, fs_y, fs_x; int hf, wf;
+    const float* desc_f; long long ds_b, ds_c;
+    const long long *b_ids, *i_ids, *j_ids;
+    const int* count;
+    const float* mkq_c;
+    const char* wpack;           // nlayers x (2 * W_ELEMS * 2 + 4 * CF * 4) bytes
+    int nlayers; unsigned cross_bits; int enc_enable;
+    int wc, stride;
+    float fine_scale;
+    float* expec_f; float* mkq_f;
+    float* dbg_win; float* dbg_f3;
+    unsigned long long* stamps;
+};
+
+// f32 staging image [64][128], 16-byte chunks swizzled like the planes (32 chunks per row)
+__device__ __forceinline__ int stage_off(int row, int chunk) { return row * (CF * 4) + ((chunk ^ (row & 15)) << 4); }
+
+// LayerNorm over the 128 features of a token, spread over the 4 feature-tile waves of its match (wave (tt, ft) holds
+// features 32 ft .. 32 ft + 31 of tokens 32 tt .. 32 tt + 31 as a D[feature][token] accumulator).  Two-pass; partial
+// sums cross waves through `scratch` ([2][4][64] floats).  Contains 2 workgroup barriers.
+__device__ __forceinline__ void layernorm_featrow128(f32x16& m, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* scratch, int ft, int tt, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    const int tok = 32 * tt + r;
+    float s = 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) s += m[reg];
+    s += __shfl_xor(s, 32, 64);
+    if (h == 0) scratch[ft * 64 + tok] = s;
+    __syncthreads();
+    const float mean = ((scratch[tok] + scratch[64 + tok]) + (scratch[128 + tok] + scratch[192 + tok])) * (1.0f / CF);
+    float q = 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const float d = m[reg] - mean;
+        q += d * d;
+    }
+    q += __shfl_xor(q, 32, 64);
+    if (h == 0) scratch[256 + ft * 64 + tok] = q;
+    __syncthreads();
+    const float var = ((scratch[256 + tok] + scratch[320 + tok]) + (scratch[384 + tok] + scratch[448 + tok])) * (1.0f / CF);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int f0 = 32 * ft + 8 * g + 4 * h;
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(gamma + f0);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(beta + f0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[4 * g + j] = (m[4 * g + j] - mean) * rstd * gv[j] + bv[j];
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void fine_refine_bf16_kernel(FineBArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PL = NS == 3 ? 2 : 1;
+    constexpr int XB = TOK * ROWB, HB = TOK * HROWB;   // 16 KiB / 32 KiB per plane
+    char* XH = smem;
+    char* XL = smem + (PL - 1) * XB;
+    char* YH = smem + PL * XB;
+    char* YL = YH + (PL - 1) * XB;
+    char* HH = smem + 2 * PL * XB;
+    char* HL = HH + (PL - 1) * HB;
+    // f32 staging [64][128] (32 KiB) and the LayerNorm exchange live in H while it is idle.
+    // LDS total: split 32 + 32 + 64 = 128 KiB, plain 64 KiB.
+    char* stage = HH;
+    float* scratch = reinterpret_cast<float*>(HH);
+    const int k0 = 2 * blockIdx.x;
+    const int total = *p.count;
+    if (k0 >= total) return;
+    // 8 waves: wave = 4 * tt + ft owns feature tile ft (features 32 ft .. 32 ft + 31) of match / token tile tt
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ft = wave & 3, tt = wave >> 2;
+    const int r = lane & 31, h = lane >> 5;
+    OPHIP_STAMP(p.stamps, blockIdx.x, 0);
+
+    // ---- gather both matches into the f32 staging image --------------------------------------------
+    for (int mi = 0; mi < 2; ++mi) {
+        const int k = k0 + mi;
+        const bool live = k < total;
+        const int b = live ? (int)p.b_ids[k] : 0, i3 = live ? (int)p.i_ids[k] : 0, j = live ? (int)p.j_ids[k] : 0;
+        const int cy = p.stride * (j / p.wc), cx = p.stride * (j % p.wc);
+        const float* ff = p.feat_f + (size_t)b * p.fs_b;
+        if (p.fs_c == 1) {
+            for (int e = tid; e < WIN * CF; e += 512) {
+                const int rr = e >> 7, c = e & 127;
+                const int y = cy + rr / 5 - 2, x = cx + rr % 5 - 2;
+                float v = 0.f;
+                if (live && y >= 0 && y < p.hf && x >= 0 && x < p.wf) v = ff[(size_t)y * p.fs_y + (size_t)x * p.fs_x + c];
+                *reinterpret_cast<float*>(stage + stage_off(32 * mi + rr, c >> 2) + 4 * (c & 3)) = v;
+            }
+        } else {
+            for (int q = tid; q < CF * 5; q += 512) {
+                const int c = q / 5, ky = q % 5;
+                const int y = cy + ky - 2;
+                const bool yin = live && y >= 0 && y < p.hf;
+                const float* src = ff + (size_t)c * p.fs_c + (size_t)(yin ? y : 0) * p.fs_y;
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) {
+                    const int x = cx + kx - 2;
+                    float v = 0.f;
+                    if (yin && x >= 0 && x < p.wf) v = src[(size_t)x * p.fs_x];
+                    *reinterpret_cast<float*>(stage + stage_off(32 * mi + ky * 5 + kx, c >> 2) + 4 * (c & 3)) = v;
+                }
+            }
+        }
+        if (tid < CF) {
+            const float v = live ? p.desc_f[(size_t)b * p.ds_b + (size_t)tid * p.ds_c + i3] : 0.f;
+            *reinterpret_cast<float*>(stage + stage_off(32 * mi + TOK3D, tid >> 2) + 4 * (tid & 3)) = v;
+        }
+        for (int e = tid; e < 6 * CF; e += 512) {
+            const int rr = 26 + (e >> 7), c = e & 127;
+            *reinterpret_cast<float*>(stage + stage_off(32 * mi + rr, c >> 2) + 4 * (c & 3)) = 0.f;
+        }
+    }
+    __syncthreads();
+    OPHIP_STAMP(p.stamps, blockIdx.x, 1);
+    // residual stream in registers, D[feature][token] layout: this wave's 32 features of its 32 tokens
+    f32x16 xres;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(stage + stage_off(32 * tt + r, 8 * ft + 2 * g + h));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xres[4 * g + j] = v[j];
+    }
+    __syncthreads();                                 // staging (in H) fully consumed before anything else lands there
+    store_featrow_acc<NS>(xres, XH, XL, ROWB, 32 * ft, 32 * tt, lane);
+    __syncthreads();
+
+    const int nl = p.enc_enable ? p.nlayers : 0;
+    constexpr size_t LAYER_BYTES = (size_t)2 * W_ELEMS * 2 + 4 * CF * 4;
+    // plane offsets in fragments: Wq | Wkv (per feature tile: K tile, V tile) | Wm | W0 | W2
+    constexpr int OQ = 0, OKV = CF * CF / 8, OM = 3 * CF * CF / 8, O0 = 4 * CF * CF / 8, O2 = 8 * CF * CF / 8;
+    const bf16x8 zeros = zero_bf8();
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    // this wave's token rows inside the planes
+    const char* xh = XH + 32 * tt * ROWB; const char* xl = XL + 32 * tt * ROWB;
+    const char* yh = YH + 32 * tt * ROWB; const char* yl = YL + 32 * tt * ROWB;
+    const char* hh = HH + 32 * tt * HROWB; const char* hl = HL + 32 * tt * HROWB;
+
+    WRing<1, 2, NS> rq;
+    WRing<2, 2, NS> rkv;
+    if (nl > 0) {
+        const bf16x8* w_hi = reinterpret_cast<const bf16x8*>(p.wpack);
+        const bf16x8* w_lo = w_hi + W_ELEMS / 8;
+        rq.fill(w_hi + OQ + (size_t)ft * TS + lane, w_lo + OQ + (size_t)ft * TS + lane, TS);
+        rkv.fill(w_hi + OKV + (size_t)(2 * ft) * TS + lane, w_lo + OKV + (size_t)(2 * ft) * TS + lane, TS);
+    }
+    for (int l = 0; l < nl; ++l) {
+        const char* wl = p.wpack + (size_t)l * LAYER_BYTES;
+        const bf16x8* w_hi = reinterpret_cast<const bf16x8*>(wl);
+        const bf16x8* w_lo = w_hi + W_ELEMS / 8;
+        const float* ln = reinterpret_cast<const float*>(wl + (size_t)2 * W_ELEMS * 2);
+        const bool cross = (p.cross_bits >> l) & 1u;
+
+        // ---- phase 1: Q (D[feature][token]) and K, V (D[token][feature]) of this wave's match from X ----------
+        f32x16 q[1][1] = {{zero16()}};
+        f32x16 kv_[2][1] = {{zero16()}, {zero16()}};
+        gemm_bf16_ring<1, 1, NS, true, KB, 2>(q, rq, w_hi + OQ + (size_t)ft * TS + lane, w_lo + OQ + (size_t)ft * TS + lane, TS, xh, xl, ROWB, 0, lane);
+        gemm_bf16_ring<2, 1, NS, false, KB, 2>(kv_, rkv, w_hi + OKV + (size_t)(2 * ft) * TS + lane, w_lo + OKV + (size_t)(2 * ft) * TS + lane, TS,
+                                               xh, xl, ROWB, 0, lane);
+        OPHIP_STAMP(p.stamps, blockIdx.x, 2 + 8 * l);
+        WRing<1, 2, NS> rm;                      // merge weights: in flight during the register-only attention below
+        rm.fill(w_hi + OM + (size_t)ft * TS + lane, w_lo + OM + (size_t)ft * TS + lane, TS);
+        // ---- KV / Ksum of the two source sets and phi(Q) KV, all in registers -------------------------------
+        {
+            const bool is3d = r == TOK3D;                 // on the token (lane) axis of D[feature][token] tiles
+            const bool use_w = cross ? is3d : !is3d;      // this token attends to the window set (else: the 3D token)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) q[0][0][reg] = elu_plus_one_fast(q[0][0][reg]);
+            // masked phi(K) / scaled V fragments straight from the accumulators (rows = tokens of this match)
+            auto f_kw = [&](int reg, float v) { return acc_row(reg, h) < WIN ? elu_plus_one_fast(v) : 0.f; };
+            auto f_k3 = [&](int reg, float v) { return acc_row(reg, h) == TOK3D ? elu_plus_one_fast(v) : 0.f; };
+            auto f_vs = [&](int reg, float v) {       // values / v_length of the stream the token belongs to (25 | 1)
+                const int row = acc_row(reg, h);
+                return row < WIN ? v * 0.04f : (row == TOK3D ? v : 0.f);
+            };
+            // a token attends to exactly one source set: phi(Q) is masked per set on the token (lane) axis and both sets
+            // accumulate into one num / den tile.  Window set first, then the 3D token (row 25 = k-step 1 only: k-step 0
+            // of that set is all zeros), so that only two KV tiles are live at a time.
+            const auto block_diag = [&](f32x16& t) {          // two 16-wide heads per 32-wide tile
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                    if ((acc_row(reg, h) >> 4) != (r >> 4)) t[reg] = 0.f;
+            };
+            f32x16 num = zero16(), den = zero16();
+            {
+                f32x16 kvw = zero16(), ksw = zero16();
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    bf16x8 wh, wl2, vh, vl;
+                    acc_frag_map<NS>(kv_[0][0], st, f_kw, wh, wl2);
+                    acc_frag_map<NS>(kv_[1][0], st, f_vs, vh, vl);
+                    kvw = mma_bf16<NS>(wh, wl2, vh, vl, kvw);
+                    ksw = mma_bf16<NS>(wh, wl2, ones, zeros, ksw);
+                }
+                block_diag(kvw);
+                block_diag(ksw);
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    bf16x8 qh, ql, ah, al;
+                    acc_frag<NS>(q[0][0], st, qh, ql);
+                    const bf16x8 qwh = select_frag(use_w, qh, zeros), qwl = select_frag(use_w, ql, zeros);
+                    acc_frag<NS>(kvw, st, ah, al); num = mma_bf16<NS>(ah, al, qwh, qwl, num);
+                    acc_frag<NS>(ksw, st, ah, al); den = mma_bf16<NS>(ah, al, qwh, qwl, den);
+                }
+            }
+            {
+                f32x16 kv3 = zero16(), ks3 = zero16();
+                bf16x8 th, tl, vh, vl;
+                acc_frag_map<NS>(kv_[0][0], 1, f_k3, th, tl);
+                acc_frag_map<NS>(kv_[1][0], 1, f_vs, vh, vl);
+                kv3 = mma_bf16<NS>(th, tl, vh, vl, kv3);
+                ks3 = mma_bf16<NS>(th, tl, ones, zeros, ks3);
+                block_diag(kv3);
+                block_diag(ks3);
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    bf16x8 qh, ql, ah, al;
+                    acc_frag<NS>(q[0][0], st, qh, ql);
+                    const bf16x8 q3h = select_frag(!use_w, qh, zeros), q3l = select_frag(!use_w, ql, zeros);
+                    acc_frag<NS>(kv3, st, ah, al); num = mma_bf16<NS>(ah, al, q3h, q3l, num);
+                    acc_frag<NS>(ks3, st, ah, al); den = mma_bf16<NS>(ah, al, q3h, q3l, den);
+                }
+            }
+            const float S = use_w ? 25.0f : 1.0f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) num[reg] = num[reg] * rcp_fast(den[reg] + 1e-6f) * S;
+            store_featrow_acc<NS>(num, YH, YL, ROWB, 32 * ft, 32 * tt, lane);
+        }
+        __syncthreads();
+        OPHIP_STAMP(p.stamps, blockIdx.x, 3 + 8 * l);
+        // ---- phase 2: merge + LN1 -> Y -----------------------------------------------------------------
+        WRing<2, 2, NS> r0;                      // MLP-up weights (hidden tiles 2 ft, 2 ft + 1)
+        {
+            f32x16 m[1][1] = {{zero16()}};
+            gemm_bf16_ring<1, 1, NS, true, KB, 2>(m, rm, w_hi + OM + (size_t)ft * TS + lane, w_lo + OM + (size_t)ft * TS + lane, TS, yh, yl, ROWB, 0, lane);
+            r0.fill(w_hi + O0 + (size_t)(2 * ft) * TS2 + lane, w_lo + O0 + (size_t)(2 * ft) * TS2 + lane, TS2);
+            OPHIP_STAMP(p.stamps, blockIdx.x, 4 + 8 * l);
+            layernorm_featrow128(m[0][0], ln, ln + CF, scratch, ft, tt, lane);       // first barrier also fences the reads of Y
+            store_featrow_acc<NS>(m[0][0], YH, YL, ROWB, 32 * ft, 32 * tt, lane);
+        }
+        __syncthreads();
+        OPHIP_STAMP(p.stamps, blockIdx.x, 5 + 8 * l);
+        // ---- phase 3: hidden = relu([x, msg] W0^T) -> H (256 features) ---------------------------------------
+        WRing<1, 2, NS> r2;
+        {
+            f32x16 hd[2][1] = {{zero16()}, {zero16()}};
+            gemm_bf16_ring_cat<2, 1, NS, KB2, 2>(hd, r0, w_hi + O0 + (size_t)(2 * ft) * TS2 + lane, w_lo + O0 + (size_t)(2 * ft) * TS2 + lane, TS2,
+                                                 xh, xl, yh, yl, ROWB, lane);
+            r2.fill(w_hi + O2 + (size_t)ft * TS2 + lane, w_lo + O2 + (size_t)ft * TS2 + lane, TS2);
+            OPHIP_STAMP(p.stamps, blockIdx.x, 6 + 8 * l);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) hd[t][0][reg] = fmaxf(hd[t][0][reg], 0.f);
+                store_featrow_acc<NS>(hd[t][0], HH, HL, HROWB, 64 * ft + 32 * t, 32 * tt, lane);
+            }
+        }
+        __syncthreads();
+        OPHIP_STAMP(p.stamps, blockIdx.x, 7 + 8 * l);
+        // ---- phase 4: o = hidden W2^T, LN2, residual ------------------------------------------------------
+        f32x16 o[1][1] = {{zero16()}};
+        gemm_bf16_ring<1, 1, NS, true, KB2, 2>(o, r2, w_hi + O2 + (size_t)ft * TS2 + lane, w_lo + O2 + (size_t)ft * TS2 + lane, TS2, hh, hl, HROWB, 0, lane);
+        OPHIP_STAMP(p.stamps, blockIdx.x, 8 + 8 * l);
+        if (l + 1 < nl) {                        // next layer's first weights travel during LN2 and the plane rewrite
+            const bf16x8* n_hi = reinterpret_cast<const bf16x8*>(wl + LAYER_BYTES);
+            const bf16x8* n_lo = n_hi + W_ELEMS / 8;
+            rq.fill(n_hi + OQ + (size_t)ft * TS + lane, n_lo + OQ + (size_t)ft * TS + lane, TS);
+            rkv.fill(n_hi + OKV + (size_t)(2 * ft) * TS + lane, n_lo + OKV + (size_t)(2 * ft) * TS + lane, TS);
+        }
+        __syncthreads();                         // every wave is done reading H before the LayerNorm exchange reuses it
+        layernorm_featrow128(o[0][0], ln + 2 * CF, ln + 3 * CF, scratch, ft, tt, lane);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) xres[reg] += o[0][0][reg];
+        store_featrow_acc<NS>(xres, XH, XL, ROWB, 32 * ft, 32 * tt, lane);
+        __syncthreads();
+        OPHIP_STAMP(p.stamps, blockIdx.x, 9 + 8 * l);
+    }
+
+    // ---- final f32 features to the staging image, then correlation -> softmax -> expectation -------------------
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 v = {xres[4 * g], xres[4 * g + 1], xres[4 * g + 2], xres[4 * g + 3]};
+        *reinterpret_cast<f32x4*>(stage + stage_off(32 * tt + r, 8 * ft + 2 * g + h)) = v;
+    }
+    __syncthreads();
+    if (p.dbg_win) {
+        for (int mi = 0; mi < 2; ++mi) {
+            const int k = k0 + mi;
+            if (k >= total) break;
+            for (int e = tid; e < WIN * CF; e += 512) {
+                const int rr = e >> 7, c = e & 127;
+                p.dbg_win[(size_t)k * WIN * CF + e] = *reinterpret_cast<const float*>(stage + stage_off(32 * mi + rr, c >> 2) + 4 * (c & 3));
+            }
+            if (tid < CF) p.dbg_f3[(size_t)k * CF + tid] = *reinterpret_cast<const float*>(stage + stage_off(32 * mi + TOK3D, tid >> 2) + 4 * (tid & 3));
+        }
+    }
+    if (ft == 0 && k0 + tt < total) {
+        const int k = k0 + tt, base = 32 * tt;
+        float t = -INFINITY;
+        if (lane < WIN) {
+            float dot = 0.f;
+            for (int c4 = 0; c4 < CF / 4; ++c4) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(stage + stage_off(base + TOK3D, c4));
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(stage + stage_off(base + lane, c4));
+                dot += a[0] * bq[0];
+                dot += a[1] * bq[1];
+                dot += a[2] * bq[2];
+                dot += a[3] * bq[3];
+            }
+            t = dot * 0.08838834764831845f;              // 1 / sqrt(128)
+        }
+        const float m = wave_max(t);
+        const float e = lane < WIN ? expf(t - m) : 0.f;
+        const float sum = wave_sum(e);
+        const float pr = e / sum;
+        const float gx = (float)(lane % 5 - 2) * 0.5f, gy = (float)(lane / 5 - 2) * 0.5f;
+        const float ex = wave_sum(pr * gx), ey = wave_sum(pr * gy);
+        const float ex2 = wave_sum(pr * gx * gx), ey2 = wave_sum(pr * gy * gy);
+        if (lane == 0) {
+            const float vx = ex2 - ex * ex, vy = ey2 - ey * ey;
+            const float sd = sqrtf(fmaxf(vx, 1e-10f)) + sqrtf(fmaxf(vy, 1e-10f));
+            p.expec_f[3 * k] = ex; p.expec_f[3 * k + 1] = ey; p.expec_f[3 * k + 2] = sd;
+            p.mkq_f[2 * k] = p.mkq_c[2 * k] + ex * p.fine_scale;
+            p.mkq_f[2 * k + 1] = p.mkq_c[2 * k + 1] + ey * p.fine_scale;
+        }
+    }
+    OPHIP_STAMP(p.stamps, blockIdx.x, 31);
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes, const char* what) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return e == hipSuccess ? 0 : ophip_fail(e, what);
+}
+
+}  // namespace
+
+extern "C" size_t ophip_fine_bf16_wpack_bytes(int nlayers) { return (size_t)nlayers * ((size_t)2 * W_ELEMS * 2 + 4 * CF * 4); }
+
+extern "C" int ophip_fine_refine_bf16(const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x, int hf, int wf,
+                                      const float* desc3d_f, long long ds_b, long long ds_c,
+                                      const long long* b_ids, const long long* i_ids, const long long* j_ids, const int* count, int max_matches,
+                                      const float* mkpts_c, const void* wpack, int nlayers, unsigned cross_bits, int encoder_enable, int nsplit,
+                                      int wc, int stride, float fine_scale, float* expec_f, float* mkpts_f,
+                                      float* dbg_win, float* dbg_f3, void* stream_) {
+    if (!feat_f || !desc3d_f || !b_ids || !i_ids || !j_ids || !count || !mkpts_c || !expec_f || !mkpts_f)
+        return ophip_bad_arg(__func__, "null pointer");
+    if (encoder_enable && (!wpack || nlayers < 1 || nlayers > 32)) return ophip_bad_arg(__func__, "encoder enabled without weights");
+    if (nsplit != 1 && nsplit != 3) return ophip_bad_arg(__func__, "nsplit must be 1 (bf16) or 3 (split bf16)");
+    if ((dbg_win == nullptr) != (dbg_f3 == nullptr)) return ophip_bad_arg(__func__, "dbg_win and dbg_f3 go together");
+    if (max_matches <= 0) return 0;
+    FineBArgs a;
+    a.feat_f = feat_f; a.fs_b = fs_b; a.fs_c = fs_c; a.fs_y = fs_y; a.fs_x = fs_x; a.hf = hf; a.wf = wf;
+    a.desc_f = desc3d_f; a.ds_b = ds_b; a.ds_c = ds_c;
+    a.b_ids = b_ids; a.i_ids = i_ids; a.j_ids = j_ids; a.count = count; a.mkq_c = mkpts_c;
+    a.wpack = reinterpret_cast<const char*>(wpack); a.nlayers = nlayers; a.cross_bits = cross_bits; a.enc_enable = encoder_enable;
+    a.wc = wc; a.stride = stride; a.fine_scale = fine_scale;
+    a.expec_f = expec_f; a.mkq_f = mkpts_f; a.dbg_win = dbg_win; a.dbg_f3 = dbg_f3;
+    a.stamps = ophip_stamp_buffer();
+    hipStream_t stream = (hipStream_t)stream_;
+    const int grid = (max_matches + 1) / 2;
+    const size_t lds = nsplit == 3 ? (size_t)(32 + 32 + 64) * 1024 : (size_t)(16 + 16 + 32) * 1024;
+    static bool attr[2] = {false, false};
+    if (nsplit == 3) {
+        if (!attr[1]) { if (int rc = set_lds(fine_refine_bf16_kernel<3>, lds, "hipFuncSetAttribute(fine_refine_bf16)")) return rc; attr[1] = true; }
+        OPHIP_LAUNCH("fine_refine", stream, fine_refine_bf16_kernel<3>, dim3(grid), dim3(512), lds, stream, a);
+    } else {
+        if (!attr[0]) { if (int rc = set_lds(fine_refine_bf16_kernel<1>, lds, "hipFuncSetAttribute(fine_refine_bf16)")) return rc; attr[0] = true; }
+        OPHIP_LAUNCH("fine_refine", stream, fine_refine_bf16_kernel<1>, dim3(grid), dim3(512), lds, stream, a);
+    }
+    OPHIP_CHECK_LAUNCH();
+    return 0;
+}

@@ -163,3 +163,11 @@ struct ophip_timed {
         ophip_timed t__(NAME, (STREAM));                        \
         hipLaunchKernelGGL(__VA_ARGS__);                        \
     } while (0)
+
+// Diagnostic cycle stamps (NULL in production): ophip_debug_stamps(buf) makes the instrumented kernels record
+// s_memtime at phase boundaries, 32 slots per workgroup, written by one lane.  Never read by any kernel.
+extern "C" unsigned long long* ophip_stamp_buffer(void);
+#define OPHIP_STAMP(buf, wg, slot)                                                        \
+    do {                                                                                  \
+        if ((buf) && threadIdx.x == 0) (buf)[(size_t)(wg) * 32 + (slot)] = __builtin_readcyclecounter(); \
+    } while (0)

@@ -27,6 +27,14 @@ __device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
     lo = (__bf16)(v - (float)hi);
 }
 
+// Fast transcendental forms for the bf16 / split-bf16 modes (their error budget is ~1e-5, these are ~1e-6):
+// exp via v_exp_f32 (2^x), reciprocal via v_rcp_f32.  The exact-f32 kernels keep libm expf and true division.
+__device__ __forceinline__ float elu_plus_one_fast(float x) { return x > 0.f ? x + 1.0f : __expf(x); }
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// lane-uniform-per-lane select of a whole fragment (4 packed registers)
+__device__ __forceinline__ bf16x8 select_frag(bool keep, const bf16x8& v, const bf16x8& z) { return keep ? v : z; }
+
 __device__ __forceinline__ bf16x8 zero_bf8() {
     bf16x8 z;
 #pragma unroll
@@ -45,7 +53,8 @@ __device__ __forceinline__ f32x16 mma_bf16(const bf16x8& ahi, const bf16x8& alo,
 }
 
 // byte offset of 16-byte chunk `chunk` of row `row` in a swizzled plane with row pitch `rowb`
-__device__ __forceinline__ int plane_off(int row, int chunk, int rowb) { return row * rowb + ((chunk ^ (row & 15)) << 4); }
+// (`swz` = 15 for rows of >= 16 chunks; 7 for 8-chunk rows (128-byte pitch): then rows r and r + 8 share a slot: 2-way)
+__device__ __forceinline__ int plane_off(int row, int chunk, int rowb, int swz = 15) { return row * rowb + ((chunk ^ (row & swz)) << 4); }
 
 // registers 8s..8s+7 of an accumulator as a (hi, lo) fragment
 template <int NS>
@@ -59,27 +68,49 @@ __device__ __forceinline__ void acc_frag(const f32x16& a, int s, bf16x8& hi, bf1
     }
 }
 
+// Register ring of packed weight fragments, PD k-blocks deep, NT output tiles wide.  fill() issues the first PD k-blocks;
+// it is called one phase AHEAD of the GEMM that consumes it (weights do not depend on data), so that the L2 round trip
+// of a GEMM's first fragments overlaps the previous phase's MFMAs, epilogue and barrier.
+template <int NT, int PD, int NS>
+struct WRing {
+    bf16x8 hi[PD][NT], lo[PD][NT];
+    __device__ __forceinline__ void fill(const bf16x8* __restrict__ whi, const bf16x8* __restrict__ wlo, int tstride) {
+#pragma unroll
+        for (int p = 0; p < PD; ++p)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                hi[p][t] = whi[(size_t)t * tstride + (size_t)p * 64];
+                lo[p][t] = (NS == 3) ? wlo[(size_t)t * tstride + (size_t)p * 64] : zero_bf8();
+            }
+    }
+};
+
+// registers 8s..8s+7 of an accumulator, each mapped through f(reg, value), as a (hi, lo) fragment
+template <int NS, class F>
+__device__ __forceinline__ void acc_frag_map(const f32x16& a, int s, F f, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        __bf16 hh, ll;
+        split_bf16(f(8 * s + j, a[8 * s + j]), hh, ll);
+        hi[j] = hh;
+        lo[j] = (NS == 3) ? ll : (__bf16)0.f;
+    }
+}
+
 // GEMM of a packed weight matrix against an LDS activation tile.
 //   W_IS_A = true :  acc[t][tt] += W(tile t)[32 x K] . Act(token tile tt)[32 x K]^T   -> D[feature row][token col]
 //   W_IS_A = false:  acc[t][tt] += Act(tt)[32 x K] . W(t)[32 x K]^T                   -> D[token row][feature col]
 // whi/wlo point at [first tile of this wave][first k-block][lane]; tstride = fragments between tiles (= KB_total * 64).
 // act_hi/act_lo: swizzled planes; chunk0 = first 16-byte chunk of the activation row that k-block 0 reads.
-// Weight fragments stream L2 -> VGPR through a register ring PD k-blocks deep (compile-time slots): the kernels run
-// one wave per SIMD, so the ring is what hides the L2 round trip (~600 ns under load) behind the MFMAs.
-// KBLOCKS must be a multiple of PD.
+// Weight fragments stream L2 -> VGPR through the ring (compile-time slots): the kernels run one wave per SIMD, so the
+// ring is what hides the L2 round trip behind the MFMAs.  KBLOCKS must be a multiple of PD.  `ring` must have been
+// filled from the same whi/wlo/tstride.
 template <int NT, int TT, int NS, bool W_IS_A, int KBLOCKS, int PD>
-__device__ __forceinline__ void gemm_bf16(f32x16 (&acc)[NT][TT], const bf16x8* __restrict__ whi, const bf16x8* __restrict__ wlo,
-                                          int tstride, const char* act_hi, const char* act_lo, int rowb, int chunk0, int lane) {
+__device__ __forceinline__ void gemm_bf16_ring(f32x16 (&acc)[NT][TT], WRing<NT, PD, NS>& ring, const bf16x8* __restrict__ whi,
+                                               const bf16x8* __restrict__ wlo, int tstride, const char* act_hi, const char* act_lo,
+                                               int rowb, int chunk0, int lane, int swz = 15) {
     static_assert(KBLOCKS % PD == 0, "k-blocks must be a multiple of the prefetch depth");
     const int r = lane & 31, h = lane >> 5;
-    bf16x8 w_hi[PD][NT], w_lo[PD][NT];
-#pragma unroll
-    for (int p = 0; p < PD; ++p)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            w_hi[p][t] = whi[(size_t)t * tstride + (size_t)p * 64];
-            w_lo[p][t] = (NS == 3) ? wlo[(size_t)t * tstride + (size_t)p * 64] : zero_bf8();
-        }
     for (int kb0 = 0; kb0 < KBLOCKS; kb0 += PD) {
 #pragma unroll
         for (int p = 0; p < PD; ++p) {
@@ -87,7 +118,7 @@ __device__ __forceinline__ void gemm_bf16(f32x16 (&acc)[NT][TT], const bf16x8* _
             bf16x8 x_hi[TT], x_lo[TT];
 #pragma unroll
             for (int tt = 0; tt < TT; ++tt) {
-                const int off = plane_off(32 * tt + r, chunk0 + 2 * kb + h, rowb);
+                const int off = plane_off(32 * tt + r, chunk0 + 2 * kb + h, rowb, swz);
                 x_hi[tt] = *reinterpret_cast<const bf16x8*>(act_hi + off);
                 x_lo[tt] = (NS == 3) ? *reinterpret_cast<const bf16x8*>(act_lo + off) : zero_bf8();
             }
@@ -95,24 +126,72 @@ __device__ __forceinline__ void gemm_bf16(f32x16 (&acc)[NT][TT], const bf16x8* _
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int tt = 0; tt < TT; ++tt)
-                    acc[t][tt] = W_IS_A ? mma_bf16<NS>(w_hi[p][t], w_lo[p][t], x_hi[tt], x_lo[tt], acc[t][tt])
-                                        : mma_bf16<NS>(x_hi[tt], x_lo[tt], w_hi[p][t], w_lo[p][t], acc[t][tt]);
-            // refill this ring slot with k-block kb + PD (the tail re-reads the last block: harmless, keeps the loop uniform)
-            const int kn = (kb + PD < KBLOCKS) ? kb + PD : KBLOCKS - 1;
+                    acc[t][tt] = W_IS_A ? mma_bf16<NS>(ring.hi[p][t], ring.lo[p][t], x_hi[tt], x_lo[tt], acc[t][tt])
+                                        : mma_bf16<NS>(x_hi[tt], x_lo[tt], ring.hi[p][t], ring.lo[p][t], acc[t][tt]);
+            // refill this slot with k-block kb + PD (nothing to fetch at the tail)
+            if (kb + PD < KBLOCKS) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                w_hi[p][t] = whi[(size_t)t * tstride + (size_t)kn * 64];
-                if (NS == 3) w_lo[p][t] = wlo[(size_t)t * tstride + (size_t)kn * 64];
+                for (int t = 0; t < NT; ++t) {
+                    ring.hi[p][t] = whi[(size_t)t * tstride + (size_t)(kb + PD) * 64];
+                    if (NS == 3) ring.lo[p][t] = wlo[(size_t)t * tstride + (size_t)(kb + PD) * 64];
+                }
             }
             __builtin_amdgcn_sched_barrier(0);      // keep the refill here (see tile.h)
         }
     }
 }
 
+// Same, with the K range split in two halves read from two plane pairs (the [x, msg] concatenation feeding the MLP):
+// k-blocks [0, KBLOCKS/2) from (a_hi, a_lo), the rest from (b_hi, b_lo); both with pitch rowb, chunk 0 first.
+template <int NT, int TT, int NS, int KBLOCKS, int PD>
+__device__ __forceinline__ void gemm_bf16_ring_cat(f32x16 (&acc)[NT][TT], WRing<NT, PD, NS>& ring, const bf16x8* __restrict__ whi,
+                                                   const bf16x8* __restrict__ wlo, int tstride, const char* a_hi, const char* a_lo,
+                                                   const char* b_hi, const char* b_lo, int rowb, int lane) {
+    static_assert(KBLOCKS % (2 * PD) == 0, "each half must be a multiple of the prefetch depth");
+    const int r = lane & 31, h = lane >> 5;
+    for (int kb0 = 0; kb0 < KBLOCKS; kb0 += PD) {
+        const bool second = kb0 >= KBLOCKS / 2;
+        const char* s_hi = second ? b_hi : a_hi;
+        const char* s_lo = second ? b_lo : a_lo;
+        const int kbase = second ? kb0 - KBLOCKS / 2 : kb0;
+#pragma unroll
+        for (int p = 0; p < PD; ++p) {
+            const int kb = kb0 + p;
+            bf16x8 x_hi[TT], x_lo[TT];
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) {
+                const int off = plane_off(32 * tt + r, 2 * (kbase + p) + h, rowb);
+                x_hi[tt] = *reinterpret_cast<const bf16x8*>(s_hi + off);
+                x_lo[tt] = (NS == 3) ? *reinterpret_cast<const bf16x8*>(s_lo + off) : zero_bf8();
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) acc[t][tt] = mma_bf16<NS>(ring.hi[p][t], ring.lo[p][t], x_hi[tt], x_lo[tt], acc[t][tt]);
+            if (kb + PD < KBLOCKS) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    ring.hi[p][t] = whi[(size_t)t * tstride + (size_t)(kb + PD) * 64];
+                    if (NS == 3) ring.lo[p][t] = wlo[(size_t)t * tstride + (size_t)(kb + PD) * 64];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int NT, int TT, int NS, bool W_IS_A, int KBLOCKS, int PD>
+__device__ __forceinline__ void gemm_bf16(f32x16 (&acc)[NT][TT], const bf16x8* __restrict__ whi, const bf16x8* __restrict__ wlo,
+                                          int tstride, const char* act_hi, const char* act_lo, int rowb, int chunk0, int lane, int swz = 15) {
+    WRing<NT, PD, NS> ring;
+    ring.fill(whi, wlo, tstride);
+    gemm_bf16_ring<NT, TT, NS, W_IS_A, KBLOCKS, PD>(acc, ring, whi, wlo, tstride, act_hi, act_lo, rowb, chunk0, lane, swz);
+}
+
 // Store a D[feature row][token col] accumulator into the planes: lane (token = tok0 + r, half h) owns features
 // feat0 + 8g + 4h + {0..3} in regs 4g..4g+3  ->  one 8-byte store per g and plane.
 template <int NS>
-__device__ __forceinline__ void store_featrow_acc(const f32x16& a, char* phi, char* plo, int rowb, int feat0, int tok0, int lane) {
+__device__ __forceinline__ void store_featrow_acc(const f32x16& a, char* phi, char* plo, int rowb, int feat0, int tok0, int lane, int swz = 15) {
     const int r = lane & 31, h = lane >> 5;
     const int row = tok0 + r;
 #pragma unroll
@@ -125,7 +204,7 @@ __device__ __forceinline__ void store_featrow_acc(const f32x16& a, char* phi, ch
             vh[j] = hh;
             vl[j] = ll;
         }
-        const int off = plane_off(row, (feat0 >> 3) + g, rowb) + 8 * h;
+        const int off = plane_off(row, (feat0 >> 3) + g, rowb, swz) + 8 * h;
         *reinterpret_cast<bf16x4*>(phi + off) = vh;
         if (NS == 3) *reinterpret_cast<bf16x4*>(plo + off) = vl;
     }

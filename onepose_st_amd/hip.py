@@ -25,6 +25,7 @@ _SIGNATURES = {
     "ophip_device_info": (c_i, [ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.c_char_p, c_i]),
     "ophip_timing_select": (c_i, [ctypes.c_char_p]),
     "ophip_timing_read": (c_i, [ctypes.POINTER(c_i), ctypes.POINTER(ctypes.c_double)]),
+    "ophip_debug_stamps": (c_i, [ctypes.c_void_p]),
     "ophip_pe_add_transpose": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_void_p]),
     "ophip_transpose_cl": (c_i, [c_f, c_f, c_i, c_i, c_i, ctypes.c_void_p]),
     "ophip_kpt_encode": (c_i, [c_f, c_ll, c_f, c_ll, c_f, c_f, c_f, c_i, c_i, ctypes.c_void_p]),
@@ -35,9 +36,12 @@ _SIGNATURES = {
     "ophip_encoder_layer_bf16": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_i, c_i, c_f, ctypes.c_void_p]),
     "ophip_coarse_workspace_floats": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "ophip_coarse_match": (c_i, [c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_i, ctypes.c_double, ctypes.c_float, c_i, ctypes.c_float,
-                                 c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, ctypes.c_void_p]),
+                                 c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, ctypes.c_void_p]),
     "ophip_fine_refine": (c_i, [c_f, c_ll, c_ll, c_ll, c_ll, c_i, c_i, c_f, c_ll, c_ll, c_f, c_f, c_f, c_f, c_i,
                                 c_f, c_f, c_i, ctypes.c_uint, c_i, c_i, c_i, ctypes.c_float, c_f, c_f, c_f, c_f, ctypes.c_void_p]),
+    "ophip_fine_bf16_wpack_bytes": (ctypes.c_size_t, [c_i]),
+    "ophip_fine_refine_bf16": (c_i, [c_f, c_ll, c_ll, c_ll, c_ll, c_i, c_i, c_f, c_ll, c_ll, c_f, c_f, c_f, c_f, c_i,
+                                     c_f, c_f, c_i, ctypes.c_uint, c_i, c_i, c_i, c_i, ctypes.c_float, c_f, c_f, c_f, c_f, ctypes.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

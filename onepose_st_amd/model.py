@@ -142,6 +142,7 @@ class OnePosePlus_model(nn.Module):
         if self.precision != "f32":
             blocks["coarse_bf16"] = [packing.pack_coarse_layer_bf16(sd, f"loftr_coarse.layers.{i}.").to(device)
                                      for i in range(len(self.loftr_coarse.layer_names))]
+            blocks["fine_bf16"] = packing.pack_fine_layers_bf16(sd, "loftr_fine.layers.", len(self.loftr_fine.layer_names)).to(device)
         self._packed = (key, blocks)
         return blocks
 
@@ -250,7 +251,7 @@ class OnePosePlus_model(nn.Module):
             lib_call("ophip_coarse_match", P(x3d), P(x2d), P(kpts_d), bstride(kpts_d), B, N, M, wc,
                      float(cm["dual_softmax"]["temperature"]), float(cm["thr"]), int(cm["border_rm"]), float(scale),
                      P(conf), P(cws), P(b_ids, torch.int64), P(i_ids, torch.int64), P(j_ids, torch.int64),
-                     P(mconf), P(mk3d), P(mkc), P(count, torch.int32), S)
+                     P(mconf), P(mk3d), P(mkc), P(count, torch.int32), {"f32": 0, "bf16": 1, "bf16x3": 3}[self.precision], S)
         data["conf_matrix"] = conf
 
         fine_on = bool(cfg["fine_matching"]["enable"])
@@ -267,11 +268,19 @@ class OnePosePlus_model(nn.Module):
             stride = hf // hc
             fine_scale = (cf["window_size"] // 2) * (data["q_hw_i"][0] / hf)
             max_matches = min(cap, B * min(N, M) + 64)      # mutual matches are one per row and (barring exact ties) per column
-            lib_call("ophip_fine_refine", P(ff), ff.stride(0), ff.stride(1), ff.stride(2), ff.stride(3), hf, wf,
-                     P(desc_fine_d), bstride(desc_fine_d), desc_fine_d.stride(1),
-                     P(b_ids, torch.int64), P(i_ids, torch.int64), P(j_ids, torch.int64), P(count, torch.int32), max_matches,
-                     P(mkc), P(W["fine"]), len(names_f), ctypes.c_uint(cross_bits), 1 if cf["enable"] else 0,
-                     wc, stride, float(fine_scale), P(expec), P(mkf), P(dbg_w), P(dbg_3), S)
+            if self.precision == "f32":
+                lib_call("ophip_fine_refine", P(ff), ff.stride(0), ff.stride(1), ff.stride(2), ff.stride(3), hf, wf,
+                         P(desc_fine_d), bstride(desc_fine_d), desc_fine_d.stride(1),
+                         P(b_ids, torch.int64), P(i_ids, torch.int64), P(j_ids, torch.int64), P(count, torch.int32), max_matches,
+                         P(mkc), P(W["fine"]), len(names_f), ctypes.c_uint(cross_bits), 1 if cf["enable"] else 0,
+                         wc, stride, float(fine_scale), P(expec), P(mkf), P(dbg_w), P(dbg_3), S)
+            else:
+                lib_call("ophip_fine_refine_bf16", P(ff), ff.stride(0), ff.stride(1), ff.stride(2), ff.stride(3), hf, wf,
+                         P(desc_fine_d), bstride(desc_fine_d), desc_fine_d.stride(1),
+                         P(b_ids, torch.int64), P(i_ids, torch.int64), P(j_ids, torch.int64), P(count, torch.int32), max_matches,
+                         P(mkc), P(W["fine_bf16"], None), len(names_f), ctypes.c_uint(cross_bits), 1 if cf["enable"] else 0,
+                         3 if self.precision == "bf16x3" else 1,
+                         wc, stride, float(fine_scale), P(expec), P(mkf), P(dbg_w), P(dbg_3), S)
 
         K = int(count.item())                       # the one host sync of the frame
         if fine_on and K > min(cap, B * min(N, M) + 64):

@@ -109,3 +109,21 @@ def pack_coarse_layer_bf16(sd: dict, prefix: str) -> torch.Tensor:
     out = _bytes(hi, lo, torch.cat(_ln(sd, prefix)))
     assert out.numel() == 2 * 2 * 10 * 256 * 256 + 16 * 256
     return out
+
+
+def pack_fine_layers_bf16(sd: dict, prefix: str, n_layers: int) -> torch.Tensor:
+    """uint8 block for ``ophip_fine_refine_bf16``: per layer ``[hi: Wq | Wkv | Wm | W0 | W2][lo: same][ln f32]`` where
+    ``Wkv`` stacks per wave w = 0..3 ``Wk[32w:32w+32]`` then ``Wv[32w:32w+32]`` (``prefix`` like ``"loftr_fine.layers."``)."""
+    blocks = []
+    for i in range(n_layers):
+        p = f"{prefix}{i}."
+        wq, wk, wv = (sd[p + n + ".weight"] for n in ("q_proj", "k_proj", "v_proj"))
+        if tuple(wq.shape) != (128, 128):
+            raise ValueError("fine encoder kernel is specialised for d_model = 128")
+        wkv = torch.cat([torch.cat([wk[32 * w:32 * w + 32], wv[32 * w:32 * w + 32]], 0) for w in range(4)], 0)
+        flat = torch.cat([pack_linear_frag16(m) for m in (wq, wkv, sd[p + "merge.weight"], sd[p + "mlp.0.weight"], sd[p + "mlp.2.weight"])])
+        hi, lo = split_planes(flat)
+        blocks.append(_bytes(hi, lo, torch.cat(_ln(sd, p))))
+    out = torch.cat(blocks)
+    assert out.numel() == n_layers * (2 * 2 * 10 * 128 * 128 + 16 * 128)
+    return out

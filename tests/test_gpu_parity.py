@@ -127,7 +127,7 @@ def test_encoder_layer_bf16(sd, dev, nsplit, rtol, atol, cross, B, L3, L2):
     close(y2, r2, rtol=rtol, atol=atol, msg="2D stream")
 
 
-def _coarse_match(dev, f3, f2, kp, wc, thr=0.1, border=2, temp=0.08, scale=8.0):
+def _coarse_match(dev, f3, f2, kp, wc, thr=0.1, border=2, temp=0.08, scale=8.0, nsplit=0):
     B, N, _ = f3.shape
     M = f2.shape[1]
     cap = B * N
@@ -139,7 +139,7 @@ def _coarse_match(dev, f3, f2, kp, wc, thr=0.1, border=2, temp=0.08, scale=8.0):
     kd, f3d, f2d = kp.to(dev), f3.to(dev), f2.to(dev)      # keep the device copies alive across the call
     hip.call("ophip_coarse_match", hip.ptr(f3d), hip.ptr(f2d), hip.ptr(kd), kd.stride(0), B, N, M, wc,
              temp, thr, border, scale, hip.ptr(conf), hip.ptr(ws), *[hip.ptr(t, torch.int64) for t in ids],
-             hip.ptr(mconf), hip.ptr(mk3), hip.ptr(mkc), hip.ptr(cnt, torch.int32), hip.stream_handle())
+             hip.ptr(mconf), hip.ptr(mk3), hip.ptr(mkc), hip.ptr(cnt, torch.int32), nsplit, hip.stream_handle())
     K = int(cnt.item())
     return conf, [t[:K] for t in ids], mconf[:K], mk3[:K], mkc[:K]
 
@@ -154,18 +154,21 @@ def _planted_features(B, N, hc, wc, seed, n_plant):
     return f3 * 1.5, f2
 
 
+@pytest.mark.parametrize("nsplit,rtol", [(0, 1e-4), (3, 1e-3), (1, 0.5)])
 @pytest.mark.parametrize("B,N,hc,wc", [(1, 300, 10, 13), (2, 129, 9, 9), (1, 1000, 30, 40)])
-def test_coarse_match_vs_oracle(dev, B, N, hc, wc):
+def test_coarse_match_vs_oracle(dev, B, N, hc, wc, nsplit, rtol):
+    """similarity GEMM in exact f32 (0), split-bf16 (3) or bf16 (1).  conf = exp(.) products, so its relative error
+    is the absolute error of the logits (|sim| up to ~40 here): 1e-4 / 1e-3 / O(0.1)."""
     f3, f2 = _planted_features(B, N, hc, wc, 3, min(N, hc * wc) // 2)
     kp = torch.randn(B, N, 3, generator=torch.Generator().manual_seed(4))
     ref_conf = orc.dual_softmax_confidence(f3, f2, 0.08)
     ref = orc.coarse_match_select(ref_conf, (hc, wc), (hc * 8, wc * 8), kp, 0.1, 2)
-    conf, (b_ids, i_ids, j_ids), mconf, mk3, mkc = _coarse_match(dev, f3, f2, kp, wc)
-    close(conf, ref_conf, rtol=1e-4, atol=1e-7, msg="conf_matrix")
+    conf, (b_ids, i_ids, j_ids), mconf, mk3, mkc = _coarse_match(dev, f3, f2, kp, wc, nsplit=nsplit)
+    close(conf, ref_conf, rtol=rtol, atol=1e-7, msg="conf_matrix")
     assert len(ref["i_ids"]) > 10
     for got, want in ((b_ids, ref["b_ids"]), (i_ids, ref["i_ids"]), (j_ids, ref["j_ids"])):
         assert got.dtype == torch.int64 and torch.equal(got.cpu(), want)
-    close(mconf, ref["mconf"], atol=1e-6)
+    close(mconf, ref["mconf"], rtol=rtol, atol=1e-6)
     assert torch.equal(mk3.cpu(), ref["mkpts_3d_db"]) and torch.equal(mkc.cpu(), ref["mkpts_query_c"])
 
 
@@ -201,14 +204,15 @@ def test_coarse_match_empty(dev):
     close(conf, orc.dual_softmax_confidence(f3, f2, 0.08), atol=1e-7)
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16"])
 @pytest.mark.parametrize("channels_last", [False, True])
-def test_fine_refine_vs_oracle(sd, cfg, dev, channels_last):
+def test_fine_refine_vs_oracle(sd, cfg, dev, channels_last, mode):
     B, N, hc, wc = 2, 90, 6, 7
     hf, wf = hc * 4, wc * 4
     g = torch.Generator().manual_seed(7)
     feat_f = torch.randn(B, 128, hf, wf, generator=g)
     desc = torch.randn(B, 128, N, generator=g)
-    K = 37
+    K = 37                                       # odd: the last bf16 workgroup holds a single match
     b_ids = torch.sort(torch.randint(0, B, (K,), generator=g))[0]
     i_ids = torch.randint(0, N, (K,), generator=g)
     j_ids = torch.randint(0, hc * wc, (K,), generator=g)
@@ -221,7 +225,6 @@ def test_fine_refine_vs_oracle(sd, cfg, dev, channels_last):
     if channels_last:
         ff = ff.contiguous(memory_format=torch.channels_last)
         assert ff.stride(1) == 1
-    w = torch.cat([packing.pack_fine_layer(sd, f"loftr_fine.layers.{i}.") for i in range(2)]).to(dev)
     cap = 64
     pad = lambda t: torch.cat([t, torch.zeros(cap - K, *t.shape[1:], dtype=t.dtype)]).to(dev)
     bd, idd, jd, mkd = pad(b_ids), pad(i_ids), pad(j_ids), pad(mkc)
@@ -230,16 +233,26 @@ def test_fine_refine_vs_oracle(sd, cfg, dev, channels_last):
     mkf = torch.full((cap, 2), float("nan"), device=dev)
     dw, d3 = torch.empty(cap, 25, 128, device=dev), torch.empty(cap, 128, device=dev)
     dd = desc.to(dev)
-    hip.call("ophip_fine_refine", hip.ptr(ff), ff.stride(0), ff.stride(1), ff.stride(2), ff.stride(3), hf, wf,
-             hip.ptr(dd), dd.stride(0), dd.stride(1), hip.ptr(bd, torch.int64), hip.ptr(idd, torch.int64), hip.ptr(jd, torch.int64),
-             hip.ptr(cnt, torch.int32), cap, hip.ptr(mkd), hip.ptr(w), 2, ctypes.c_uint(2), 1, wc, 4, 4.0,
-             hip.ptr(expec), hip.ptr(mkf), hip.ptr(dw), hip.ptr(d3), hip.stream_handle())
-    close(dw[:K], wino, msg="fine encoder, window stream")
-    close(d3[:K], f3o[:, 0], msg="fine encoder, 3D stream")
-    close(expec[:K, :2], ref["expec_f"][:, :2], msg="expec_f xy")
-    close(expec[:K, 2], ref["expec_f"][:, 2], rtol=1e-3, atol=1e-3, msg="expec_f std (ill-conditioned, see test_oracle_golden)")
-    close(mkf[:K], ref["mkpts_query_f"], msg="mkpts_query_f")
-    assert torch.isnan(expec[K:]).all()          # surplus workgroups exit without writing
+    head = (hip.ptr(ff), ff.stride(0), ff.stride(1), ff.stride(2), ff.stride(3), hf, wf, hip.ptr(dd), dd.stride(0), dd.stride(1),
+            hip.ptr(bd, torch.int64), hip.ptr(idd, torch.int64), hip.ptr(jd, torch.int64), hip.ptr(cnt, torch.int32), cap, hip.ptr(mkd))
+    tail = (wc, 4, 4.0, hip.ptr(expec), hip.ptr(mkf), hip.ptr(dw), hip.ptr(d3), hip.stream_handle())
+    if mode == "f32":
+        w = torch.cat([packing.pack_fine_layer(sd, f"loftr_fine.layers.{i}.") for i in range(2)]).to(dev)
+        hip.call("ophip_fine_refine", *head, hip.ptr(w), 2, ctypes.c_uint(2), 1, *tail)
+        rt, at = RTOL, ATOL
+    else:
+        w = packing.pack_fine_layers_bf16(sd, "loftr_fine.layers.", 2).to(dev)
+        assert w.numel() == hip.load().ophip_fine_bf16_wpack_bytes(2)
+        hip.call("ophip_fine_refine_bf16", *head, hip.ptr(w, None), 2, ctypes.c_uint(2), 1, 3 if mode == "bf16x3" else 1, *tail)
+        rt, at = (5e-4, 2e-4) if mode == "bf16x3" else (1e-1, 1e-1)
+    print(f"{mode}: fine encoder max abs err window {(dw[:K].cpu() - wino).abs().max().item():.3e}, "
+          f"3D {(d3[:K].cpu() - f3o[:, 0]).abs().max().item():.3e}, mkpts_f {(mkf[:K].cpu() - ref['mkpts_query_f']).abs().max().item():.3e} px")
+    close(dw[:K], wino, rtol=rt, atol=at, msg="fine encoder, window stream")
+    close(d3[:K], f3o[:, 0], rtol=rt, atol=at, msg="fine encoder, 3D stream")
+    close(expec[:K, :2], ref["expec_f"][:, :2], rtol=rt, atol=at, msg="expec_f xy")
+    close(expec[:K, 2], ref["expec_f"][:, 2], rtol=max(rt, 1e-3), atol=max(at, 1e-3), msg="expec_f std (ill-conditioned, see test_oracle_golden)")
+    close(mkf[:K], ref["mkpts_query_f"], rtol=rt, atol=4 * at, msg="mkpts_query_f")
+    assert torch.isnan(expec[K:]).all()          # surplus workgroups / the empty half of the last one write nothing
 
 
 # ------------------------------------------------------------------------------------------------
