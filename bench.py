@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="frames per step")
     ap.add_argument("--workload", default="c2", choices=sorted(CONFIG_SIZES))
     ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames per rank (cycled)")
-    ap.add_argument("--precision", default=os.environ.get("OPHIP_PRECISION", "f32"), choices=["f32", "bf16x3", "bf16"],
+    ap.add_argument("--precision", default=os.environ.get("OPHIP_PRECISION", "bf16x3"), choices=["f32", "bf16x3", "bf16"],
                     help="matrix arithmetic of the encoder kernels (see DESIGN.md section 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)

@@ -30,6 +30,10 @@ struct SimArgs {
     float temp;          // temperature + 1e-4
 };
 
+// exact-f32 mode keeps libm expf; the bf16 modes (error budget ~1e-5) use v_exp_f32
+template <bool FAST>
+__device__ __forceinline__ float exp_sel(float x) { return FAST ? __expf(x) : expf(x); }
+
 __device__ __forceinline__ void merge_ms(float& m, float& e, float m2, float e2) {
     const float mm = fmaxf(m, m2);
     if (mm == -INFINITY) { m = mm; e = 0.f; return; }
@@ -49,6 +53,7 @@ __device__ __forceinline__ float half_sum(float v) {
 }
 
 // Shared epilogue of the similarity kernels: S = acc / T', row / column (max, sum exp) of this 128 x 128 tile.
+template <bool FAST>
 __device__ __forceinline__ void sim_epilogue(f32x16 (&acc)[2][2], const SimArgs& p, float (&rowst)[2][TM][2], float (&colst)[2][TN][2],
                                              int tid, int i0, int j0, int b) {
     const int lane = tid & 63, wave = tid >> 6;
@@ -74,7 +79,7 @@ __device__ __forceinline__ void sim_epilogue(f32x16 (&acc)[2][2], const SimArgs&
             }
             const float m = half_max(fmaxf(v[0], v[1]));
             float e = 0.f;
-            if (m != -INFINITY) e = expf(v[0] - m) + expf(v[1] - m);
+            if (m != -INFINITY) e = exp_sel<FAST>(v[0] - m) + exp_sel<FAST>(v[1] - m);
             e = half_sum(e);
             if (r == 0) { rowst[wc][lrow][0] = m; rowst[wc][lrow][1] = e; }
         }
@@ -97,7 +102,7 @@ __device__ __forceinline__ void sim_epilogue(f32x16 (&acc)[2][2], const SimArgs&
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const bool iv = (i0 + 64 * wr + 32 * x + acc_row(reg, h)) < p.N;
-                    e += iv ? expf(acc[x][y][reg] - m) : 0.f;
+                    e += iv ? exp_sel<FAST>(acc[x][y][reg] - m) : 0.f;
                 }
         }
         e += __shfl_xor(e, 32, 64);
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(256) void sim_stats_kernel(SimArgs p) {
         }
     }
 
-    sim_epilogue(acc, p, rowst, colst, tid, i0, j0, b);
+    sim_epilogue<false>(acc, p, rowst, colst, tid, i0, j0, b);
 }
 
 // Same tile on the bf16 matrix pipe.  K chunks of 64 features are staged as (hi, lo) bf16 planes with a 144-byte row
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_stats_bf16
             __syncthreads();
         }
     }
-    sim_epilogue(acc, p, rowst, colst, tid, i0, j0, b);
+    sim_epilogue<true>(acc, p, rowst, colst, tid, i0, j0, b);
 }
 
 struct CombineArgs {
@@ -333,7 +338,7 @@ constexpr int CONF_ROWS = 16;      // rows per workgroup
 constexpr int CONF_RB = 4;         // rows in flight per thread (independent 16 B loads)
 constexpr int CONF_U = 4;          // float4 groups per thread per row  => span <= 4096 columns
 
-template <bool VEC>
+template <bool VEC, bool FAST>
 __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
     __shared__ float red_v[4][CONF_ROWS];
     __shared__ int red_j[4][CONF_ROWS];
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             // softmax over the 3D axis (dim=1: column stats) times softmax over the 2D axis (dim=2: row stats)
-                            const float c = (expf(s[q][u][e] - cm[u][e]) * cinv[u][e]) * (expf(s[q][u][e] - rm) * rinv);
+                            const float c = (exp_sel<FAST>(s[q][u][e] - cm[u][e]) * cinv[u][e]) * (exp_sel<FAST>(s[q][u][e] - rm) * rinv);
                             s[q][u][e] = c;
                             if (jq + e < je) {
                                 cbest[u][e] = fmaxf(cbest[u][e], c);
@@ -579,10 +584,11 @@ extern "C" int ophip_coarse_match(const float* feat3d, const float* feat2d, cons
     OPHIP_LAUNCH("stat_combine", stream, stat_combine_kernel, dim3((N + M + 31) / 32, B), dim3(256), 0, stream, ca);
     OPHIP_CHECK_LAUNCH();
     ConfArgs fa{conf, rowstat, colstat, rowbest, reinterpret_cast<unsigned*>(colmax), N, M, nspan, spanw, nrb};
-    if (M % 4 == 0)
-        OPHIP_LAUNCH("conf", stream, conf_kernel<true>, dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
-    else
-        OPHIP_LAUNCH("conf", stream, conf_kernel<false>, dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
+    const bool vec = M % 4 == 0, fast = nsplit != 0;
+    if (vec && fast) OPHIP_LAUNCH("conf", stream, (conf_kernel<true, true>), dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
+    else if (vec) OPHIP_LAUNCH("conf", stream, (conf_kernel<true, false>), dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
+    else if (fast) OPHIP_LAUNCH("conf", stream, (conf_kernel<false, true>), dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
+    else OPHIP_LAUNCH("conf", stream, (conf_kernel<false, false>), dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
     OPHIP_CHECK_LAUNCH();
     SelectArgs se{conf, rowbest, colmax, keypoints3d, kpts_bstride, B, N, M, nspan, wc, border_rm, thr, scale,
                   b_ids, i_ids, j_ids, mconf, mkpts3d, mkpts_c, count};

@@ -2,8 +2,9 @@
 // (tile_bf16.h).  Same three launches per layer and the same mathematics as csrc/encoder.hip (reference:
 // loftr_module/transformer.py:65-94,146-159, linear_attention.py:29-61); what changes is the mapping to the machine:
 //
-//   * a workgroup owns 64 tokens (two 32-token MFMA tiles): every weight fragment fetched from L2 feeds two tiles,
-//     and one launch at c2 is 185 workgroups = one resident wave of work on 256 CUs;
+//   * a workgroup owns 64 tokens (two 32-token MFMA tiles) and runs 8 waves: wave (tt, fw) = feature group fw of token
+//     tile tt, so each SIMD holds two waves whose dependent chains cover each other; one launch at c2 is 185 workgroups
+//     = one resident wave of work on 256 CUs; weight rings are filled one phase ahead (tile_bf16.h WRing);
 //   * operands swap roles in attn_apply: A = packed weights, B = activations, so an accumulator holds
 //     D[feature][token] -- four consecutive features of one token per lane and register quad.  Epilogues therefore
 //     write 8-byte packed bf16 quads into the [token][feature] LDS planes, LayerNorm reduces over registers (plus a
@@ -29,63 +30,60 @@ struct KvRedArgs {
     const float* x[2];
     long long xbs[2];
     int L[2];
-    int tiles[2];
+    int tiles[2];                   // 64-token workgroup tiles per stream
+    int slabs[2];                   // 32-token partial slabs per stream (= ceil(L / 32))
     const bf16x8 *w_hi, *w_lo;      // Wkv fragments
-    float* partial;                 // [B][tiles0 + tiles1][KV_PART_FLOATS]
+    float* partial;                 // [B][slabs0 + slabs1][KV_PART_FLOATS]
 };
 
 template <int NS>
-__global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void kv_reduce_bf16_kernel(KvRedArgs a) {
+__global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void kv_reduce_bf16_kernel(KvRedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PL = NS == 3 ? 2 : 1;
     char* XH = smem;
     char* XL = smem + (PL - 1) * TOK * ROWB;
+    // 8 waves: wave = 4 * tt + fw owns heads 2 fw, 2 fw + 1 (K and V tiles) of token tile tt -> one partial slab per
+    // 32 tokens; two waves per SIMD cover each other's MFMA -> VALU latencies
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fw = wave & 3, tt = wave >> 2;
     const int r = lane & 31, h = lane >> 5;
     const int tile = blockIdx.x, b = blockIdx.y;
     const int s = tile >= a.tiles[0] ? 1 : 0;
     const int lt = s ? tile - a.tiles[0] : tile;
     const int L = a.L[s], tok0 = lt * TOK;
-    load_rows_to_planes<NS, C, TOK>(XH, XL, a.x[s] + (size_t)b * a.xbs[s], tok0, L, tid, 256);
+    WRing<4, 2, NS> ring;
+    const bf16x8* whi = a.w_hi + (size_t)(4 * fw) * TS + lane;
+    const bf16x8* wlo = a.w_lo + (size_t)(4 * fw) * TS + lane;
+    ring.fill(whi, wlo, TS);                         // weights travel while the activation tile is staged
+    load_rows_to_planes<NS, C, TOK>(XH, XL, a.x[s] + (size_t)b * a.xbs[s], tok0, L, tid, 512);
     __syncthreads();
+    if (tok0 + 32 * tt >= L) return;                 // second half of a ragged last tile: no tokens, no slab
 
-    // D[token][feature]: t = 0,1 -> K of heads 2w, 2w+1;  t = 2,3 -> V of the same heads
-    f32x16 acc[4][2];
+    // D[token][feature]: t = 0,1 -> K of heads 2fw, 2fw+1;  t = 2,3 -> V of the same heads
+    f32x16 acc[4][1];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) acc[t][tt] = zero16();
-    gemm_bf16<4, 2, NS, false, KB, 4>(acc, a.w_hi + (size_t)(4 * wave) * TS + lane, a.w_lo + (size_t)(4 * wave) * TS + lane, TS,
-                                      XH, XL, ROWB, 0, lane);
-    const float flen = (float)L;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const bool valid = tok0 + 32 * tt + acc_row(reg, h) < L;
-                acc[t][tt][reg] = valid ? elu_plus_one(acc[t][tt][reg]) : 0.f;
-                acc[2 + t][tt][reg] = acc[2 + t][tt][reg] / flen;
-            }
-    bf16x8 ones, zeros = zero_bf8();
+    for (int t = 0; t < 4; ++t) acc[t][0] = zero16();
+    gemm_bf16_ring<4, 1, NS, false, KB, 2>(acc, ring, whi, wlo, TS, XH + 32 * tt * ROWB, XL + 32 * tt * ROWB, ROWB, 0, lane);
+    const float inv_len = 1.0f / (float)L;
+    const bf16x8 zeros = zero_bf8();
+    bf16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
-    float* out = a.partial + ((size_t)b * (a.tiles[0] + a.tiles[1]) + tile) * KV_PART_FLOATS;
+    auto f_k = [&](int reg, float v) { return tok0 + 32 * tt + acc_row(reg, h) < L ? elu_plus_one_fast(v) : 0.f; };   // padded tokens drop out
+    auto f_v = [&](int reg, float v) { return v * inv_len; };                                                       // values / v_length
+    float* out = a.partial + ((size_t)b * (a.slabs[0] + a.slabs[1]) + (s ? a.slabs[0] : 0) + 2 * lt + tt) * KV_PART_FLOATS;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         f32x16 kv = zero16(), ks = zero16();
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                bf16x8 khi, klo, vhi, vlo;
-                acc_frag<NS>(acc[t][tt], st, khi, klo);
-                acc_frag<NS>(acc[2 + t][tt], st, vhi, vlo);
-                kv = mma_bf16<NS>(khi, klo, vhi, vlo, kv);        // KV[d][v] += sum_tok phi(K)[tok][d] V[tok][v]
-                ks = mma_bf16<NS>(khi, klo, ones, zeros, ks);     // Ksum[d] replicated over v
-            }
-        const int head = 2 * wave + t;
+        for (int st = 0; st < 2; ++st) {
+            bf16x8 khi, klo, vhi, vlo;
+            acc_frag_map<NS>(acc[t][0], st, f_k, khi, klo);
+            acc_frag_map<NS>(acc[2 + t][0], st, f_v, vhi, vlo);
+            kv = mma_bf16<NS>(khi, klo, vhi, vlo, kv);        // KV[d][v] += sum_tok phi(K)[tok][d] V[tok][v]
+            ks = mma_bf16<NS>(khi, klo, ones, zeros, ks);     // Ksum[d] replicated over v
+        }
+        const int head = 2 * fw + t;
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             float* o = out + ((size_t)(head * 2 + st) * 64 + lane) * 8;
@@ -151,63 +149,52 @@ struct AttnBArgs {
     float srclen[2];
     const bf16x8 *w_hi, *w_lo; // layer block planes (Wq | Wkv | Wm | W0 | W2)
     const float* ln;           // g1 b1 g2 b2
+    unsigned long long* stamps;
 };
 
-// LayerNorm over the feature axis of D[feature][token] accumulators spread over the 4 waves (wave w: features
-// 64w..64w+63).  Two-pass; partial sums cross waves through `scratch` ([2][4][64] floats).  Contains 2 barriers.
-__device__ __forceinline__ void layernorm_featrow(f32x16 (&m)[2][2], const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                  float* scratch, int wave, int lane) {
+// LayerNorm over the 256 features of a token held as D[feature][token] accumulators by the 4 feature-group waves of
+// its token tile (wave (tt, fw): features 64 fw .. 64 fw + 63).  Two-pass; partial sums cross waves through `scratch`
+// ([2][4][64] floats).  Contains 2 workgroup barriers.
+__device__ __forceinline__ void layernorm_featrow(f32x16 (&m)[2][1], const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  float* scratch, int fw, int tt, int lane) {
     const int r = lane & 31, h = lane >> 5;
-    float mean[2], rstd[2];
+    const int tok = 32 * tt + r;
+    float s = 0.f;
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-        float s = 0.f;
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) s += m[t][tt][reg];
-        s += __shfl_xor(s, 32, 64);
-        if (h == 0) scratch[wave * 64 + 32 * tt + r] = s;
-    }
+        for (int reg = 0; reg < 16; ++reg) s += m[t][0][reg];
+    s += __shfl_xor(s, 32, 64);
+    if (h == 0) scratch[fw * 64 + tok] = s;
     __syncthreads();
+    const float mean = ((scratch[tok] + scratch[64 + tok]) + (scratch[128 + tok] + scratch[192 + tok])) * (1.0f / C);
+    float q = 0.f;
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-        const int tok = 32 * tt + r;
-        mean[tt] = ((scratch[tok] + scratch[64 + tok]) + (scratch[128 + tok] + scratch[192 + tok])) * (1.0f / C);
-        float q = 0.f;
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const float d = m[t][tt][reg] - mean[tt];
-                q += d * d;
-            }
-        q += __shfl_xor(q, 32, 64);
-        if (h == 0) scratch[256 + wave * 64 + tok] = q;
-    }
+        for (int reg = 0; reg < 16; ++reg) {
+            const float d = m[t][0][reg] - mean;
+            q += d * d;
+        }
+    q += __shfl_xor(q, 32, 64);
+    if (h == 0) scratch[256 + fw * 64 + tok] = q;
     __syncthreads();
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-        const int tok = 32 * tt + r;
-        const float var = ((scratch[256 + tok] + scratch[320 + tok]) + (scratch[384 + tok] + scratch[448 + tok])) * (1.0f / C);
-        rstd[tt] = 1.0f / sqrtf(var + 1e-5f);
-    }
+    const float var = ((scratch[256 + tok] + scratch[320 + tok]) + (scratch[384 + tok] + scratch[448 + tok])) * (1.0f / C);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int f0 = 64 * wave + 32 * t + 8 * g + 4 * h;
+            const int f0 = 64 * fw + 32 * t + 8 * g + 4 * h;
             const f32x4 gv = *reinterpret_cast<const f32x4*>(gamma + f0);
             const f32x4 bv = *reinterpret_cast<const f32x4*>(beta + f0);
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) m[t][tt][4 * g + j] = (m[t][tt][4 * g + j] - mean[tt]) * rstd[tt] * gv[j] + bv[j];
+            for (int j = 0; j < 4; ++j) m[t][0][4 * g + j] = (m[t][0][4 * g + j] - mean) * rstd * gv[j] + bv[j];
         }
 }
 
 template <int NS>
-__global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 1) void attn_apply_bf16_kernel(AttnBArgs a) {
+__global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void attn_apply_bf16_kernel(AttnBArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PL = NS == 3 ? 2 : 1;
     constexpr int XB = TOK * ROWB, HB = TOK * HROWB;
@@ -218,129 +205,131 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 1) void attn_apply_bf1
     char* HH = smem + 2 * PL * XB;
     char* HL = HH + (PL - 1) * HB;
     float* scratch = reinterpret_cast<float*>(HH);          // LayerNorm exchange; H is idle whenever a LayerNorm runs
+    // 8 waves: wave = 4 * tt + fw owns feature group fw (features 64 fw .. 64 fw + 63 = heads 2 fw, 2 fw + 1) of token
+    // tile tt; the two token tiles' dependent chains share each SIMD (2 waves / SIMD)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fw = wave & 3, tt = wave >> 2;
     const int r = lane & 31, h = lane >> 5;
     const int tile = blockIdx.x, b = blockIdx.y;
     const int s = tile >= a.tiles[0] ? 1 : 0;
     const int lt = s ? tile - a.tiles[0] : tile;
     const int L = a.L[s], tok0 = lt * TOK;
     const float* xg = a.x[s] + (size_t)b * a.xbs[s];
-    load_rows_to_planes<NS, C, TOK>(XH, XL, xg, tok0, L, tid, 256);
+
+    const bf16x8 *wq_hi = a.w_hi + (size_t)(2 * fw) * TS + lane, *wq_lo = a.w_lo + (size_t)(2 * fw) * TS + lane;
+    const bf16x8 *wm_hi = a.w_hi + 3 * C * C / 8 + (size_t)(2 * fw) * TS + lane, *wm_lo = a.w_lo + 3 * C * C / 8 + (size_t)(2 * fw) * TS + lane;
+    const bf16x8 *w0_hi = a.w_hi + 4 * C * C / 8 + lane, *w0_lo = a.w_lo + 4 * C * C / 8 + lane;
+    const bf16x8 *w2_hi = a.w_hi + 8 * C * C / 8 + (size_t)(2 * fw) * TS2 + lane, *w2_lo = a.w_lo + 8 * C * C / 8 + (size_t)(2 * fw) * TS2 + lane;
+    // this wave's token rows inside the planes
+    const char *xh = XH + 32 * tt * ROWB, *xl = XL + 32 * tt * ROWB;
+    const char *yh = YH + 32 * tt * ROWB, *yl = YL + 32 * tt * ROWB;
+    const char *hh = HH + 32 * tt * HROWB, *hl = HL + 32 * tt * HROWB;
+
+    WRing<2, 4, NS> rq;
+    rq.fill(wq_hi, wq_lo, TS);                       // weights travel while the activation tile is staged
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    OPHIP_STAMP(a.stamps, wg, 0);
+    load_rows_to_planes<NS, C, TOK>(XH, XL, xg, tok0, L, tid, 512);
     __syncthreads();
+    OPHIP_STAMP(a.stamps, wg, 1);
 
-    const bf16x8 *wq_hi = a.w_hi, *wq_lo = a.w_lo;
-    const bf16x8 *wm_hi = a.w_hi + 3 * C * C / 8, *wm_lo = a.w_lo + 3 * C * C / 8;
-    const bf16x8 *w0_hi = a.w_hi + 4 * C * C / 8, *w0_lo = a.w_lo + 4 * C * C / 8;
-    const bf16x8 *w2_hi = a.w_hi + 8 * C * C / 8, *w2_lo = a.w_lo + 8 * C * C / 8;
-
-    // ---- Q projection (this wave: heads 2w, 2w+1), phi, linear attention from registers -------------------
+    // ---- Q projection (heads 2fw, 2fw+1), phi, linear attention from registers -----------------------------
+    WRing<2, 4, NS> rm;
     {
-        f32x16 q[2][2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) q[t][tt] = zero16();
-        gemm_bf16<2, 2, NS, true, KB, 4>(q, wq_hi + (size_t)(2 * wave) * TS + lane, wq_lo + (size_t)(2 * wave) * TS + lane, TS, XH, XL, ROWB, 0, lane);
+        f32x16 q[2][1] = {{zero16()}, {zero16()}};
+        gemm_bf16_ring<2, 1, NS, true, KB, 4>(q, rq, wq_hi, wq_lo, TS, xh, xl, ROWB, 0, lane);
+        OPHIP_STAMP(a.stamps, wg, 2);
+        rm.fill(wm_hi, wm_lo, TS);                   // merge weights: in flight during the attention below
         const char* kvb = a.kv[s] + (size_t)b * a.kvbs;
         const float* ksum = reinterpret_cast<const float*>(kvb + KV_FRAG_BYTES);
         const float S = a.srclen[s];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int head = 2 * wave + t;
-            bf16x8 kvh[2], kvl[2], ksh[2], ksl[2];
+            const int head = 2 * fw + t;
+            f32x16 num = zero16(), den = zero16();
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) q[t][0][reg] = elu_plus_one_fast(q[t][0][reg]);
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                kvh[st] = *reinterpret_cast<const bf16x8*>(kvb + ((size_t)((head * 2 + st) * 2 + 0) * 64 + lane) * 16);
-                kvl[st] = (NS == 3) ? *reinterpret_cast<const bf16x8*>(kvb + ((size_t)((head * 2 + st) * 2 + 1) * 64 + lane) * 16) : zero_bf8();
+                const bf16x8 kvh = *reinterpret_cast<const bf16x8*>(kvb + ((size_t)((head * 2 + st) * 2 + 0) * 64 + lane) * 16);
+                const bf16x8 kvl = (NS == 3) ? *reinterpret_cast<const bf16x8*>(kvb + ((size_t)((head * 2 + st) * 2 + 1) * 64 + lane) * 16) : zero_bf8();
                 const float* kp = ksum + head * 32 + h * 16 + 8 * st;
+                bf16x8 ksh, ksl, qh, ql;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    __bf16 hh, ll;
-                    split_bf16(kp[j], hh, ll);
-                    ksh[st][j] = hh;
-                    ksl[st][j] = (NS == 3) ? ll : (__bf16)0.f;
+                    __bf16 hh2, ll2;
+                    split_bf16(kp[j], hh2, ll2);
+                    ksh[j] = hh2;
+                    ksl[j] = (NS == 3) ? ll2 : (__bf16)0.f;
                 }
+                acc_frag<NS>(q[t][0], st, qh, ql);
+                num = mma_bf16<NS>(kvh, kvl, qh, ql, num);      // num^T[v][tok] = sum_d KV[d][v] phiQ[tok][d]
+                den = mma_bf16<NS>(ksh, ksl, qh, ql, den);      // den[tok] replicated over v
             }
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) q[t][tt][reg] = elu_plus_one(q[t][tt][reg]);
-                f32x16 num = zero16(), den = zero16();
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    bf16x8 qh, ql;
-                    acc_frag<NS>(q[t][tt], st, qh, ql);
-                    num = mma_bf16<NS>(kvh[st], kvl[st], qh, ql, num);      // num^T[v][tok] = sum_d KV[d][v] phiQ[tok][d]
-                    den = mma_bf16<NS>(ksh[st], ksl[st], qh, ql, den);      // den[tok] replicated over v
-                }
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) num[reg] = num[reg] * (1.0f / (den[reg] + 1e-6f)) * S;
-                store_featrow_acc<NS>(num, YH, YL, ROWB, 32 * head, 32 * tt, lane);
-            }
+            for (int reg = 0; reg < 16; ++reg) num[reg] = num[reg] * rcp_fast(den[reg] + 1e-6f) * S;
+            store_featrow_acc<NS>(num, YH, YL, ROWB, 32 * head, 32 * tt, lane);
         }
     }
     __syncthreads();
+    OPHIP_STAMP(a.stamps, wg, 3);
     // ---- merge + LayerNorm 1 -> Y ----------------------------------------------------------------
+    WRing<1, 4, NS> r0;
     {
-        f32x16 m[2][2];
+        f32x16 m[2][1] = {{zero16()}, {zero16()}};
+        gemm_bf16_ring<2, 1, NS, true, KB, 4>(m, rm, wm_hi, wm_lo, TS, yh, yl, ROWB, 0, lane);
+        OPHIP_STAMP(a.stamps, wg, 4);
+        r0.fill(w0_hi + (size_t)fw * TS2, w0_lo + (size_t)fw * TS2, TS2);          // MLP-up weights of chunk 0
+        layernorm_featrow(m, a.ln, a.ln + C, scratch, fw, tt, lane);     // its first barrier also fences the reads of Y above
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) m[t][tt] = zero16();
-        gemm_bf16<2, 2, NS, true, KB, 4>(m, wm_hi + (size_t)(2 * wave) * TS + lane, wm_lo + (size_t)(2 * wave) * TS + lane, TS, YH, YL, ROWB, 0, lane);
-        layernorm_featrow(m, a.ln, a.ln + C, scratch, wave, lane);     // its first barrier also fences the reads of Y above
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) store_featrow_acc<NS>(m[t][tt], YH, YL, ROWB, 64 * wave + 32 * t, 32 * tt, lane);
+        for (int t = 0; t < 2; ++t) store_featrow_acc<NS>(m[t][0], YH, YL, ROWB, 64 * fw + 32 * t, 32 * tt, lane);
     }
     __syncthreads();
+    OPHIP_STAMP(a.stamps, wg, 5);
     // ---- MLP: hidden = relu([x, msg] W0^T) in four 128-feature chunks, o += hidden_chunk W2[:, chunk]^T ---------
-    f32x16 o[2][2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) o[t][tt] = zero16();
+    f32x16 o[2][1] = {{zero16()}, {zero16()}};
     for (int c = 0; c < 4; ++c) {
-        f32x16 hd[1][2] = {{zero16(), zero16()}};
-        const size_t wt = (size_t)(4 * c + wave) * TS2 + lane;
-        gemm_bf16<1, 2, NS, true, KB, 8>(hd, w0_hi + wt, w0_lo + wt, TS2, XH, XL, ROWB, 0, lane);
-        gemm_bf16<1, 2, NS, true, KB, 8>(hd, w0_hi + wt + (size_t)KB * 64, w0_lo + wt + (size_t)KB * 64, TS2, YH, YL, ROWB, 0, lane);
+        f32x16 hd[1][1] = {{zero16()}};
+        const size_t wt = (size_t)(4 * c + fw) * TS2;
+        gemm_bf16_ring_cat<1, 1, NS, KB2, 4>(hd, r0, w0_hi + wt, w0_lo + wt, TS2, xh, xl, yh, yl, ROWB, lane);
+        OPHIP_STAMP(a.stamps, wg, 6 + 4 * c);
+        WRing<2, 4, NS> r2;
+        r2.fill(w2_hi + (size_t)(8 * c) * 64, w2_lo + (size_t)(8 * c) * 64, TS2);
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) hd[0][tt][reg] = fmaxf(hd[0][tt][reg], 0.f);
-            store_featrow_acc<NS>(hd[0][tt], HH, HL, HROWB, 32 * wave, 32 * tt, lane);
-        }
+        for (int reg = 0; reg < 16; ++reg) hd[0][0][reg] = fmaxf(hd[0][0][reg], 0.f);
+        store_featrow_acc<NS>(hd[0][0], HH, HL, HROWB, 32 * fw, 32 * tt, lane);
         __syncthreads();
-        const size_t w2t = (size_t)(2 * wave) * TS2 + (size_t)(8 * c) * 64 + lane;
-        gemm_bf16<2, 2, NS, true, 8, 4>(o, w2_hi + w2t, w2_lo + w2t, TS2, HH, HL, HROWB, 0, lane);
+        OPHIP_STAMP(a.stamps, wg, 7 + 4 * c);
+        gemm_bf16_ring<2, 1, NS, true, 8, 4>(o, r2, w2_hi + (size_t)(8 * c) * 64, w2_lo + (size_t)(8 * c) * 64, TS2, hh, hl, HROWB, 0, lane);
+        OPHIP_STAMP(a.stamps, wg, 8 + 4 * c);
+        if (c + 1 < 4) r0.fill(w0_hi + wt + (size_t)4 * TS2, w0_lo + wt + (size_t)4 * TS2, TS2);
         __syncthreads();
+        OPHIP_STAMP(a.stamps, wg, 9 + 4 * c);
     }
-    layernorm_featrow(o, a.ln + 2 * C, a.ln + 3 * C, scratch, wave, lane);
+    layernorm_featrow(o, a.ln + 2 * C, a.ln + 3 * C, scratch, fw, tt, lane);
+    OPHIP_STAMP(a.stamps, wg, 22);
     // ---- stage LN2 output as f32 [64][256] over the (now dead) X / Y planes, then x + msg with whole-row stores ----
-    float* stage = reinterpret_cast<float*>(smem);
+    char* stage = smem;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int row = 32 * tt + r;
-                const int ch = 16 * wave + 8 * t + 2 * g + h;          // 16-byte chunk of the f32 row
-                f32x4 v = {o[t][tt][4 * g], o[t][tt][4 * g + 1], o[t][tt][4 * g + 2], o[t][tt][4 * g + 3]};
-                *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(stage) + row * (C * 4) + ((ch ^ (row & 15)) << 4)) = v;
-            }
+        for (int g = 0; g < 4; ++g) {
+            const int row = 32 * tt + r;
+            const int ch = 16 * fw + 8 * t + 2 * g + h;          // 16-byte chunk of the f32 row
+            f32x4 v = {o[t][0][4 * g], o[t][0][4 * g + 1], o[t][0][4 * g + 2], o[t][0][4 * g + 3]};
+            *reinterpret_cast<f32x4*>(stage + row * (C * 4) + ((ch ^ (row & 15)) << 4)) = v;
+        }
     __syncthreads();
     float* yg = a.y[s] + (size_t)b * a.ybs[s];
-    for (int i = tid; i < TOK * (C / 4); i += 256) {
+    for (int i = tid; i < TOK * (C / 4); i += 512) {
         const int row = i / (C / 4), ch = i % (C / 4);
         if (tok0 + row < L) {
-            const f32x4 mv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(stage) + row * (C * 4) + ((ch ^ (row & 15)) << 4));
+            const f32x4 mv = *reinterpret_cast<const f32x4*>(stage + row * (C * 4) + ((ch ^ (row & 15)) << 4));
             const f32x4 xv = *reinterpret_cast<const f32x4*>(xg + (size_t)(tok0 + row) * C + 4 * ch);
             *reinterpret_cast<f32x4*>(yg + (size_t)(tok0 + row) * C + 4 * ch) = xv + mv;
         }
     }
+    OPHIP_STAMP(a.stamps, wg, 31);
 }
 
 template <typename K>
@@ -352,8 +341,8 @@ int set_lds(K kernel, size_t bytes, const char* what) {
 }  // namespace
 
 extern "C" size_t ophip_encoder_bf16_workspace_bytes(int B, int L3d, int L2d) {
-    const size_t tiles = (size_t)((L3d + TOK - 1) / TOK + (L2d + TOK - 1) / TOK);
-    return (size_t)B * tiles * KV_PART_FLOATS * 4 + (size_t)B * 2 * KV_BLOCK_BYTES + 256;
+    const size_t slabs = (size_t)((L3d + 31) / 32 + (L2d + 31) / 32);
+    return (size_t)B * slabs * KV_PART_FLOATS * 4 + (size_t)B * 2 * KV_BLOCK_BYTES + 256;
 }
 
 extern "C" size_t ophip_encoder_bf16_wpack_bytes(void) { return (size_t)2 * W_ELEMS * 2 + 4 * C * 4; }
@@ -366,8 +355,9 @@ extern "C" int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, floa
     if (x3d == y3d || x2d == y2d) return ophip_bad_arg(__func__, "in-place layer is not supported (cross layers read the pre-update streams)");
     hipStream_t stream = (hipStream_t)stream_;
     const int t3 = (L3d + TOK - 1) / TOK, t2 = (L2d + TOK - 1) / TOK;
+    const int s3 = (L3d + 31) / 32, s2 = (L2d + 31) / 32;
     float* partial = reinterpret_cast<float*>(workspace);
-    char* kv = reinterpret_cast<char*>(workspace) + (size_t)B * (t3 + t2) * KV_PART_FLOATS * 4;
+    char* kv = reinterpret_cast<char*>(workspace) + (size_t)B * (s3 + s2) * KV_PART_FLOATS * 4;
     kv += (256 - (reinterpret_cast<uintptr_t>(kv) & 255)) & 255;
     // layer block: [hi plane: Wq | Wkv | Wm | W0 | W2][lo plane: same][g1 b1 g2 b2 f32]   (packing.pack_coarse_layer_bf16)
     const bf16x8* w_hi = reinterpret_cast<const bf16x8*>(wpack);
@@ -378,22 +368,22 @@ extern "C" int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, floa
     KvRedArgs ka;
     ka.x[0] = x3d; ka.x[1] = x2d;
     ka.xbs[0] = (long long)L3d * C; ka.xbs[1] = (long long)L2d * C;
-    ka.L[0] = L3d; ka.L[1] = L2d; ka.tiles[0] = t3; ka.tiles[1] = t2;
+    ka.L[0] = L3d; ka.L[1] = L2d; ka.tiles[0] = t3; ka.tiles[1] = t2; ka.slabs[0] = s3; ka.slabs[1] = s2;
     ka.w_hi = w_hi + C * C / 8; ka.w_lo = w_lo + C * C / 8;
     ka.partial = partial;
     const size_t lds_kv = (size_t)PL * TOK * ROWB;
     static bool attr_kv[2] = {false, false}, attr_at[2] = {false, false};
     if (nsplit == 3) {
         if (!attr_kv[1]) { if (int rc = set_lds(kv_reduce_bf16_kernel<3>, lds_kv, "hipFuncSetAttribute(kv_reduce_bf16)")) return rc; attr_kv[1] = true; }
-        OPHIP_LAUNCH("kv_reduce", stream, kv_reduce_bf16_kernel<3>, dim3(t3 + t2, B), dim3(256), lds_kv, stream, ka);
+        OPHIP_LAUNCH("kv_reduce", stream, kv_reduce_bf16_kernel<3>, dim3(t3 + t2, B), dim3(512), lds_kv, stream, ka);
     } else {
         if (!attr_kv[0]) { if (int rc = set_lds(kv_reduce_bf16_kernel<1>, lds_kv, "hipFuncSetAttribute(kv_reduce_bf16)")) return rc; attr_kv[0] = true; }
-        OPHIP_LAUNCH("kv_reduce", stream, kv_reduce_bf16_kernel<1>, dim3(t3 + t2, B), dim3(256), lds_kv, stream, ka);
+        OPHIP_LAUNCH("kv_reduce", stream, kv_reduce_bf16_kernel<1>, dim3(t3 + t2, B), dim3(512), lds_kv, stream, ka);
     }
     OPHIP_CHECK_LAUNCH();
 
     KvSumBArgs sa;
-    sa.partial = partial; sa.kv = kv; sa.tiles[0] = t3; sa.tiles[1] = t2;
+    sa.partial = partial; sa.kv = kv; sa.tiles[0] = s3; sa.tiles[1] = s2;
     OPHIP_LAUNCH("kv_sum", stream, kv_sum_bf16_kernel, dim3(KV_PART_FLOATS / 64, 2 * B), dim3(1024), 0, stream, sa);
     OPHIP_CHECK_LAUNCH();
 
@@ -407,13 +397,14 @@ extern "C" int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, floa
     aa.srclen[0] = (float)(is_cross ? L2d : L3d);
     aa.srclen[1] = (float)(is_cross ? L3d : L2d);
     aa.w_hi = w_hi; aa.w_lo = w_lo; aa.ln = ln;
+    aa.stamps = ophip_stamp_buffer();
     const size_t lds_at = (size_t)PL * (2 * TOK * ROWB + TOK * HROWB);
     if (nsplit == 3) {
         if (!attr_at[1]) { if (int rc = set_lds(attn_apply_bf16_kernel<3>, lds_at, "hipFuncSetAttribute(attn_apply_bf16)")) return rc; attr_at[1] = true; }
-        OPHIP_LAUNCH("attn_apply", stream, attn_apply_bf16_kernel<3>, dim3(t3 + t2, B), dim3(256), lds_at, stream, aa);
+        OPHIP_LAUNCH("attn_apply", stream, attn_apply_bf16_kernel<3>, dim3(t3 + t2, B), dim3(512), lds_at, stream, aa);
     } else {
         if (!attr_at[0]) { if (int rc = set_lds(attn_apply_bf16_kernel<1>, lds_at, "hipFuncSetAttribute(attn_apply_bf16)")) return rc; attr_at[0] = true; }
-        OPHIP_LAUNCH("attn_apply", stream, attn_apply_bf16_kernel<1>, dim3(t3 + t2, B), dim3(256), lds_at, stream, aa);
+        OPHIP_LAUNCH("attn_apply", stream, attn_apply_bf16_kernel<1>, dim3(t3 + t2, B), dim3(512), lds_at, stream, aa);
     }
     OPHIP_CHECK_LAUNCH();
     return 0;

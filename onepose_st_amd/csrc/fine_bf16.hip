@@ -103,43 +103,77 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void fine_refine_bf
     OPHIP_STAMP(p.stamps, blockIdx.x, 0);
 
     // ---- gather both matches into the f32 staging image --------------------------------------------
-    for (int mi = 0; mi < 2; ++mi) {
-        const int k = k0 + mi;
-        const bool live = k < total;
-        const int b = live ? (int)p.b_ids[k] : 0, i3 = live ? (int)p.i_ids[k] : 0, j = live ? (int)p.j_ids[k] : 0;
-        const int cy = p.stride * (j / p.wc), cx = p.stride * (j % p.wc);
-        const float* ff = p.feat_f + (size_t)b * p.fs_b;
-        if (p.fs_c == 1) {
-            for (int e = tid; e < WIN * CF; e += 512) {
-                const int rr = e >> 7, c = e & 127;
-                const int y = cy + rr / 5 - 2, x = cx + rr % 5 - 2;
-                float v = 0.f;
-                if (live && y >= 0 && y < p.hf && x >= 0 && x < p.wf) v = ff[(size_t)y * p.fs_y + (size_t)x * p.fs_x + c];
-                *reinterpret_cast<float*>(stage + stage_off(32 * mi + rr, c >> 2) + 4 * (c & 3)) = v;
-            }
-        } else {
-            for (int q = tid; q < CF * 5; q += 512) {
-                const int c = q / 5, ky = q % 5;
-                const int y = cy + ky - 2;
-                const bool yin = live && y >= 0 && y < p.hf;
-                const float* src = ff + (size_t)c * p.fs_c + (size_t)(yin ? y : 0) * p.fs_y;
+    // every load of both matches is issued before the first LDS write, so their latencies overlap
+    // (named scalars + selects: a runtime-indexed array would live in scratch)
+    const bool live0 = k0 < total, live1 = k0 + 1 < total;
+    const int b0 = (int)p.b_ids[k0], i30 = (int)p.i_ids[k0], j0 = (int)p.j_ids[k0];
+    const int b1 = live1 ? (int)p.b_ids[k0 + 1] : 0, i31 = live1 ? (int)p.i_ids[k0 + 1] : 0, j1 = live1 ? (int)p.j_ids[k0 + 1] : 0;
+    const int cy0 = p.stride * (j0 / p.wc), cx0 = p.stride * (j0 % p.wc);
+    const int cy1 = p.stride * (j1 / p.wc), cx1 = p.stride * (j1 % p.wc);
+#define MLIVE(mi) ((mi) ? live1 : live0)
+#define MB(mi) ((mi) ? b1 : b0)
+#define MI3(mi) ((mi) ? i31 : i30)
+#define MCY(mi) ((mi) ? cy1 : cy0)
+#define MCX(mi) ((mi) ? cx1 : cx0)
+    if (p.fs_c == 1) {                   // channels-last: 512 B contiguous per pixel; 2 x 25 x 128 elements / 512 threads
+        constexpr int PER = (2 * WIN * CF + 511) / 512;
+        float v[PER];
 #pragma unroll
-                for (int kx = 0; kx < 5; ++kx) {
-                    const int x = cx + kx - 2;
-                    float v = 0.f;
-                    if (yin && x >= 0 && x < p.wf) v = src[(size_t)x * p.fs_x];
-                    *reinterpret_cast<float*>(stage + stage_off(32 * mi + ky * 5 + kx, c >> 2) + 4 * (c & 3)) = v;
-                }
+        for (int u = 0; u < PER; ++u) {
+            const int e = tid + 512 * u;
+            v[u] = 0.f;
+            if (e < 2 * WIN * CF) {
+                const int mi = e / (WIN * CF), e2 = e % (WIN * CF), rr = e2 >> 7, c = e2 & 127;
+                const int y = MCY(mi) + rr / 5 - 2, x = MCX(mi) + rr % 5 - 2;
+                if (MLIVE(mi) && y >= 0 && y < p.hf && x >= 0 && x < p.wf)
+                    v[u] = p.feat_f[(size_t)MB(mi) * p.fs_b + (size_t)y * p.fs_y + (size_t)x * p.fs_x + c];
             }
         }
-        if (tid < CF) {
-            const float v = live ? p.desc_f[(size_t)b * p.ds_b + (size_t)tid * p.ds_c + i3] : 0.f;
-            *reinterpret_cast<float*>(stage + stage_off(32 * mi + TOK3D, tid >> 2) + 4 * (tid & 3)) = v;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = tid + 512 * u;
+            if (e < 2 * WIN * CF) {
+                const int mi = e / (WIN * CF), e2 = e % (WIN * CF), rr = e2 >> 7, c = e2 & 127;
+                *reinterpret_cast<float*>(stage + stage_off(32 * mi + rr, c >> 2) + 4 * (c & 3)) = v[u];
+            }
         }
-        for (int e = tid; e < 6 * CF; e += 512) {
-            const int rr = 26 + (e >> 7), c = e & 127;
-            *reinterpret_cast<float*>(stage + stage_off(32 * mi + rr, c >> 2) + 4 * (c & 3)) = 0.f;
+    } else {                             // NCHW: one (match, channel, window row) run of 5 consecutive x per slot
+        constexpr int RUNS = 2 * CF * 5, PER = (RUNS + 511) / 512;
+        float v[PER][5];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int q = tid + 512 * u;
+            const int mi = q / (CF * 5), q2 = q % (CF * 5), c = q2 / 5, ky = q2 % 5;
+            const bool ok = q < RUNS && MLIVE(mi);
+            const int m2 = mi < 2 ? mi : 0;
+            const int y = MCY(m2) + ky - 2;
+            const bool yin = ok && y >= 0 && y < p.hf;
+            const float* src = p.feat_f + (size_t)MB(m2) * p.fs_b + (size_t)c * p.fs_c + (size_t)(yin ? y : 0) * p.fs_y;
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) {
+                const int x = MCX(m2) + kx - 2;
+                v[u][kx] = (yin && x >= 0 && x < p.wf) ? src[(size_t)x * p.fs_x] : 0.f;
+            }
         }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int q = tid + 512 * u;
+            if (q < RUNS) {
+                const int mi = q / (CF * 5), q2 = q % (CF * 5), c = q2 / 5, ky = q2 % 5;
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx)
+                    *reinterpret_cast<float*>(stage + stage_off(32 * mi + ky * 5 + kx, c >> 2) + 4 * (c & 3)) = v[u][kx];
+            }
+        }
+    }
+    if (tid < 2 * CF) {                  // the 3D fine descriptor (row 25) of both matches
+        const int mi = tid >> 7, c = tid & 127;
+        const float v = MLIVE(mi) ? p.desc_f[(size_t)MB(mi) * p.ds_b + (size_t)c * p.ds_c + MI3(mi)] : 0.f;
+        *reinterpret_cast<float*>(stage + stage_off(32 * mi + TOK3D, c >> 2) + 4 * (c & 3)) = v;
+    }
+    for (int e = tid; e < 2 * 6 * CF; e += 512) {      // padding rows 26..31
+        const int mi = e / (6 * CF), e2 = e % (6 * CF), rr = 26 + (e2 >> 7), c = e2 & 127;
+        *reinterpret_cast<float*>(stage + stage_off(32 * mi + rr, c >> 2) + 4 * (c & 3)) = 0.f;
     }
     __syncthreads();
     OPHIP_STAMP(p.stamps, blockIdx.x, 1);

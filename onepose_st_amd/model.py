@@ -105,8 +105,11 @@ class OnePosePlus_model(nn.Module):
         self.loftr_fine = _EncoderParams(cf)
         self._pe_enable = bool(config["positional_encoding"]["enable"])
         self._pe_shape = tuple(config["positional_encoding"]["pos_emb_shape"])
-        # arithmetic of the coarse encoder: "f32" exact-f32 MFMA | "bf16x3" split-bf16 MFMA (~f32-grade) | "bf16"
-        self.precision = str(config.get("hip_precision", os.environ.get("OPHIP_PRECISION", "f32")))
+        # matrix arithmetic of the HIP kernels:
+        #   "bf16x3" (default) split-bf16 MFMA, 3 x v_mfma_f32_32x32x16_bf16 per product, f32 accumulate: ~f32-grade
+        #   "f32"    exact-f32 MFMA (v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain), 1/16 of the bf16 rate
+        #   "bf16"   plain bf16 operands: fastest, ~1e-2 relative on activations
+        self.precision = str(config.get("hip_precision", os.environ.get("OPHIP_PRECISION", "bf16x3")))
         if self.precision not in ("f32", "bf16x3", "bf16"):
             raise ValueError(f"hip_precision {self.precision!r}: expected 'f32', 'bf16x3' or 'bf16'")
         self._packed = None          # (key, dict of device weight blocks)
