@@ -33,6 +33,7 @@ sys.path.insert(0, REPO)
 from onepose_st_amd import hip  # noqa: E402
 from onepose_st_amd.config import default_config  # noqa: E402
 from onepose_st_amd.model import OnePosePlus_model  # noqa: E402
+from onepose_st_amd.pnp import ransac_PnP  # noqa: E402
 from onepose_st_amd.sharding import OBJECT_KEYS as OBJ_KEYS, broadcast_object_block, frame_chunk  # noqa: E402
 from onepose_st_amd.synthetic import CONFIG_SIZES, make_synthetic_inputs, make_synthetic_state_dict  # noqa: E402
 
@@ -77,6 +78,8 @@ def main():
     ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames per rank (cycled)")
     ap.add_argument("--precision", default=os.environ.get("OPHIP_PRECISION", "bf16x3"), choices=["f32", "bf16x3", "bf16"],
                     help="matrix arithmetic of the encoder kernels (see DESIGN.md section 4)")
+    ap.add_argument("--no-pnp", action="store_true", help="time the matcher only (no host PnP)")
+    ap.add_argument("--pnp-threads", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
@@ -123,11 +126,32 @@ def main():
         batches.append((torch.cat([frames[i][0] for i in idx]), torch.cat([frames[i][1] for i in idx])))
     obj_b = {k: v.expand(B, *v.shape[1:]) for k, v in obj.items()}
 
+    # host PnP (metric: "2D-3D match + PnP"): frame t's pose is solved on host threads (C++, GIL released) while the GPU
+    # matches frame t + 1; every pose is joined before the clock stops
+    from concurrent.futures import ThreadPoolExecutor
+    pool = None if args.no_pnp else ThreadPoolExecutor(max_workers=max(1, args.pnp_threads))
+    K_cam = first["K"].numpy()
+    pending = []
+
     def step(i):
         fc, ff = batches[i % len(batches)]
         data = dict(obj_b)
         model.forward_features(data, fc, ff, image_hw)
+        if pool is not None:
+            m = torch.cat([data["mkpts_query_f"], data["mkpts_3d_db"]], dim=1).cpu().numpy()      # one small D2H (K x 5 floats)
+            if B == 1:
+                pending.append(pool.submit(ransac_PnP, K_cam, m[:, :2], m[:, 2:], 1, 7))
+            else:
+                bid = data["b_ids"].cpu().numpy()
+                for bb in range(B):
+                    sel = bid == bb
+                    pending.append(pool.submit(ransac_PnP, K_cam, m[sel, :2], m[sel, 2:], 1, 7))
         return data
+
+    def join_poses():
+        out = [f.result() for f in pending]
+        pending.clear()
+        return out
 
     def sync_all():
         torch.cuda.synchronize()
@@ -139,12 +163,15 @@ def main():
     for i in range(args.warmup):
         last = step(i)
     n_matches = int(last["i_ids"].numel()) if args.warmup else -1
+    poses = join_poses()
+    n_inliers = int(len(poses[-1][2])) if poses else -1
 
     hip.timing_select("attn_apply")
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    join_poses()
     sync_all()
     dt = time.perf_counter() - t0
     launches, kern_ms = hip.timing_read()
@@ -180,7 +207,10 @@ def main():
             "frames_per_step": B,
             "matches_per_frame": n_matches // max(B, 1),
             "timed_region": "rows a1-a11 (PE, keypoint encoding, 6-layer coarse encoder, dual-softmax + mutual-NN incl. the "
-                            "N x M conf_matrix write, fine refinement); backbone and host PnP outside",
+                            "N x M conf_matrix write, fine refinement)" + ("" if args.no_pnp else " + host PnP/RANSAC of every frame "
+                            f"(C++, {args.pnp_threads} host threads, overlapped with the next frame, all joined before the clock stops)")
+                            + "; backbone outside",
+            "pnp_inliers_per_frame": n_inliers,
             "parallelism": f"frames sharded over {world} rank(s), one RCCL broadcast of weights + 3D block ({bcast_bytes} B)",
         },
         "roofline": {

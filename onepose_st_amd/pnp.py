@@ -1,0 +1,54 @@
+"""Host PnP + RANSAC with the reference's ``ransac_PnP`` signature (``src/utils/metric_utils.py:121-209``), backed by
+``libonepose_pnp.so`` (C++, ``csrc_host/pnp.cpp``) through ctypes.  ``ctypes`` releases the GIL during the call, so a
+pipeline can solve frame t's pose on a host thread while the GPU matches frame t + 1 (``bench.py``)."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libonepose_pnp.so")
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(f"{_LIB_PATH} not found: run __graft_entry__.build()")
+        lib = ctypes.CDLL(_LIB_PATH)
+        lib.oppnp_ransac.restype = ctypes.c_int
+        lib.oppnp_ransac.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                     ctypes.c_int, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+        if lib.oppnp_abi_version() != 1:
+            raise RuntimeError("libonepose_pnp.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def ransac_PnP(K, pts_2d, pts_3d, scale=1, pnp_reprojection_error=5, img_hw=None, use_pycolmap_ransac=False,
+               confidence=0.99, min_iters=8, max_iters=10000, seed=1):
+    """-> ``(pose [3,4], pose_homo [4,4], inliers [k] int64)`` like the reference.  ``scale`` multiplies the 3D points
+    for the solve and divides the translation afterwards (the reference's OpenCV branch, ``metric_utils.py:186,200``);
+    ``img_hw`` / ``use_pycolmap_ransac`` are accepted for signature compatibility and ignored."""
+    lib = load()
+    K = np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(3, 3))
+    p2 = np.ascontiguousarray(np.asarray(pts_2d, dtype=np.float32).reshape(-1, 2))
+    p3 = np.ascontiguousarray(np.asarray(pts_3d, dtype=np.float32).reshape(-1, 3) * np.float32(scale))
+    n = p2.shape[0]
+    if p3.shape[0] != n:
+        raise ValueError("pts_2d and pts_3d must have the same length")
+    pose = np.zeros((3, 4), dtype=np.float64)
+    mask = np.zeros(max(n, 1), dtype=np.uint8)
+    n_in, iters = ctypes.c_int(0), ctypes.c_int(0)
+    rc = lib.oppnp_ransac(K.ctypes.data, p2.ctypes.data, p3.ctypes.data, n, float(pnp_reprojection_error), float(confidence),
+                          int(min_iters), int(max_iters), int(seed), pose.ctypes.data, mask.ctypes.data,
+                          ctypes.byref(n_in), ctypes.byref(iters))
+    if rc < 0:
+        raise ValueError("oppnp_ransac: invalid arguments")
+    pose[:, 3] /= scale
+    pose_homo = np.concatenate([pose, np.array([[0.0, 0.0, 0.0, 1.0]])], axis=0)
+    inliers = np.nonzero(mask[:n])[0].astype(np.int64) if rc == 0 else np.array([], dtype=np.int64)
+    return pose, pose_homo, inliers

@@ -21,6 +21,7 @@ import torch
 from oracle import onepose_oracle as orc
 from onepose_st_amd import hip, host_math, packing
 from onepose_st_amd.model import OnePosePlus_model
+from onepose_st_amd.pnp import ransac_PnP
 from onepose_st_amd.synthetic import make_synthetic_inputs
 
 pytestmark = pytest.mark.gpu
@@ -298,6 +299,23 @@ def _check_against(data, want, precision="f32"):
     print(f"[{precision}] K={len(want['mconf'])}: max |mkpts_query_f err| = {err_px:.2e} px, max mconf rel err = {err_conf:.2e}")
 
 
+def _pose_parity(data, ref_mk3d, ref_mkf, inp, label):
+    """north_star: pose R|t within 1e-4 relative.  The same deterministic host PnP (onepose_st_amd.pnp) is applied to the
+    HIP path's matches and to the reference / oracle matches (the reference's pycolmap / OpenCV solvers are not
+    available: pose parity is pinned to equal inputs -> equal estimator)."""
+    Kc = inp["K"].numpy()
+    pose_g, _, inl_g = ransac_PnP(Kc, data["mkpts_query_f"].cpu().numpy(), data["mkpts_3d_db"].cpu().numpy(), pnp_reprojection_error=7)
+    pose_r, _, inl_r = ransac_PnP(Kc, np.asarray(ref_mkf), np.asarray(ref_mk3d), pnp_reprojection_error=7)
+    dR = np.abs(pose_g[:, :3] - pose_r[:, :3]).max()
+    dt = np.linalg.norm(pose_g[:, 3] - pose_r[:, 3]) / np.linalg.norm(pose_r[:, 3])
+    gt = inp["pose_gt"].numpy()
+    ang = np.degrees(np.arccos(np.clip((np.trace(pose_g[:, :3] @ gt[:, :3].T) - 1) / 2, -1, 1)))
+    print(f"[{label}] pose parity: max |dR| = {dR:.2e}, |dt|/|t| = {dt:.2e}; vs planted pose: {ang:.3f} deg, "
+          f"{np.linalg.norm(pose_g[:, 3] - gt[:, 3]) * 1000:.2f} mm; inliers {len(inl_g)}/{len(inl_r)}")
+    assert dR < 1e-4 and dt < 1e-4
+    assert len(inl_g) == len(inl_r) and ang < 0.5 and np.linalg.norm(pose_g[:, 3] - gt[:, 3]) < 5e-3
+
+
 def test_c1_against_reference_golden(model, sd, cfg, dev, golden_dir):
     g = np.load(os.path.join(golden_dir, "c1_feature_boundary.npz"))
     inp = make_synthetic_inputs(sd, n_points=1000, image_hw=(240, 320), n_plant=600, seed=1, config=cfg)
@@ -309,6 +327,7 @@ def test_c1_against_reference_golden(model, sd, cfg, dev, golden_dir):
     np.testing.assert_allclose(conf.max(dim=2)[0][0].cpu().numpy(), g["conf_rowmax"], rtol=rt_conf, atol=1e-6)
     np.testing.assert_allclose(conf.max(dim=1)[0][0].cpu().numpy(), g["conf_colmax"], rtol=rt_conf, atol=1e-6)
     assert data["bs"] == 1 and tuple(data["q_hw_c"]) == (30, 40) and tuple(data["q_hw_f"]) == (120, 160) and data["W"] == 5
+    _pose_parity(data, g["mkpts_3d_db"], g["mkpts_query_f"], inp, f"c1 {model.precision} vs reference golden")
 
 
 def test_b2_ragged_against_reference_golden(model, sd, cfg, dev, golden_dir):
@@ -355,6 +374,7 @@ def test_c2_full_size_against_oracle_and_properties(model, sd, cfg, dev):
     assert K > 2000
     _check_against(data, {k: ref[k].numpy() for k in ("b_ids", "i_ids", "j_ids", "m_bids", "mconf", "mkpts_3d_db", "mkpts_query_c",
                                                       "mkpts_query_f", "expec_f")}, model.precision)
+    _pose_parity(data, ref["mkpts_3d_db"].numpy(), ref["mkpts_query_f"].numpy(), inp, f"c2 {model.precision} vs oracle")
     conf, i, j = data["conf_matrix"][0], data["i_ids"], data["j_ids"]
     v = conf[i, j]
     assert torch.equal(v, data["mconf"])

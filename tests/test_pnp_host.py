@@ -1,0 +1,64 @@
+"""Host PnP + RANSAC (C++): recovers planted poses, rejects outliers, is deterministic, handles degenerate input."""
+import numpy as np
+import pytest
+
+from onepose_st_amd.pnp import ransac_PnP
+
+
+def _scene(n, seed, noise_px=0.0, outlier_frac=0.0):
+    rng = np.random.default_rng(seed)
+    X = (rng.random((n, 3)) - 0.5) * np.array([0.2, 0.14, 0.1])
+    ax = rng.normal(size=3); ax /= np.linalg.norm(ax); ang = 0.5
+    Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
+    t = np.array([0.01, -0.02, 0.45])
+    K = np.array([[1216.0, 0, 320.0], [0, 1216.0, 240.0], [0, 0, 1]])
+    pc = X @ R.T + t
+    uv = (pc[:, :2] / pc[:, 2:]) * 1216.0 + np.array([320.0, 240.0])
+    uv += noise_px * rng.normal(size=uv.shape)
+    n_out = int(outlier_frac * n)
+    if n_out:
+        uv[:n_out] = rng.random((n_out, 2)) * np.array([640.0, 480.0])
+    return K, uv.astype(np.float32), X.astype(np.float32), R, t, n_out
+
+
+def _rot_err(Ra, Rb):
+    return np.degrees(np.arccos(np.clip((np.trace(Ra @ Rb.T) - 1) / 2, -1, 1)))
+
+
+def test_exact_data_recovers_pose():
+    K, uv, X, R, t, _ = _scene(500, 0)
+    pose, homo, inl = ransac_PnP(K, uv, X, pnp_reprojection_error=7)
+    assert _rot_err(pose[:, :3], R) < 1e-3 and np.linalg.norm(pose[:, 3] - t) / np.linalg.norm(t) < 1e-5
+    assert len(inl) == 500 and homo.shape == (4, 4) and np.allclose(homo[3], [0, 0, 0, 1])
+
+
+def test_noise_and_outliers():
+    K, uv, X, R, t, n_out = _scene(2000, 1, noise_px=0.5, outlier_frac=0.3)
+    pose, _, inl = ransac_PnP(K, uv, X, pnp_reprojection_error=7)
+    assert _rot_err(pose[:, :3], R) < 0.05 and np.linalg.norm(pose[:, 3] - t) / np.linalg.norm(t) < 2e-3
+    assert len(inl) >= 0.95 * (2000 - n_out) and (inl >= n_out).mean() > 0.97
+    pose2, _, inl2 = ransac_PnP(K, uv, X, pnp_reprojection_error=7)                  # deterministic
+    assert np.array_equal(pose, pose2) and np.array_equal(inl, inl2)
+
+
+def test_scale_argument_and_degenerate_inputs():
+    K, uv, X, R, t, _ = _scene(300, 2, noise_px=0.2)
+    p1, _, _ = ransac_PnP(K, uv, X, scale=1)
+    p2, _, _ = ransac_PnP(K, uv, X, scale=1000)                                      # inference.py:181-189 passes scale=1000
+    assert np.allclose(p1[:, :3], p2[:, :3], atol=1e-6) and np.allclose(p1[:, 3], p2[:, 3], rtol=1e-4, atol=1e-7)
+    pose, homo, inl = ransac_PnP(K, uv[:4], X[:4])                                   # too few points: identity, no inliers
+    assert np.array_equal(pose, np.eye(4)[:3]) and len(inl) == 0
+    pose, _, inl = ransac_PnP(K, np.zeros((0, 2)), np.zeros((0, 3)))
+    assert np.array_equal(pose, np.eye(4)[:3]) and len(inl) == 0
+    with pytest.raises(ValueError):
+        ransac_PnP(K, uv[:10], X[:9])
+
+
+def test_pose_is_insensitive_at_matcher_noise_level():
+    """1e-4 px perturbations of the 2D keypoints (the HIP path's deviation from the oracle) move the pose by < 1e-6 rel."""
+    K, uv, X, R, t, _ = _scene(2800, 3, noise_px=0.7)
+    p1, _, _ = ransac_PnP(K, uv, X, pnp_reprojection_error=7)
+    uv2 = uv + np.float32(1e-4) * np.random.default_rng(9).normal(size=uv.shape).astype(np.float32)
+    p2, _, _ = ransac_PnP(K, uv2, X, pnp_reprojection_error=7)
+    assert np.abs(p1[:, :3] - p2[:, :3]).max() < 1e-6 and np.linalg.norm(p1[:, 3] - p2[:, 3]) / np.linalg.norm(p1[:, 3]) < 1e-6
