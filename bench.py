@@ -33,7 +33,7 @@ sys.path.insert(0, REPO)
 from onepose_st_amd import hip  # noqa: E402
 from onepose_st_amd.config import default_config  # noqa: E402
 from onepose_st_amd.model import OnePosePlus_model  # noqa: E402
-from onepose_st_amd.pnp import ransac_PnP  # noqa: E402
+from onepose_st_amd.pnp import PnPPool  # noqa: E402
 from onepose_st_amd.sharding import OBJECT_KEYS as OBJ_KEYS, broadcast_object_block, frame_chunk  # noqa: E402
 from onepose_st_amd.synthetic import CONFIG_SIZES, make_synthetic_inputs, make_synthetic_state_dict  # noqa: E402
 
@@ -128,28 +128,43 @@ def main():
 
     # host PnP (metric: "2D-3D match + PnP"): frame t's pose is solved on host threads (C++, GIL released) while the GPU
     # matches frame t + 1; every pose is joined before the clock stops
-    from concurrent.futures import ThreadPoolExecutor
-    pool = None if args.no_pnp else ThreadPoolExecutor(max_workers=max(1, args.pnp_threads))
-    K_cam = first["K"].numpy()
+    pool = None if args.no_pnp else PnPPool(first["K"].numpy(), threads=max(1, args.pnp_threads), pnp_reprojection_error=7)
     pending = []
 
-    def step(i):
-        fc, ff = batches[i % len(batches)]
-        data = dict(obj_b)
-        model.forward_features(data, fc, ff, image_hw)
+    inflight = []
+
+    def complete(pend):
+        """finish one frame (waits on ITS event only) and hand its matches to the host PnP pool"""
+        data = pend.finish()
         if pool is not None:
-            m = torch.cat([data["mkpts_query_f"], data["mkpts_3d_db"]], dim=1).cpu().numpy()      # one small D2H (K x 5 floats)
+            hst = pend.host
             if B == 1:
-                pending.append(pool.submit(ransac_PnP, K_cam, m[:, :2], m[:, 2:], 1, 7))
+                pending.append(pool.submit(hst["mkpts_2d"], hst["mkpts_3d_db"]))
             else:
-                bid = data["b_ids"].cpu().numpy()
                 for bb in range(B):
-                    sel = bid == bb
-                    pending.append(pool.submit(ransac_PnP, K_cam, m[sel, :2], m[sel, 2:], 1, 7))
+                    sel = hst["b_ids"] == bb
+                    pending.append(pool.submit(hst["mkpts_2d"][sel], hst["mkpts_3d_db"][sel]))
         return data
 
+    def step(i):
+        """enqueue batch i, then finish batch i - 1: the GPU always has the next frame queued behind the current one"""
+        fc, ff = batches[i % len(batches)]
+        inflight.append(model.enqueue_features(dict(obj_b), fc, ff, image_hw, host_copy=pool is not None))
+        if len(inflight) > 1:
+            return complete(inflight.pop(0))
+        return None
+
+    def drain():
+        last_data = None
+        while inflight:
+            last_data = complete(inflight.pop(0))
+        return last_data
+
     def join_poses():
-        out = [f.result() for f in pending]
+        if pool is None:
+            return []
+        pool.wait_all()
+        out = [pool.result(tk) for tk in pending]
         pending.clear()
         return out
 
@@ -161,16 +176,18 @@ def main():
             torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        last = step(i)
-    n_matches = int(last["i_ids"].numel()) if args.warmup else -1
+        step(i)
+    last = drain()
+    n_matches = int(last["i_ids"].numel()) if last is not None else -1
     poses = join_poses()
-    n_inliers = int(len(poses[-1][2])) if poses else -1
+    n_inliers = int(poses[-1][1]) if poses else -1
 
     hip.timing_select("attn_apply")
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    drain()
     join_poses()
     sync_all()
     dt = time.perf_counter() - t0

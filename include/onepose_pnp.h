@@ -21,6 +21,16 @@ int oppnp_ransac(const double* K, const float* pts2d, const float* pts3d, int n,
                  int min_iters, int max_iters, unsigned long long seed, double* pose_out, unsigned char* inlier_mask,
                  int* n_inliers, int* iters_run);
 
+/* Asynchronous pool: library-owned host threads solve poses while the caller keeps feeding the GPU (the per-frame path
+ * has no Python in it).  submit copies its inputs and returns a ticket 0, 1, 2, ...; wait_all blocks until every
+ * submitted pose is solved; result reads one (return value as oppnp_ransac). */
+void* oppnp_pool_create(int threads);
+void oppnp_pool_destroy(void* pool);
+long long oppnp_pool_submit(void* pool, const double* K, const float* pts2d, const float* pts3d, int n, double reproj_err_px,
+                            double confidence, int min_iters, int max_iters, unsigned long long seed);
+long long oppnp_pool_wait_all(void* pool);
+int oppnp_pool_result(void* pool, long long ticket, double* pose_out, int* n_inliers);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,10 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -366,4 +370,105 @@ extern "C" int oppnp_ransac(const double* K, const float* pts2d, const float* pt
     if (inlier_mask) std::memcpy(inlier_mask, best_mask.data(), (size_t)n);
     if (n_inliers) *n_inliers = best_cnt;
     return best_cnt >= 6 ? 0 : 1;
+}
+
+// ---- asynchronous pool: poses are solved on library-owned host threads (no Python / GIL on the per-frame path) --------
+namespace {
+
+struct Job {
+    double K[9];
+    std::vector<float> p2, p3;
+    double thr, conf;
+    int min_it, max_it;
+    unsigned long long seed;
+    long long ticket;
+};
+struct Result {
+    double pose[12];
+    int n_inliers, rc;
+};
+
+struct Pool {
+    std::vector<std::thread> workers;
+    std::deque<Job> queue;
+    std::vector<Result> results;          // indexed by ticket
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    long long submitted = 0, finished = 0;
+    bool stop = false;
+
+    explicit Pool(int n) {
+        for (int i = 0; i < n; ++i) workers.emplace_back([this] { run(); });
+    }
+    ~Pool() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv_work.notify_all();
+        for (auto& t : workers) t.join();
+    }
+    void run() {
+        for (;;) {
+            Job job;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [this] { return stop || !queue.empty(); });
+                if (stop && queue.empty()) return;
+                job = std::move(queue.front());
+                queue.pop_front();
+            }
+            Result r;
+            const int n = (int)(job.p2.size() / 2);
+            r.rc = oppnp_ransac(job.K, job.p2.data(), job.p3.data(), n, job.thr, job.conf, job.min_it, job.max_it, job.seed, r.pose,
+                                nullptr, &r.n_inliers, nullptr);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                results[(size_t)job.ticket] = r;
+                ++finished;
+            }
+            cv_done.notify_all();
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" void* oppnp_pool_create(int threads) { return new Pool(threads < 1 ? 1 : threads); }
+
+extern "C" void oppnp_pool_destroy(void* pool) { delete reinterpret_cast<Pool*>(pool); }
+
+// copies the inputs and returns a ticket (0, 1, 2, ...) at once
+extern "C" long long oppnp_pool_submit(void* pool_, const double* K, const float* pts2d, const float* pts3d, int n, double reproj_err_px,
+                                       double confidence, int min_iters, int max_iters, unsigned long long seed) {
+    Pool* pool = reinterpret_cast<Pool*>(pool_);
+    if (!pool || !K || n < 0 || (n > 0 && (!pts2d || !pts3d))) return -1;
+    Job job;
+    std::memcpy(job.K, K, sizeof(job.K));
+    job.p2.assign(pts2d, pts2d + 2 * (size_t)n);
+    job.p3.assign(pts3d, pts3d + 3 * (size_t)n);
+    job.thr = reproj_err_px; job.conf = confidence; job.min_it = min_iters; job.max_it = max_iters; job.seed = seed;
+    {
+        std::lock_guard<std::mutex> lk(pool->mu);
+        job.ticket = pool->submitted++;
+        pool->results.resize((size_t)pool->submitted);
+        pool->queue.push_back(std::move(job));
+    }
+    pool->cv_work.notify_one();
+    return pool->submitted - 1;
+}
+
+// blocks until every submitted job is finished; returns their number
+extern "C" long long oppnp_pool_wait_all(void* pool_) {
+    Pool* pool = reinterpret_cast<Pool*>(pool_);
+    std::unique_lock<std::mutex> lk(pool->mu);
+    pool->cv_done.wait(lk, [pool] { return pool->finished == pool->submitted; });
+    return pool->finished;
+}
+
+extern "C" int oppnp_pool_result(void* pool_, long long ticket, double* pose_out, int* n_inliers) {
+    Pool* pool = reinterpret_cast<Pool*>(pool_);
+    std::lock_guard<std::mutex> lk(pool->mu);
+    if (ticket < 0 || ticket >= (long long)pool->results.size()) return -1;
+    const Result& r = pool->results[(size_t)ticket];
+    if (pose_out) std::memcpy(pose_out, r.pose, sizeof(r.pose));
+    if (n_inliers) *n_inliers = r.n_inliers;
+    return r.rc;
 }

@@ -170,10 +170,18 @@ class OnePosePlus_model(nn.Module):
             feat_c, feat_f = self.backbone(data["query_image"])
         self.forward_features(data, feat_c, feat_f)
 
-    @torch.no_grad()
     def forward_features(self, data, feat_c, feat_f, image_hw=None, want_fine_debug=False):
         """The north_star path: everything after the backbone.  ``feat_c [B,256,H/8,W/8]``,
         ``feat_f [B,128,H/2,W/2]`` (any strides); fills ``data`` like :meth:`forward`."""
+        self.enqueue_features(data, feat_c, feat_f, image_hw, want_fine_debug).finish()
+
+    @torch.no_grad()
+    def enqueue_features(self, data, feat_c, feat_f, image_hw=None, want_fine_debug=False, host_copy=False):
+        """Enqueue the whole path for one batch on the current stream WITHOUT synchronising and return a
+        :class:`PendingFrame`; ``.finish()`` waits for that frame only (an event, not the stream) and fills ``data``.
+        A pipeline enqueues frame t + 1 before finishing frame t, so the GPU never idles on the host
+        (``bench.py``).  ``host_copy=True`` also queues the D2H of the match buffers into pinned memory, which
+        ``finish()`` exposes as numpy arrays (``pending.host``) for host PnP."""
         if not feat_c.is_cuda:
             raise hip.HipLibraryError("OnePosePlus_model runs on the HIP device only (no CPU fallback): move the "
                                       "model and its inputs to 'cuda'")
@@ -285,27 +293,80 @@ class OnePosePlus_model(nn.Module):
                          3 if self.precision == "bf16x3" else 1,
                          wc, stride, float(fine_scale), P(expec), P(mkf), P(dbg_w), P(dbg_3), S)
 
-        K = int(count.item())                       # the one host sync of the frame
-        if fine_on and K > min(cap, B * min(N, M) + 64):
+        pend = PendingFrame(self, data, dev, B, N, M, cap, fine_on, want_fine_debug,
+                            dict(b_ids=b_ids, i_ids=i_ids, j_ids=j_ids, mconf=mconf, mk3d=mk3d, mkc=mkc, count=count,
+                                 expec=expec if fine_on else None, mkf=mkf if fine_on else None,
+                                 dbg_w=dbg_w if fine_on else None, dbg_3=dbg_3 if fine_on else None), host_copy)
+        return pend
+
+
+class PendingFrame:
+    """A batch whose kernels are enqueued but whose match count has not been read yet."""
+
+    _pinned_pool = {}
+
+    def __init__(self, model, data, dev, B, N, M, cap, fine_on, want_dbg, bufs, host_copy):
+        self.model, self.data, self.dev = model, data, dev
+        self.B, self.N, self.M, self.cap, self.fine_on, self.want_dbg = B, N, M, cap, fine_on, want_dbg
+        self.bufs = bufs
+        self.host = None
+        key = (cap, bool(host_copy))
+        pool = PendingFrame._pinned_pool.setdefault(key, [])
+        self._pin = pool.pop() if pool else self._alloc_pinned(cap, host_copy)
+        self._key = key
+        self._pin["count"].copy_(bufs["count"], non_blocking=True)
+        if host_copy:
+            self._pin["mk3d"].copy_(bufs["mk3d"], non_blocking=True)
+            self._pin["mk2d"].copy_(bufs["mkf"] if fine_on else bufs["mkc"], non_blocking=True)
+            self._pin["b_ids"].copy_(bufs["b_ids"], non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+        self.done = False
+
+    @staticmethod
+    def _alloc_pinned(cap, host_copy):
+        pin = {"count": torch.empty(1, dtype=torch.int32).pin_memory()}
+        if host_copy:
+            pin["mk3d"] = torch.empty(cap, 3, dtype=torch.float32).pin_memory()
+            pin["mk2d"] = torch.empty(cap, 2, dtype=torch.float32).pin_memory()
+            pin["b_ids"] = torch.empty(cap, dtype=torch.int64).pin_memory()
+        return pin
+
+    def finish(self):
+        """Wait for this frame (event), read K, fill ``data`` exactly like the reference's ``forward``."""
+        if self.done:
+            return self.data
+        self.event.synchronize()                    # the one host wait of the frame
+        K = int(self._pin["count"][0])
+        B, N, M, cap = self.B, self.N, self.M, self.cap
+        if self.fine_on and K > min(cap, B * min(N, M) + 64):
             raise RuntimeError("more coarse matches than the fine grid covers (exact confidence ties); "
                                "re-run with a larger grid is not implemented")
-        b_ids, i_ids, j_ids = b_ids[:K], i_ids[:K], j_ids[:K]
-        mconf, mk3d, mkc = mconf[:K], mk3d[:K], mkc[:K]
+        if "mk3d" in self._pin:
+            self.host = {"K": K, "mkpts_3d_db": self._pin["mk3d"][:K].numpy().copy(), "mkpts_2d": self._pin["mk2d"][:K].numpy().copy(),
+                         "b_ids": self._pin["b_ids"][:K].numpy().copy()}
+        PendingFrame._pinned_pool[self._key].append(self._pin)
+        bf = self.bufs
+        data, dev = self.data, self.dev
+        b_ids, i_ids, j_ids = bf["b_ids"][:K], bf["i_ids"][:K], bf["j_ids"][:K]
+        mconf, mk3d, mkc = bf["mconf"][:K], bf["mk3d"][:K], bf["mkc"][:K]
         data.update({
             "b_ids": b_ids, "i_ids": i_ids, "j_ids": j_ids,
             "gt_mask": mconf == 0, "m_bids": b_ids.clone(),
             "mkpts_3d_db": mk3d, "mkpts_query_c": mkc, "mconf": mconf,
         })
-        if not fine_on:
+        self.done = True
+        if not self.fine_on:
             data.update({"mkpts_3d_db": data["mkpts_3d_db"], "mkpts_query_f": data["mkpts_query_c"]})
-            return
-        data.update({"W": cfg["loftr_fine"]["window_size"]})
+            return data
+        data.update({"W": self.model.config["loftr_fine"]["window_size"]})
         if K == 0:
             data.update({"expec_f": torch.empty(0, 3, device=dev), "mkpts_3d_db": mk3d, "mkpts_query_f": mkc})
-            return
-        data.update({"expec_f": expec[:K], "mkpts_3d_db": mk3d, "mkpts_query_f": mkf[:K]})
-        if want_fine_debug:
-            data["_fine_win"], data["_fine_f3"] = dbg_w[:K], dbg_3[:K]
+            return data
+        data.update({"expec_f": bf["expec"][:K], "mkpts_3d_db": mk3d, "mkpts_query_f": bf["mkf"][:K]})
+        if self.want_dbg:
+            data["_fine_win"], data["_fine_f3"] = bf["dbg_w"][:K], bf["dbg_3"][:K]
+        return data
 
 
 def build_model(model_configs, ckpt_path) -> OnePosePlus_model:

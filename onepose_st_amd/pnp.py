@@ -22,6 +22,16 @@ def load():
         lib.oppnp_ransac.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_double,
                                      ctypes.c_int, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+        lib.oppnp_pool_create.restype = ctypes.c_void_p
+        lib.oppnp_pool_create.argtypes = [ctypes.c_int]
+        lib.oppnp_pool_destroy.argtypes = [ctypes.c_void_p]
+        lib.oppnp_pool_submit.restype = ctypes.c_longlong
+        lib.oppnp_pool_submit.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double,
+                                          ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_ulonglong]
+        lib.oppnp_pool_wait_all.restype = ctypes.c_longlong
+        lib.oppnp_pool_wait_all.argtypes = [ctypes.c_void_p]
+        lib.oppnp_pool_result.restype = ctypes.c_int
+        lib.oppnp_pool_result.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
         if lib.oppnp_abi_version() != 1:
             raise RuntimeError("libonepose_pnp.so ABI version mismatch")
         _lib = lib
@@ -52,3 +62,38 @@ def ransac_PnP(K, pts_2d, pts_3d, scale=1, pnp_reprojection_error=5, img_hw=None
     pose_homo = np.concatenate([pose, np.array([[0.0, 0.0, 0.0, 1.0]])], axis=0)
     inliers = np.nonzero(mask[:n])[0].astype(np.int64) if rc == 0 else np.array([], dtype=np.int64)
     return pose, pose_homo, inliers
+
+
+class PnPPool:
+    """Library-owned worker threads: ``submit`` copies the matches and returns a ticket immediately."""
+
+    def __init__(self, K, threads=3, pnp_reprojection_error=7, confidence=0.99, min_iters=8, max_iters=10000, seed=1):
+        self._lib = load()
+        self._K = np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(3, 3))
+        self._args = (float(pnp_reprojection_error), float(confidence), int(min_iters), int(max_iters), int(seed))
+        self._pool = ctypes.c_void_p(self._lib.oppnp_pool_create(int(threads)))
+
+    def submit(self, pts_2d, pts_3d) -> int:
+        p2 = np.ascontiguousarray(pts_2d, dtype=np.float32)
+        p3 = np.ascontiguousarray(pts_3d, dtype=np.float32)
+        return int(self._lib.oppnp_pool_submit(self._pool, self._K.ctypes.data, p2.ctypes.data, p3.ctypes.data, p2.shape[0], *self._args))
+
+    def wait_all(self) -> int:
+        return int(self._lib.oppnp_pool_wait_all(self._pool))
+
+    def result(self, ticket: int):
+        pose = np.zeros((3, 4), dtype=np.float64)
+        n_in = ctypes.c_int(0)
+        rc = self._lib.oppnp_pool_result(self._pool, int(ticket), pose.ctypes.data, ctypes.byref(n_in))
+        return pose, n_in.value, rc
+
+    def close(self):
+        if self._pool:
+            self._lib.oppnp_pool_destroy(self._pool)
+            self._pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

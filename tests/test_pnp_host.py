@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from onepose_st_amd.pnp import ransac_PnP
+from onepose_st_amd.pnp import PnPPool, ransac_PnP
 
 
 def _scene(n, seed, noise_px=0.0, outlier_frac=0.0):
@@ -62,3 +62,16 @@ def test_pose_is_insensitive_at_matcher_noise_level():
     uv2 = uv + np.float32(1e-4) * np.random.default_rng(9).normal(size=uv.shape).astype(np.float32)
     p2, _, _ = ransac_PnP(K, uv2, X, pnp_reprojection_error=7)
     assert np.abs(p1[:, :3] - p2[:, :3]).max() < 1e-6 and np.linalg.norm(p1[:, 3] - p2[:, 3]) / np.linalg.norm(p1[:, 3]) < 1e-6
+
+
+def test_async_pool_matches_sync_calls():
+    scenes = [_scene(400 + 50 * i, 10 + i, noise_px=0.3, outlier_frac=0.1) for i in range(6)]
+    K = scenes[0][0]
+    pool = PnPPool(K, threads=3, pnp_reprojection_error=7)
+    tickets = [pool.submit(s[1], s[2]) for s in scenes]
+    assert tickets == list(range(6)) and pool.wait_all() == 6
+    for tk, s in zip(tickets, scenes):
+        pose, n_in, rc = pool.result(tk)
+        ref, _, inl = ransac_PnP(K, s[1], s[2], pnp_reprojection_error=7)
+        assert rc == 0 and np.array_equal(pose, ref) and n_in == len(inl)
+    pool.close()
