@@ -28,6 +28,7 @@ struct SimArgs {
     float* colpart;      // [B][ntr][M][2]
     int N, M, ntr, ntc;
     float temp;          // temperature + 1e-4
+    unsigned long long* stamps;
 };
 
 // exact-f32 mode keeps libm expf; the bf16 modes (error budget ~1e-5) use v_exp_f32
@@ -52,86 +53,96 @@ __device__ __forceinline__ float half_sum(float v) {
     return v;
 }
 
-// Shared epilogue of the similarity kernels: S = acc / T', row / column (max, sum exp) of this 128 x 128 tile.
+// Shared epilogue of the similarity kernels.  The S tile (128 x 128 f32) is staged through LDS (row pitch 130 floats:
+// conflict-free for the two-lanes-per-row / per-column sweeps below), then
+//   * stored with whole-row 16-byte accesses (the accumulator layout would need 64 scalar stores per lane),
+//   * reduced to per-row and per-column (max, sum exp): two lanes per row (resp. column), each sweeping every other
+//     element sequentially -- no cross-lane shuffles except the final pair merge.
+// In-kernel stamps had the previous register-level epilogue (640 shuffles per wave) at 63 % of the kernel.
+constexpr int SLD = 130;
+constexpr size_t SIM_STAGE_BYTES = (size_t)TM * SLD * sizeof(float);        // 66 560
+
 template <bool FAST>
-__device__ __forceinline__ void sim_epilogue(f32x16 (&acc)[2][2], const SimArgs& p, float (&rowst)[2][TM][2], float (&colst)[2][TN][2],
-                                             int tid, int i0, int j0, int b) {
+__device__ __forceinline__ void sim_epilogue(f32x16 (&acc)[2][2], const SimArgs& p, float* St, int tid, int i0, int j0, int b) {
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
-    // ---- epilogue: S, row / column (max, sum exp) of this tile -------------------------------
+    __syncthreads();                                  // every wave is done reading the operand tiles that St overlays
+    const float inv_temp = 1.0f / p.temp;             // fast modes: one reciprocal instead of 64 divisions per lane
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                St[(64 * wr + 32 * x + acc_row(reg, h)) * SLD + 64 * wc + 32 * y + r] = FAST ? acc[x][y][reg] * inv_temp : acc[x][y][reg] / p.temp;
+    __syncthreads();
+    // ---- S -> conf buffer, whole rows ------------------------------------------------------------
     float* conf = p.conf + (size_t)b * p.N * p.M;
-    bool jv[2];
+    const bool vec = (p.M & 3) == 0;
+#pragma unroll 4
+    for (int i = tid; i < TM * (TN / 4); i += 256) {
+        const int row = i / (TN / 4), c4 = i % (TN / 4);
+        const int gi = i0 + row, gj = j0 + 4 * c4;
+        if (gi >= p.N || gj >= p.M) continue;
+        const float* src = St + row * SLD + 4 * c4;
+        if (vec) {
+            f32x4 v = {src[0], src[1], src[2], src[3]};
+            *reinterpret_cast<f32x4*>(conf + (size_t)gi * p.M + gj) = v;
+        } else {
 #pragma unroll
-    for (int y = 0; y < 2; ++y) jv[y] = (j0 + 64 * wc + 32 * y + r) < p.M;
-#pragma unroll
-    for (int x = 0; x < 2; ++x) {
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int lrow = 64 * wr + 32 * x + acc_row(reg, h);
-            const int i = i0 + lrow;
-            float v[2];
-#pragma unroll
-            for (int y = 0; y < 2; ++y) {
-                const float s = acc[x][y][reg] / p.temp;
-                acc[x][y][reg] = s;
-                if (i < p.N && jv[y]) conf[(size_t)i * p.M + j0 + 64 * wc + 32 * y + r] = s;
-                v[y] = jv[y] ? s : -INFINITY;
-            }
-            const float m = half_max(fmaxf(v[0], v[1]));
-            float e = 0.f;
-            if (m != -INFINITY) e = exp_sel<FAST>(v[0] - m) + exp_sel<FAST>(v[1] - m);
-            e = half_sum(e);
-            if (r == 0) { rowst[wc][lrow][0] = m; rowst[wc][lrow][1] = e; }
+            for (int e = 0; e < 4; ++e)
+                if (gj + e < p.M) conf[(size_t)gi * p.M + gj + e] = src[e];
         }
     }
+    // ---- row / column (max, sum exp).  Lanes (2k, 2k + 1) share row (resp. column) k and take its even / odd
+    // elements: 64 independent LDS reads into registers (latency overlapped), then max and sum exp from registers ----
+    const int idx = tid >> 1, par = tid & 1;
+    {
+        const int ncol = min(TN, p.M - j0);
+        float v[TN / 2];
 #pragma unroll
-    for (int y = 0; y < 2; ++y) {
-        float m = -INFINITY;
+        for (int q = 0; q < TN / 2; ++q) v[q] = (2 * q + par < ncol) ? St[idx * SLD + 2 * q + par] : -INFINITY;
+        float m = -INFINITY, e = 0.f;
 #pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const bool iv = (i0 + 64 * wr + 32 * x + acc_row(reg, h)) < p.N;
-                m = fmaxf(m, iv ? acc[x][y][reg] : -INFINITY);
-            }
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        float e = 0.f;
+        for (int q = 0; q < TN / 2; ++q) m = fmaxf(m, v[q]);
         if (m != -INFINITY) {
 #pragma unroll
-            for (int x = 0; x < 2; ++x)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const bool iv = (i0 + 64 * wr + 32 * x + acc_row(reg, h)) < p.N;
-                    e += iv ? exp_sel<FAST>(acc[x][y][reg] - m) : 0.f;
-                }
+            for (int q = 0; q < TN / 2; ++q) e += exp_sel<FAST>(v[q] - m);          // exp(-inf) = 0 for the masked tail
         }
-        e += __shfl_xor(e, 32, 64);
-        if (h == 0) { colst[wr][64 * wc + 32 * y + r][0] = m; colst[wr][64 * wc + 32 * y + r][1] = e; }
+        const float m2 = __shfl_xor(m, 1, 64), e2 = __shfl_xor(e, 1, 64);
+        float ma = par ? m2 : m, ea = par ? e2 : e, mb = par ? m : m2, eb = par ? e : e2;      // even lane's part first
+        merge_ms(ma, ea, mb, eb);
+        if (par == 0 && i0 + idx < p.N) {
+            float* o = p.rowpart + (((size_t)b * p.ntc + (j0 / TN)) * p.N + i0 + idx) * 2;
+            o[0] = ma; o[1] = ea;
+        }
     }
-    __syncthreads();
-    if (tid < TM) {
-        float m = rowst[0][tid][0], e = rowst[0][tid][1];
-        merge_ms(m, e, rowst[1][tid][0], rowst[1][tid][1]);
-        if (i0 + tid < p.N) {
-            float* o = p.rowpart + (((size_t)b * p.ntc + (j0 / TN)) * p.N + i0 + tid) * 2;
-            o[0] = m; o[1] = e;
+    {
+        const int nrow = min(TM, p.N - i0);
+        float v[TM / 2];
+#pragma unroll
+        for (int q = 0; q < TM / 2; ++q) v[q] = (2 * q + par < nrow) ? St[(2 * q + par) * SLD + idx] : -INFINITY;
+        float m = -INFINITY, e = 0.f;
+#pragma unroll
+        for (int q = 0; q < TM / 2; ++q) m = fmaxf(m, v[q]);
+        if (m != -INFINITY) {
+#pragma unroll
+            for (int q = 0; q < TM / 2; ++q) e += exp_sel<FAST>(v[q] - m);
         }
-    } else {
-        const int c = tid - TM;
-        float m = colst[0][c][0], e = colst[0][c][1];
-        merge_ms(m, e, colst[1][c][0], colst[1][c][1]);
-        if (j0 + c < p.M) {
-            float* o = p.colpart + (((size_t)b * p.ntr + (i0 / TM)) * p.M + j0 + c) * 2;
-            o[0] = m; o[1] = e;
+        const float m2 = __shfl_xor(m, 1, 64), e2 = __shfl_xor(e, 1, 64);
+        float ma = par ? m2 : m, ea = par ? e2 : e, mb = par ? m : m2, eb = par ? e : e2;
+        merge_ms(ma, ea, mb, eb);
+        if (par == 0 && j0 + idx < p.M) {
+            float* o = p.colpart + (((size_t)b * p.ntr + (i0 / TM)) * p.M + j0 + idx) * 2;
+            o[0] = ma; o[1] = ea;
         }
     }
 }
 
 __global__ __launch_bounds__(256) void sim_stats_kernel(SimArgs p) {
-    __shared__ __attribute__((aligned(16))) float At[TM * LDT];
-    __shared__ __attribute__((aligned(16))) float Bt[TN * LDT];
-    __shared__ float rowst[2][TM][2];
-    __shared__ float colst[2][TN][2];
+    extern __shared__ __attribute__((aligned(16))) char smem_f[];
+    float* At = reinterpret_cast<float*>(smem_f);            // [TM][LDT]
+    float* Bt = At + TM * LDT;                               // [TN][LDT]; the S staging image overlays both afterwards
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
     const int j0 = blockIdx.x * TN, i0 = blockIdx.y * TM, b = blockIdx.z;
@@ -190,7 +201,7 @@ __global__ __launch_bounds__(256) void sim_stats_kernel(SimArgs p) {
         }
     }
 
-    sim_epilogue<false>(acc, p, rowst, colst, tid, i0, j0, b);
+    sim_epilogue<false>(acc, p, reinterpret_cast<float*>(smem_f), tid, i0, j0, b);
 }
 
 // Same tile on the bf16 matrix pipe.  K chunks of 64 features are staged as (hi, lo) bf16 planes with a 144-byte row
@@ -206,8 +217,6 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_stats_bf16
     char* AL = smem + (PL - 1) * PB;
     char* BH = smem + PL * PB;
     char* BL = BH + (PL - 1) * PB;
-    __shared__ float rowst[2][TM][2];
-    __shared__ float colst[2][TN][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
     const int j0 = blockIdx.x * TN, i0 = blockIdx.y * TM, b = blockIdx.z;
@@ -257,9 +266,12 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_stats_bf16
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y) acc[x][y] = zero16();
+    const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    OPHIP_STAMP(p.stamps, wg, 0);
     prefetch(0);
     stage();
     __syncthreads();
+    OPHIP_STAMP(p.stamps, wg, 1);
     constexpr int NKC = C / SKC;
     for (int kc = 0; kc < NKC; ++kc) {
         if (kc + 1 < NKC) prefetch(kc + 1);
@@ -280,13 +292,17 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_stats_bf16
 #pragma unroll
                 for (int y = 0; y < 2; ++y) acc[x][y] = mma_bf16<NS>(fah[x], fal[x], fbh[y], fbl[y], acc[x][y]);
         }
+        OPHIP_STAMP(p.stamps, wg, 2 + 3 * kc);
         __syncthreads();
+        OPHIP_STAMP(p.stamps, wg, 3 + 3 * kc);
         if (kc + 1 < NKC) {
             stage();
             __syncthreads();
         }
+        OPHIP_STAMP(p.stamps, wg, 4 + 3 * kc);
     }
-    sim_epilogue<true>(acc, p, rowst, colst, tid, i0, j0, b);
+    sim_epilogue<true>(acc, p, reinterpret_cast<float*>(smem), tid, i0, j0, b);
+    OPHIP_STAMP(p.stamps, wg, 31);
 }
 
 struct CombineArgs {
@@ -562,22 +578,23 @@ extern "C" int ophip_coarse_match(const float* feat3d, const float* feat2d, cons
     float* rowbest = colstat + (size_t)B * M * 2;
     float* colmax = rowbest + (size_t)B * nspan * N * 3;
 
-    SimArgs sa{feat3d, feat2d, conf, rowpart, colpart, N, M, ntr, ntc, (float)(temperature + 1e-4)};
-    if (nsplit == 0) {
-        OPHIP_LAUNCH("sim_stats", stream, sim_stats_kernel, dim3(ntc, ntr, B), dim3(256), 0, stream, sa);
-    } else {
-        const size_t lds = (size_t)(nsplit == 3 ? 4 : 2) * TM * SPITCH;
-        static bool attr[2] = {false, false};
-        if (nsplit == 3) {
-            if (!attr[1]) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sim_stats_bf16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return ophip_fail(e, "hipFuncSetAttribute(sim_stats_bf16)");
-                attr[1] = true;
-            }
-            OPHIP_LAUNCH("sim_stats", stream, sim_stats_bf16_kernel<3>, dim3(ntc, ntr, B), dim3(256), lds, stream, sa);
-        } else {
-            OPHIP_LAUNCH("sim_stats", stream, sim_stats_bf16_kernel<1>, dim3(ntc, ntr, B), dim3(256), lds, stream, sa);
+    SimArgs sa{feat3d, feat2d, conf, rowpart, colpart, N, M, ntr, ntc, (float)(temperature + 1e-4), ophip_stamp_buffer()};
+    {
+        // dynamic LDS = max(operand tiles, S staging image of the epilogue)
+        const size_t tiles = nsplit == 0 ? (size_t)(TM + TN) * LDT * sizeof(float) : (size_t)(nsplit == 3 ? 4 : 2) * TM * SPITCH;
+        const size_t lds = tiles > SIM_STAGE_BYTES ? tiles : SIM_STAGE_BYTES;
+        static bool attr[3] = {false, false, false};
+        const void* fn = nsplit == 0 ? reinterpret_cast<const void*>(sim_stats_kernel)
+                       : nsplit == 3 ? reinterpret_cast<const void*>(sim_stats_bf16_kernel<3>) : reinterpret_cast<const void*>(sim_stats_bf16_kernel<1>);
+        const int ai = nsplit == 0 ? 0 : (nsplit == 3 ? 2 : 1);
+        if (!attr[ai]) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return ophip_fail(e, "hipFuncSetAttribute(sim_stats)");
+            attr[ai] = true;
         }
+        if (nsplit == 0) OPHIP_LAUNCH("sim_stats", stream, sim_stats_kernel, dim3(ntc, ntr, B), dim3(256), lds, stream, sa);
+        else if (nsplit == 3) OPHIP_LAUNCH("sim_stats", stream, sim_stats_bf16_kernel<3>, dim3(ntc, ntr, B), dim3(256), lds, stream, sa);
+        else OPHIP_LAUNCH("sim_stats", stream, sim_stats_bf16_kernel<1>, dim3(ntc, ntr, B), dim3(256), lds, stream, sa);
     }
     OPHIP_CHECK_LAUNCH();
     CombineArgs ca{rowpart, colpart, rowstat, colstat, reinterpret_cast<unsigned*>(colmax), N, M, ntr, ntc};

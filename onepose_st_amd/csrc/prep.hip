@@ -191,6 +191,32 @@ __global__ __launch_bounds__(256) void transpose_cl_kernel(const float* __restri
     }
 }
 
+// [B][128][L] -> [B][L][128]: 32 positions x 128 channels per workgroup, 128-byte reads, whole 512-byte rows written
+// (the fine feature map goes channels-last once per frame so that a 5x5 window gather reads 25 contiguous rows
+// instead of 640 20-byte runs -- measured 328 MB -> 8x over-fetch on the NCHW gather, profiles/r01_pmc_traffic.json)
+__global__ __launch_bounds__(256) void transpose_c128_kernel(const float* __restrict__ in, float* __restrict__ out, int L) {
+    __shared__ float tile[128][33];
+    const int tid = threadIdx.x, l0 = blockIdx.x * 32, b = blockIdx.y;
+    const float* src = in + (size_t)b * 128 * L;
+    const int lx = tid & 31, cy = tid >> 5;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int c = cy + 8 * k;
+        tile[c][lx] = (l0 + lx < L) ? src[(size_t)c * L + l0 + lx] : 0.f;
+    }
+    __syncthreads();
+    float* dst = out + (size_t)b * L * 128;
+    const int p = tid >> 3, q0 = tid & 7;
+    if (l0 + p < L) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int q = q0 + 8 * m;              // float4 index inside the 128-channel row
+            f32x4 v = {tile[4 * q][p], tile[4 * q + 1][p], tile[4 * q + 2][p], tile[4 * q + 3][p]};
+            *reinterpret_cast<f32x4*>(dst + (size_t)(l0 + p) * 128 + 4 * q) = v;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int ophip_pe_add_transpose(const float* feat_nchw, const float* pe_nlc, float* out_nlc, int B, int C, int M, void* stream) {
@@ -204,6 +230,11 @@ extern "C" int ophip_pe_add_transpose(const float* feat_nchw, const float* pe_nl
 
 extern "C" int ophip_transpose_cl(const float* in_bcl, float* out_blc, int B, int C, int L, void* stream) {
     if (!in_bcl || !out_blc) return ophip_bad_arg(__func__, "null pointer");
+    if (C == 128) {
+        OPHIP_LAUNCH("transpose_cl", (hipStream_t)stream, transpose_c128_kernel, dim3((L + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, in_bcl, out_blc, L);
+        OPHIP_CHECK_LAUNCH();
+        return 0;
+    }
     OPHIP_LAUNCH("transpose_cl", (hipStream_t)stream, transpose_cl_kernel, dim3((L + 31) / 32, (C + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, in_bcl, out_blc, C, L);
     OPHIP_CHECK_LAUNCH();
     return 0;

@@ -276,17 +276,24 @@ class OnePosePlus_model(nn.Module):
             names_f = self.loftr_fine.layer_names
             cross_bits = sum(1 << i for i, n in enumerate(names_f) if n == "cross")
             ff = feat_f if feat_f.dtype == torch.float32 else feat_f.float()
+            if ff.stride(1) == 1:                      # channels-last memory already: strides as they are
+                ff_strides = (ff.stride(0), 1, ff.stride(2), ff.stride(3))
+            else:                                      # NCHW: one streaming transpose, then every window pixel is a 512-byte row
+                ff = ff.contiguous()
+                ff_cl = torch.empty(B, hf * wf, ff.shape[1], **f32)
+                lib_call("ophip_transpose_cl", P(ff), P(ff_cl), B, ff.shape[1], hf * wf, S)
+                ff, ff_strides = ff_cl, (hf * wf * ff_cl.shape[2], 1, wf * ff_cl.shape[2], ff_cl.shape[2])
             stride = hf // hc
             fine_scale = (cf["window_size"] // 2) * (data["q_hw_i"][0] / hf)
             max_matches = min(cap, B * min(N, M) + 64)      # mutual matches are one per row and (barring exact ties) per column
             if self.precision == "f32":
-                lib_call("ophip_fine_refine", P(ff), ff.stride(0), ff.stride(1), ff.stride(2), ff.stride(3), hf, wf,
+                lib_call("ophip_fine_refine", P(ff), *ff_strides, hf, wf,
                          P(desc_fine_d), bstride(desc_fine_d), desc_fine_d.stride(1),
                          P(b_ids, torch.int64), P(i_ids, torch.int64), P(j_ids, torch.int64), P(count, torch.int32), max_matches,
                          P(mkc), P(W["fine"]), len(names_f), ctypes.c_uint(cross_bits), 1 if cf["enable"] else 0,
                          wc, stride, float(fine_scale), P(expec), P(mkf), P(dbg_w), P(dbg_3), S)
             else:
-                lib_call("ophip_fine_refine_bf16", P(ff), ff.stride(0), ff.stride(1), ff.stride(2), ff.stride(3), hf, wf,
+                lib_call("ophip_fine_refine_bf16", P(ff), *ff_strides, hf, wf,
                          P(desc_fine_d), bstride(desc_fine_d), desc_fine_d.stride(1),
                          P(b_ids, torch.int64), P(i_ids, torch.int64), P(j_ids, torch.int64), P(count, torch.int32), max_matches,
                          P(mkc), P(W["fine_bf16"], None), len(names_f), ctypes.c_uint(cross_bits), 1 if cf["enable"] else 0,

@@ -1,0 +1,30 @@
+"""Diagnostic: cycle stamps of sim_stats_bf16 at c2. Not part of the product."""
+import sys, ctypes, numpy as np, torch
+sys.path.insert(0, ".")
+from onepose_st_amd import hip
+dev = torch.device("cuda:0"); hip.load()
+N, M, wc = 7000, 4800, 80
+g = torch.Generator().manual_seed(0)
+f3, f2 = torch.randn(1, N, 256, generator=g).to(dev), torch.randn(1, M, 256, generator=g).to(dev)
+kp = torch.zeros(1, N, 3, device=dev)
+conf = torch.empty(1, N, M, device=dev); ws = torch.empty(hip.load().ophip_coarse_workspace_floats(1, N, M), device=dev)
+ids = [torch.empty(N, dtype=torch.int64, device=dev) for _ in range(3)]
+mconf, mk3, mkc = torch.empty(N, device=dev), torch.empty(N, 3, device=dev), torch.empty(N, 2, device=dev)
+cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+def run():
+    hip.call("ophip_coarse_match", hip.ptr(f3), hip.ptr(f2), hip.ptr(kp), kp.stride(0), 1, N, M, wc, 0.08, 0.1, 2, 8.0, hip.ptr(conf), hip.ptr(ws),
+             *[hip.ptr(t, torch.int64) for t in ids], hip.ptr(mconf), hip.ptr(mk3), hip.ptr(mkc), hip.ptr(cnt, torch.int32), 3, hip.stream_handle())
+for _ in range(3): run()
+nwg = 38 * 55
+buf = torch.zeros(nwg * 32, dtype=torch.int64, device=dev)
+hip.call("ophip_debug_stamps", ctypes.c_void_p(buf.data_ptr())); run(); torch.cuda.synchronize(); hip.call("ophip_debug_stamps", None)
+s = buf.view(-1, 32).cpu().numpy().astype(np.int64)
+names = {1: "prologue load+stage+sync"}
+for kc in range(4):
+    names[2 + 3 * kc] = f"kc{kc} prefetch+mfma"; names[3 + 3 * kc] = f"kc{kc} sync"; names[4 + 3 * kc] = f"kc{kc} stage+sync"
+names[31] = "epilogue"
+prev = s[:, 0]
+print("WGs", nwg, "median WG cycles", np.median(s[:, 31] - s[:, 0]), "span cycles", s[:, 31].max() - s[:, 0].min())
+for k in sorted(names):
+    print(f"{names[k]:28s} {np.median(s[:, k] - prev):9.0f}")
+    prev = s[:, k]
