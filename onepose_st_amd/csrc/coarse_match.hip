@@ -351,7 +351,7 @@ struct ConfArgs {
 };
 
 constexpr int CONF_ROWS = 16;      // rows per workgroup
-constexpr int CONF_RB = 4;         // rows in flight per thread (independent 16 B loads)
+constexpr int CONF_RB = 2;         // rows per pipeline stage (two stages in flight)
 constexpr int CONF_U = 4;          // float4 groups per thread per row  => span <= 4096 columns
 
 template <bool VEC, bool FAST>
@@ -378,9 +378,9 @@ __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
             cbest[u][e] = 0.f;
         }
     const int nrows = min(CONF_ROWS, p.N - i0);
-    for (int r0 = 0; r0 < nrows; r0 += CONF_RB) {
-        // issue the loads of up to CONF_RB rows before touching any of them
-        float s[CONF_RB][CONF_U][4];
+    // software pipeline over batches of CONF_RB rows: the loads of batch k + 1 are in flight while batch k is processed
+    float s[2][CONF_RB][CONF_U][4];
+    auto load_batch = [&](int r0, float (&dst)[CONF_RB][CONF_U][4]) {
 #pragma unroll
         for (int q = 0; q < CONF_RB; ++q) {
             const int rr = min(r0 + q, nrows - 1);
@@ -391,13 +391,15 @@ __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
                 if (VEC) {
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
                     if (jq < je) v = *reinterpret_cast<const f32x4*>(row + jq);
-                    s[q][u][0] = v[0]; s[q][u][1] = v[1]; s[q][u][2] = v[2]; s[q][u][3] = v[3];
+                    dst[q][u][0] = v[0]; dst[q][u][1] = v[1]; dst[q][u][2] = v[2]; dst[q][u][3] = v[3];
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) s[q][u][e] = (jq + e < je) ? row[jq + e] : 0.f;
+                    for (int e = 0; e < 4; ++e) dst[q][u][e] = (jq + e < je) ? row[jq + e] : 0.f;
                 }
             }
         }
+    };
+    auto process_batch = [&](int r0, float (&cur)[CONF_RB][CONF_U][4]) {
 #pragma unroll
         for (int q = 0; q < CONF_RB; ++q) {
             const int rr = r0 + q;
@@ -414,8 +416,8 @@ __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             // softmax over the 3D axis (dim=1: column stats) times softmax over the 2D axis (dim=2: row stats)
-                            const float c = (exp_sel<FAST>(s[q][u][e] - cm[u][e]) * cinv[u][e]) * (exp_sel<FAST>(s[q][u][e] - rm) * rinv);
-                            s[q][u][e] = c;
+                            const float c = (exp_sel<FAST>(cur[q][u][e] - cm[u][e]) * cinv[u][e]) * (exp_sel<FAST>(cur[q][u][e] - rm) * rinv);
+                            cur[q][u][e] = c;
                             if (jq + e < je) {
                                 cbest[u][e] = fmaxf(cbest[u][e], c);
                                 if (c > bv) { bv = c; bj = jq + e; bc = 1; }
@@ -423,11 +425,11 @@ __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
                             }
                         }
                         if (VEC) {
-                            f32x4 v = {s[q][u][0], s[q][u][1], s[q][u][2], s[q][u][3]};
+                            f32x4 v = {cur[q][u][0], cur[q][u][1], cur[q][u][2], cur[q][u][3]};
                             *reinterpret_cast<f32x4*>(row + jq) = v;
                         } else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) if (jq + e < je) row[jq + e] = s[q][u][e];
+                            for (int e = 0; e < 4; ++e) if (jq + e < je) row[jq + e] = cur[q][u][e];
                         }
                     }
                 }
@@ -443,6 +445,13 @@ __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
                 if (lane == 0) { red_v[wave][rr] = wv; red_j[wave][rr] = cj; red_c[wave][rr] = cc; }
             }
         }
+    };
+    load_batch(0, s[0]);
+    for (int r0 = 0; r0 < nrows; r0 += 2 * CONF_RB) {
+        if (r0 + CONF_RB < nrows) load_batch(r0 + CONF_RB, s[1]);
+        process_batch(r0, s[0]);
+        if (r0 + 2 * CONF_RB < nrows) load_batch(r0 + 2 * CONF_RB, s[0]);
+        if (r0 + CONF_RB < nrows) process_batch(r0 + CONF_RB, s[1]);
     }
     __syncthreads();
     if (tid < nrows) {

@@ -414,6 +414,54 @@ def test_c1_bf16_modes_against_reference_golden(sd, cfg, dev, golden_dir, precis
         assert (want & planted) <= got            # every planted (margin) match survives bf16
 
 
+def test_c4_large_object_against_oracle(sd, cfg, dev):
+    """BASELINE config c4: 15 000 3D points x 19 200 cells (960 x 1280 image): the 1.15 GB conf_matrix case.
+    Indices bit-exact against the oracle, keypoints at the bf16x3 tolerance, pose parity, mutual-NN on the device."""
+    m = _model(sd, cfg, dev, "bf16x3")
+    inp = make_synthetic_inputs(sd, n_points=15000, image_hw=(960, 1280), n_plant=6000, seed=2, config=cfg)
+    data = _run_features(m, inp, dev)
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    with torch.no_grad():
+        ref = orc.forward_from_features(sd, cfg, inp, inp["feat_c"], inp["feat_f"], inp["image_hw"])
+    assert len(ref["i_ids"]) > 4000 and data["conf_matrix"].shape == (1, 15000, 19200)
+    _check_against(data, {k: ref[k].numpy() for k in ("b_ids", "i_ids", "j_ids", "m_bids", "mconf", "mkpts_3d_db", "mkpts_query_c",
+                                                      "mkpts_query_f", "expec_f")}, "bf16x3")
+    _pose_parity(data, ref["mkpts_3d_db"].numpy(), ref["mkpts_query_f"].numpy(), inp, "c4 bf16x3 vs oracle")
+    conf, i, j = data["conf_matrix"][0], data["i_ids"], data["j_ids"]
+    v = conf[i, j]
+    assert torch.equal(v, data["mconf"]) and torch.equal(v, conf.max(dim=1)[0][i]) and torch.equal(v, conf.max(dim=0)[0][j])
+    del conf, data
+
+
+def test_c3_batch32_matches_single_frame_runs(sd, cfg, dev):
+    """BASELINE config c3: 32 frames per call sharing one 3D block (expand(), stride-0 batch), 7000 x 4800, coarse + fine.
+    Every frame of the batch must equal its own B = 1 run bit for bit (frames never interact: no cross-frame state,
+    fixed-order reductions), ids must come out in ascending (b, i) order, conf_matrix is [32, 7000, 4800] (4.3 GB)."""
+    m = _model(sd, cfg, dev, "bf16x3")
+    frames = [make_synthetic_inputs(sd, n_points=7000, image_hw=(480, 640), n_plant=3000, seed=1, config=cfg, frame=f) for f in range(4)]
+    singles = [_run_features(m, fr, dev) for fr in frames]
+    B = 32
+    order = [k % 4 for k in range(B)]
+    batch = {"feat_c": torch.cat([frames[k]["feat_c"] for k in order]), "feat_f": torch.cat([frames[k]["feat_f"] for k in order]),
+             "image_hw": frames[0]["image_hw"]}
+    for key in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db"):
+        batch[key] = frames[0][key].expand(B, *frames[0][key].shape[1:])
+    d = to_dev(batch, dev)
+    data = {k: d[k] for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db")}
+    m.forward_features(data, d["feat_c"], d["feat_f"], batch["image_hw"])
+    assert data["conf_matrix"].shape == (B, 7000, 4800)
+    b_ids = data["b_ids"]
+    key = b_ids * 7000 + data["i_ids"]
+    assert bool((key[1:] > key[:-1]).all())
+    for b in range(B):
+        sel = b_ids == b
+        one = singles[order[b]]
+        for k in ("i_ids", "j_ids", "mconf", "mkpts_query_f", "mkpts_3d_db", "expec_f"):
+            assert torch.equal(data[k][sel], one[k]), (b, k)
+    assert torch.equal(data["conf_matrix"][5], singles[order[5]]["conf_matrix"][0])
+    del data, singles
+
+
 def test_fine_disabled_and_encoder_disabled(sd, cfg, dev):
     inp = make_synthetic_inputs(sd, n_points=300, image_hw=(96, 136), n_plant=100, seed=9, config=cfg)
     c2 = copy.deepcopy(cfg)
