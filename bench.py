@@ -199,6 +199,16 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # HBM bytes per launch of the roofline kernel: from the committed PMC pass (separate rocprofv3 --pmc runs), not live
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))["kernels"]
+        key = {"bf16x3": "attn_apply_bf16_kernel<3>", "bf16": "attn_apply_bf16_kernel<1>", "f32": "attn_apply_kernel"}[args.precision]
+        if key in pmc and B == 1 and args.workload == "c2":
+            traffic = pmc[key]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+
     frames_total = world * args.steps * B
     value = frames_total / dt
     avg_ms = kern_ms / max(launches, 1)
@@ -237,7 +247,7 @@ def main():
             "peak": MFMA_PEAK_TFLOPS[args.precision],
             "unit": "TFLOP/s",
             "frac": achieved / MFMA_PEAK_TFLOPS[args.precision],
-            "traffic": None,
+            "traffic": traffic,
             "launches": launches,
             "avg_launch_ms": avg_ms,
             "flops_per_launch": flops,
