@@ -80,6 +80,8 @@ def main():
                     help="matrix arithmetic of the encoder kernels (see DESIGN.md section 4)")
     ap.add_argument("--no-pnp", action="store_true", help="time the matcher only (no host PnP)")
     ap.add_argument("--pnp-threads", type=int, default=3)
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses cuda:0 (one-GPU box, with --dist-backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
@@ -89,12 +91,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.share_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     hip.load()
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     cfg = default_config()
     cfg["hip_precision"] = args.precision
@@ -241,12 +248,14 @@ def main():
             "parallelism": f"frames sharded over {world} rank(s), one RCCL broadcast of weights + 3D block ({bcast_bytes} B)",
         },
         "roofline": {
-            "kernel": "attn_apply_kernel",
+            "kernel": {"bf16x3": "attn_apply_bf16_kernel<3>", "bf16": "attn_apply_bf16_kernel<1>", "f32": "attn_apply_kernel"}[args.precision]
+                      + " (fused Q-proj + linear attention + merge + MLP + 2 LayerNorms" + (" + next layer's K/V reduce)" if args.precision != "f32" else ")"),
             "bound": "mfma",
             "achieved": achieved,
             "peak": MFMA_PEAK_TFLOPS[args.precision],
             "unit": "TFLOP/s",
             "frac": achieved / MFMA_PEAK_TFLOPS[args.precision],
+            "mfma_issue_frac": achieved * (3.0 if args.precision == "bf16x3" else 1.0) / MFMA_PEAK_TFLOPS[args.precision],
             "traffic": traffic,
             "launches": launches,
             "avg_launch_ms": avg_ms,

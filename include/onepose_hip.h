@@ -64,11 +64,16 @@ int ophip_encoder_layer(const float* x3d, const float* x2d, float* y3d, float* y
 
 /* Same layer on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, f32 accumulate).  nsplit = 1: plain bf16 operands;
  * nsplit = 3: split-bf16 (x = hi + lo, three MFMAs per product, ~f32-grade results).  wpack: packing.pack_coarse_layer_bf16
- * (ophip_encoder_bf16_wpack_bytes() bytes); workspace: ophip_encoder_bf16_workspace_bytes() bytes, 256-byte aligned. */
+ * (ophip_encoder_bf16_wpack_bytes() bytes); workspace: ophip_encoder_bf16_workspace_bytes() bytes, 256-byte aligned.
+ * Layer chaining: when wpack_next (the NEXT layer's block) is given, attn_apply also produces that layer's K/V partial
+ * slabs from the output tile while it is still on chip; the next call then passes kv_from_prev = 1 (skips its own
+ * kv_reduce launch) and slot ^ 1 (the two slab sets of the workspace ping-pong).  A stand-alone layer: wpack_next = NULL,
+ * kv_from_prev = 0, slot = 0. */
 size_t ophip_encoder_bf16_workspace_bytes(int B, int L3d, int L2d);
 size_t ophip_encoder_bf16_wpack_bytes(void);
 int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
-                             const void* wpack, int nsplit, int is_cross, void* workspace, void* stream);
+                             const void* wpack, const void* wpack_next, int nsplit, int is_cross, int kv_from_prev, int slot,
+                             void* workspace, void* stream);
 
 /* a7 + a8 -- CoarseMatching.forward + get_coarse_match, inference branch
  * (utils/coarse_matching.py:76-123, :125-242, mask_border :10-20).

@@ -36,42 +36,24 @@ struct KvRedArgs {
     float* partial;                 // [B][slabs0 + slabs1][KV_PART_FLOATS]
 };
 
+// K, V projection of one 32-token tile (rows 32 tt .. of the planes) for heads 2 fw, 2 fw + 1, then the tile's
+// KV = phi(K)^T V / Ksum partial slab straight from the accumulators.  `ring` must be filled from whi / wlo.
 template <int NS>
-__global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void kv_reduce_bf16_kernel(KvRedArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int PL = NS == 3 ? 2 : 1;
-    char* XH = smem;
-    char* XL = smem + (PL - 1) * TOK * ROWB;
-    // 8 waves: wave = 4 * tt + fw owns heads 2 fw, 2 fw + 1 (K and V tiles) of token tile tt -> one partial slab per
-    // 32 tokens; two waves per SIMD cover each other's MFMA -> VALU latencies
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fw = wave & 3, tt = wave >> 2;
+__device__ __forceinline__ void kv_slab_from_planes(WRing<4, 2, NS>& ring, const bf16x8* whi, const bf16x8* wlo, const char* xh, const char* xl,
+                                                    int tok_base, int L, float* out, int fw, int lane) {
     const int r = lane & 31, h = lane >> 5;
-    const int tile = blockIdx.x, b = blockIdx.y;
-    const int s = tile >= a.tiles[0] ? 1 : 0;
-    const int lt = s ? tile - a.tiles[0] : tile;
-    const int L = a.L[s], tok0 = lt * TOK;
-    WRing<4, 2, NS> ring;
-    const bf16x8* whi = a.w_hi + (size_t)(4 * fw) * TS + lane;
-    const bf16x8* wlo = a.w_lo + (size_t)(4 * fw) * TS + lane;
-    ring.fill(whi, wlo, TS);                         // weights travel while the activation tile is staged
-    load_rows_to_planes<NS, C, TOK>(XH, XL, a.x[s] + (size_t)b * a.xbs[s], tok0, L, tid, 512);
-    __syncthreads();
-    if (tok0 + 32 * tt >= L) return;                 // second half of a ragged last tile: no tokens, no slab
-
     // D[token][feature]: t = 0,1 -> K of heads 2fw, 2fw+1;  t = 2,3 -> V of the same heads
     f32x16 acc[4][1];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t][0] = zero16();
-    gemm_bf16_ring<4, 1, NS, false, KB, 2>(acc, ring, whi, wlo, TS, XH + 32 * tt * ROWB, XL + 32 * tt * ROWB, ROWB, 0, lane);
+    gemm_bf16_ring<4, 1, NS, false, KB, 2>(acc, ring, whi, wlo, TS, xh, xl, ROWB, 0, lane);
     const float inv_len = 1.0f / (float)L;
     const bf16x8 zeros = zero_bf8();
     bf16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
-    auto f_k = [&](int reg, float v) { return tok0 + 32 * tt + acc_row(reg, h) < L ? elu_plus_one_fast(v) : 0.f; };   // padded tokens drop out
-    auto f_v = [&](int reg, float v) { return v * inv_len; };                                                       // values / v_length
-    float* out = a.partial + ((size_t)b * (a.slabs[0] + a.slabs[1]) + (s ? a.slabs[0] : 0) + 2 * lt + tt) * KV_PART_FLOATS;
+    auto f_k = [&](int reg, float v) { return tok_base + acc_row(reg, h) < L ? elu_plus_one_fast(v) : 0.f; };   // padded tokens drop out
+    auto f_v = [&](int reg, float v) { return v * inv_len; };                                                 // values / v_length
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         f32x16 kv = zero16(), ks = zero16();
@@ -98,6 +80,33 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void kv_reduce_bf16
             for (int reg = 0; reg < 16; ++reg) o[reg] = ks[reg];
         }
     }
+}
+
+template <int NS>
+__global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void kv_reduce_bf16_kernel(KvRedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PL = NS == 3 ? 2 : 1;
+    char* XH = smem;
+    char* XL = smem + (PL - 1) * TOK * ROWB;
+    // 8 waves: wave = 4 * tt + fw owns heads 2 fw, 2 fw + 1 (K and V tiles) of token tile tt -> one partial slab per
+    // 32 tokens; two waves per SIMD cover each other's MFMA -> VALU latencies
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fw = wave & 3, tt = wave >> 2;
+    const int r = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int s = tile >= a.tiles[0] ? 1 : 0;
+    const int lt = s ? tile - a.tiles[0] : tile;
+    const int L = a.L[s], tok0 = lt * TOK;
+    WRing<4, 2, NS> ring;
+    const bf16x8* whi = a.w_hi + (size_t)(4 * fw) * TS + lane;
+    const bf16x8* wlo = a.w_lo + (size_t)(4 * fw) * TS + lane;
+    ring.fill(whi, wlo, TS);                         // weights travel while the activation tile is staged
+    load_rows_to_planes<NS, C, TOK>(XH, XL, a.x[s] + (size_t)b * a.xbs[s], tok0, L, tid, 512);
+    __syncthreads();
+    if (tok0 + 32 * tt >= L) return;                 // second half of a ragged last tile: no tokens, no slab
+
+    float* out = a.partial + ((size_t)b * (a.slabs[0] + a.slabs[1]) + (s ? a.slabs[0] : 0) + 2 * lt + tt) * KV_PART_FLOATS;
+    kv_slab_from_planes<NS>(ring, whi, wlo, XH + 32 * tt * ROWB, XL + 32 * tt * ROWB, tok0 + 32 * tt, L, out, fw, lane);
 }
 
 struct KvSumBArgs {
@@ -149,6 +158,10 @@ struct AttnBArgs {
     float srclen[2];
     const bf16x8 *w_hi, *w_lo; // layer block planes (Wq | Wkv | Wm | W0 | W2)
     const float* ln;           // g1 b1 g2 b2
+    // fused kv_reduce of the NEXT layer (NULL: not fused): its Wkv fragments and partial slabs
+    const bf16x8 *nkv_hi, *nkv_lo;
+    float* npartial;
+    int slabs[2];
     unsigned long long* stamps;
 };
 
@@ -321,12 +334,44 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void attn_apply_bf1
         }
     __syncthreads();
     float* yg = a.y[s] + (size_t)b * a.ybs[s];
+    const bool fuse = a.nkv_hi != nullptr;
+    // next layer's K|V weights start travelling now (consumed after the barrier below)
+    WRing<4, 2, NS> rkv;
+    const bf16x8* nhi = a.nkv_hi + (size_t)(4 * fw) * TS + lane;
+    const bf16x8* nlo = a.nkv_lo + (size_t)(4 * fw) * TS + lane;
+    if (fuse) rkv.fill(nhi, nlo, TS);
+    // planes of the OUTPUT tile for the fused kv_reduce: behind the f32 stage (= the Y region in split mode)
+    char* KH = smem + TOK * C * 4;
+    char* KL = KH + (PL - 1) * XB;
     for (int i = tid; i < TOK * (C / 4); i += 512) {
         const int row = i / (C / 4), ch = i % (C / 4);
+        f32x4 yv = {0.f, 0.f, 0.f, 0.f};
         if (tok0 + row < L) {
             const f32x4 mv = *reinterpret_cast<const f32x4*>(stage + row * (C * 4) + ((ch ^ (row & 15)) << 4));
             const f32x4 xv = *reinterpret_cast<const f32x4*>(xg + (size_t)(tok0 + row) * C + 4 * ch);
-            *reinterpret_cast<f32x4*>(yg + (size_t)(tok0 + row) * C + 4 * ch) = xv + mv;
+            yv = xv + mv;
+            *reinterpret_cast<f32x4*>(yg + (size_t)(tok0 + row) * C + 4 * ch) = yv;
+        }
+        if (fuse) {                                   // rows beyond L stay zero: they drop out of phi(K) and V
+            bf16x4 vh, vl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                __bf16 hh, ll;
+                split_bf16(yv[j], hh, ll);
+                vh[j] = hh; vl[j] = ll;
+            }
+            const int off = plane_off(row, ch >> 1, ROWB) + 8 * (ch & 1);
+            *reinterpret_cast<bf16x4*>(KH + off) = vh;
+            if (NS == 3) *reinterpret_cast<bf16x4*>(KL + off) = vl;
+        }
+    }
+    OPHIP_STAMP(a.stamps, wg, 30);
+    if (fuse) {
+        // ---- kv_reduce of the next layer on the tile that is still on chip (saves a launch and a re-read of the streams) ----
+        __syncthreads();
+        if (tok0 + 32 * tt < L) {
+            float* out = a.npartial + ((size_t)b * (a.slabs[0] + a.slabs[1]) + (s ? a.slabs[0] : 0) + 2 * lt + tt) * KV_PART_FLOATS;
+            kv_slab_from_planes<NS>(rkv, nhi, nlo, KH + 32 * tt * ROWB, KL + 32 * tt * ROWB, tok0 + 32 * tt, L, out, fw, lane);
         }
     }
     OPHIP_STAMP(a.stamps, wg, 31);
@@ -342,22 +387,26 @@ int set_lds(K kernel, size_t bytes, const char* what) {
 
 extern "C" size_t ophip_encoder_bf16_workspace_bytes(int B, int L3d, int L2d) {
     const size_t slabs = (size_t)((L3d + 31) / 32 + (L2d + 31) / 32);
-    return (size_t)B * slabs * KV_PART_FLOATS * 4 + (size_t)B * 2 * KV_BLOCK_BYTES + 256;
+    return 2 * (size_t)B * slabs * KV_PART_FLOATS * 4 + (size_t)B * 2 * KV_BLOCK_BYTES + 256;      // two slab sets (ping-pong) + KV
 }
 
 extern "C" size_t ophip_encoder_bf16_wpack_bytes(void) { return (size_t)2 * W_ELEMS * 2 + 4 * C * 4; }
 
 extern "C" int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
-                                        const void* wpack, int nsplit, int is_cross, void* workspace, void* stream_) {
+                                        const void* wpack, const void* wpack_next, int nsplit, int is_cross, int kv_from_prev, int slot,
+                                        void* workspace, void* stream_) {
     if (!x3d || !x2d || !y3d || !y2d || !wpack || !workspace) return ophip_bad_arg(__func__, "null pointer");
     if (B < 1 || L3d < 1 || L2d < 1) return ophip_bad_arg(__func__, "B, L3d, L2d must be >= 1");
     if (nsplit != 1 && nsplit != 3) return ophip_bad_arg(__func__, "nsplit must be 1 (bf16) or 3 (split bf16)");
+    if (slot != 0 && slot != 1) return ophip_bad_arg(__func__, "slot must be 0 or 1");
     if (x3d == y3d || x2d == y2d) return ophip_bad_arg(__func__, "in-place layer is not supported (cross layers read the pre-update streams)");
     hipStream_t stream = (hipStream_t)stream_;
     const int t3 = (L3d + TOK - 1) / TOK, t2 = (L2d + TOK - 1) / TOK;
     const int s3 = (L3d + 31) / 32, s2 = (L2d + 31) / 32;
-    float* partial = reinterpret_cast<float*>(workspace);
-    char* kv = reinterpret_cast<char*>(workspace) + (size_t)B * (s3 + s2) * KV_PART_FLOATS * 4;
+    const size_t part_floats = (size_t)B * (s3 + s2) * KV_PART_FLOATS;
+    float* partial = reinterpret_cast<float*>(workspace) + (size_t)slot * part_floats;          // this layer's slabs
+    float* partial_next = reinterpret_cast<float*>(workspace) + (size_t)(slot ^ 1) * part_floats;
+    char* kv = reinterpret_cast<char*>(workspace) + 2 * part_floats * 4;
     kv += (256 - (reinterpret_cast<uintptr_t>(kv) & 255)) & 255;
     // layer block: [hi plane: Wq | Wkv | Wm | W0 | W2][lo plane: same][g1 b1 g2 b2 f32]   (packing.pack_coarse_layer_bf16)
     const bf16x8* w_hi = reinterpret_cast<const bf16x8*>(wpack);
@@ -365,22 +414,24 @@ extern "C" int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, floa
     const float* ln = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wpack) + (size_t)2 * W_ELEMS * 2);
     const int PL = nsplit == 3 ? 2 : 1;
 
-    KvRedArgs ka;
-    ka.x[0] = x3d; ka.x[1] = x2d;
-    ka.xbs[0] = (long long)L3d * C; ka.xbs[1] = (long long)L2d * C;
-    ka.L[0] = L3d; ka.L[1] = L2d; ka.tiles[0] = t3; ka.tiles[1] = t2; ka.slabs[0] = s3; ka.slabs[1] = s2;
-    ka.w_hi = w_hi + C * C / 8; ka.w_lo = w_lo + C * C / 8;
-    ka.partial = partial;
-    const size_t lds_kv = (size_t)PL * TOK * ROWB;
-    static bool attr_kv[2] = {false, false}, attr_at[2] = {false, false};
-    if (nsplit == 3) {
-        if (!attr_kv[1]) { if (int rc = set_lds(kv_reduce_bf16_kernel<3>, lds_kv, "hipFuncSetAttribute(kv_reduce_bf16)")) return rc; attr_kv[1] = true; }
-        OPHIP_LAUNCH("kv_reduce", stream, kv_reduce_bf16_kernel<3>, dim3(t3 + t2, B), dim3(512), lds_kv, stream, ka);
-    } else {
-        if (!attr_kv[0]) { if (int rc = set_lds(kv_reduce_bf16_kernel<1>, lds_kv, "hipFuncSetAttribute(kv_reduce_bf16)")) return rc; attr_kv[0] = true; }
-        OPHIP_LAUNCH("kv_reduce", stream, kv_reduce_bf16_kernel<1>, dim3(t3 + t2, B), dim3(512), lds_kv, stream, ka);
+    if (!kv_from_prev) {
+        KvRedArgs ka;
+        ka.x[0] = x3d; ka.x[1] = x2d;
+        ka.xbs[0] = (long long)L3d * C; ka.xbs[1] = (long long)L2d * C;
+        ka.L[0] = L3d; ka.L[1] = L2d; ka.tiles[0] = t3; ka.tiles[1] = t2; ka.slabs[0] = s3; ka.slabs[1] = s2;
+        ka.w_hi = w_hi + C * C / 8; ka.w_lo = w_lo + C * C / 8;
+        ka.partial = partial;
+        const size_t lds_kv = (size_t)PL * TOK * ROWB;
+        static bool attr_kv[2] = {false, false};
+        if (nsplit == 3) {
+            if (!attr_kv[1]) { if (int rc = set_lds(kv_reduce_bf16_kernel<3>, lds_kv, "hipFuncSetAttribute(kv_reduce_bf16)")) return rc; attr_kv[1] = true; }
+            OPHIP_LAUNCH("kv_reduce", stream, kv_reduce_bf16_kernel<3>, dim3(t3 + t2, B), dim3(512), lds_kv, stream, ka);
+        } else {
+            if (!attr_kv[0]) { if (int rc = set_lds(kv_reduce_bf16_kernel<1>, lds_kv, "hipFuncSetAttribute(kv_reduce_bf16)")) return rc; attr_kv[0] = true; }
+            OPHIP_LAUNCH("kv_reduce", stream, kv_reduce_bf16_kernel<1>, dim3(t3 + t2, B), dim3(512), lds_kv, stream, ka);
+        }
+        OPHIP_CHECK_LAUNCH();
     }
-    OPHIP_CHECK_LAUNCH();
 
     KvSumBArgs sa;
     sa.partial = partial; sa.kv = kv; sa.tiles[0] = s3; sa.tiles[1] = s2;
@@ -397,8 +448,18 @@ extern "C" int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, floa
     aa.srclen[0] = (float)(is_cross ? L2d : L3d);
     aa.srclen[1] = (float)(is_cross ? L3d : L2d);
     aa.w_hi = w_hi; aa.w_lo = w_lo; aa.ln = ln;
+    aa.nkv_hi = aa.nkv_lo = nullptr; aa.npartial = partial_next; aa.slabs[0] = s3; aa.slabs[1] = s2;
+    if (wpack_next) {
+        const bf16x8* n_hi = reinterpret_cast<const bf16x8*>(wpack_next);
+        aa.nkv_hi = n_hi + C * C / 8;
+        aa.nkv_lo = n_hi + W_ELEMS / 8 + C * C / 8;
+    }
     aa.stamps = ophip_stamp_buffer();
-    const size_t lds_at = (size_t)PL * (2 * TOK * ROWB + TOK * HROWB);
+    // LDS: X, Y planes + hidden chunk; the fused tail needs the output planes behind the 64 KiB f32 stage
+    size_t lds_at = (size_t)PL * (2 * TOK * ROWB + TOK * HROWB);
+    const size_t lds_fuse = (size_t)TOK * C * 4 + (size_t)PL * TOK * ROWB;
+    if (lds_fuse > lds_at) lds_at = lds_fuse;
+    static bool attr_at[2] = {false, false};
     if (nsplit == 3) {
         if (!attr_at[1]) { if (int rc = set_lds(attn_apply_bf16_kernel<3>, lds_at, "hipFuncSetAttribute(attn_apply_bf16)")) return rc; attr_at[1] = true; }
         OPHIP_LAUNCH("attn_apply", stream, attn_apply_bf16_kernel<3>, dim3(t3 + t2, B), dim3(512), lds_at, stream, aa);

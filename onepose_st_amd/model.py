@@ -242,9 +242,12 @@ class OnePosePlus_model(nn.Module):
         else:
             nsplit = 3 if self.precision == "bf16x3" else 1
             ws = torch.empty(hip.load().ophip_encoder_bf16_workspace_bytes(B, N, M), device=dev, dtype=torch.uint8)
-            for li, name in enumerate(self.loftr_coarse.layer_names):
-                lib_call("ophip_encoder_layer_bf16", P(x3d), P(x2d), P(y3d), P(y2d), B, N, M, P(W["coarse_bf16"][li], None),
-                         nsplit, 1 if name == "cross" else 0, P(ws, None), S)
+            names_c = self.loftr_coarse.layer_names
+            for li, name in enumerate(names_c):
+                # layer li's attn_apply also emits layer li+1's K/V partial slabs from the on-chip output tile
+                nxt = W["coarse_bf16"][li + 1] if li + 1 < len(names_c) else None
+                lib_call("ophip_encoder_layer_bf16", P(x3d), P(x2d), P(y3d), P(y2d), B, N, M, P(W["coarse_bf16"][li], None), P(nxt, None),
+                         nsplit, 1 if name == "cross" else 0, 1 if li > 0 else 0, li & 1, P(ws, None), S)
                 x3d, y3d, x2d, y2d = y3d, x3d, y2d, x2d
         if self.debug:
             data["_feat3d_c"], data["_feat2d_c"] = x3d, x2d

@@ -133,7 +133,7 @@ def test_encoder_layer_bf16(sd, dev, nsplit, rtol, atol, cross, B, L3, L2):
     ws = torch.empty(hip.load().ophip_encoder_bf16_workspace_bytes(B, L3, L2), dtype=torch.uint8, device=dev)
     d3, d2 = x3.to(dev), x2.to(dev)
     y3, y2 = torch.full_like(d3, float("nan")), torch.full_like(d2, float("nan"))
-    hip.call("ophip_encoder_layer_bf16", hip.ptr(d3), hip.ptr(d2), hip.ptr(y3), hip.ptr(y2), B, L3, L2, hip.ptr(w, None), nsplit, cross,
+    hip.call("ophip_encoder_layer_bf16", hip.ptr(d3), hip.ptr(d2), hip.ptr(y3), hip.ptr(y2), B, L3, L2, hip.ptr(w, None), None, nsplit, cross, 0, 0,
              hip.ptr(ws, None), hip.stream_handle())
     e3 = (y3.cpu() - r3).abs().max().item()
     e2 = (y2.cpu() - r2).abs().max().item()

@@ -1,6 +1,6 @@
 """Diagnostic: per-phase cycle stamps of attn_apply_bf16 for one coarse layer at c2. Not part of the product."""
 import sys, ctypes, numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))
 from onepose_st_amd import hip, packing
 from onepose_st_amd.config import default_config
 from onepose_st_amd.synthetic import make_synthetic_state_dict
@@ -13,7 +13,7 @@ y3, y2 = torch.empty_like(x3), torch.empty_like(x2)
 w = packing.pack_coarse_layer_bf16(sd, "loftr_coarse.layers.0.").to(dev)
 ws = torch.empty(hip.load().ophip_encoder_bf16_workspace_bytes(1, L3, L2), dtype=torch.uint8, device=dev)
 def run():
-    hip.call("ophip_encoder_layer_bf16", hip.ptr(x3), hip.ptr(x2), hip.ptr(y3), hip.ptr(y2), 1, L3, L2, hip.ptr(w, None), nsplit, 0, hip.ptr(ws, None), hip.stream_handle())
+    hip.call("ophip_encoder_layer_bf16", hip.ptr(x3), hip.ptr(x2), hip.ptr(y3), hip.ptr(y2), 1, L3, L2, hip.ptr(w, None), None, nsplit, 0, 0, 0, hip.ptr(ws, None), hip.stream_handle())
 for _ in range(3): run()
 buf = torch.zeros(1024 * 32, dtype=torch.int64, device=dev)
 hip.call("ophip_debug_stamps", ctypes.c_void_p(buf.data_ptr())); run(); torch.cuda.synchronize(); hip.call("ophip_debug_stamps", None)

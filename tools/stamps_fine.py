@@ -1,6 +1,6 @@
 """Diagnostic: per-phase cycle stamps of fine_refine_bf16 at c2 (prints medians over workgroups). Not part of the product."""
 import sys, numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))
 from onepose_st_amd import hip
 from onepose_st_amd.config import default_config
 from onepose_st_amd.model import OnePosePlus_model

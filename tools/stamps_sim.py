@@ -1,6 +1,6 @@
 """Diagnostic: cycle stamps of sim_stats_bf16 at c2. Not part of the product."""
 import sys, ctypes, numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))
 from onepose_st_amd import hip
 dev = torch.device("cuda:0"); hip.load()
 N, M, wc = 7000, 4800, 80
