@@ -62,10 +62,14 @@ def host_cores() -> int:
     return max(1, min(n, int(os.environ.get("OPHIP_CPU_THREADS", "16"))))
 
 
-def attn_apply_flops(n_tokens: int, C: int = 256, D: int = 32) -> float:
-    """Algorithmic FLOPs of one attn_apply launch: per token q_proj 2C^2 + merge 2C^2 + mlp0 2(2C)(2C) +
-    mlp2 2(2C)C = 16 C^2, plus phi(Q) KV: 2 C D  (SURVEY.md section 8a row a5)."""
-    return float(n_tokens) * (16.0 * C * C + 2.0 * C * D)
+def attn_apply_flops(n_tokens: int, fused_kv: bool, n_layers: int = 6, C: int = 256, D: int = 32) -> float:
+    """Algorithmic FLOPs of one attn_apply launch, averaged over the layers of a frame: per token q_proj 2C^2 + merge 2C^2 +
+    mlp0 2(2C)(2C) + mlp2 2(2C)C = 16 C^2, plus phi(Q) KV: 2 C D.  In the bf16 modes the
+    launches of layers 0..n-2 also carry the next layer's K/V projection and phi(K)^T V (4 C^2 + 2 C D per token)."""
+    per_tok = 16.0 * C * C + 2.0 * C * D
+    if fused_kv:
+        per_tok += (n_layers - 1) / n_layers * (4.0 * C * C + 2.0 * C * D)
+    return float(n_tokens) * per_tok
 
 
 def main():
@@ -219,7 +223,7 @@ def main():
     frames_total = world * args.steps * B
     value = frames_total / dt
     avg_ms = kern_ms / max(launches, 1)
-    flops = attn_apply_flops(B * (n_points + M))
+    flops = attn_apply_flops(B * (n_points + M), fused_kv=args.precision != "f32")
     achieved = flops / (avg_ms * 1e-3) / 1e12 if launches else 0.0
 
     result = {
