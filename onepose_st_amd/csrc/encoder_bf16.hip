@@ -13,10 +13,11 @@
 //   * the MLP hidden layer is produced and consumed in four 128-feature chunks, so the three live tiles (x, msg/merge,
 //     hidden chunk) fit the 160 KiB LDS exactly in split mode (swizzled planes, no padding).
 #include "tile_bf16.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int C = 256, NH = 8, TOK = 64;
+constexpr int C = 256, NH = 8;
 constexpr int ROWB = C * 2;                 // plane row pitch (bytes)
 constexpr int HROWB = 128 * 2;              // hidden-chunk plane row pitch
 constexpr int KB = C / 16, TS = KB * 64;            // K = 256: 16 k-blocks, fragments per tile
@@ -82,10 +83,11 @@ __device__ __forceinline__ void kv_slab_from_planes(WRing<4, 2, NS>& ring, const
     }
 }
 
-template <int NS>
-__global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void kv_reduce_bf16_kernel(KvRedArgs a) {
+template <int NS, int TOK>
+__global__ __launch_bounds__(TOK * 8) OPHIP_WAVES_PER_SIMD(1, 2) void kv_reduce_bf16_kernel(KvRedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PL = NS == 3 ? 2 : 1;
+    constexpr int NT_ = TOK * 8;                     // threads: 4 waves per 32-token tile
     char* XH = smem;
     char* XL = smem + (PL - 1) * TOK * ROWB;
     // 8 waves: wave = 4 * tt + fw owns heads 2 fw, 2 fw + 1 (K and V tiles) of token tile tt -> one partial slab per
@@ -101,11 +103,11 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void kv_reduce_bf16
     const bf16x8* whi = a.w_hi + (size_t)(4 * fw) * TS + lane;
     const bf16x8* wlo = a.w_lo + (size_t)(4 * fw) * TS + lane;
     ring.fill(whi, wlo, TS);                         // weights travel while the activation tile is staged
-    load_rows_to_planes<NS, C, TOK>(XH, XL, a.x[s] + (size_t)b * a.xbs[s], tok0, L, tid, 512);
+    load_rows_to_planes<NS, C, TOK>(XH, XL, a.x[s] + (size_t)b * a.xbs[s], tok0, L, tid, NT_);
     __syncthreads();
     if (tok0 + 32 * tt >= L) return;                 // second half of a ragged last tile: no tokens, no slab
 
-    float* out = a.partial + ((size_t)b * (a.slabs[0] + a.slabs[1]) + (s ? a.slabs[0] : 0) + 2 * lt + tt) * KV_PART_FLOATS;
+    float* out = a.partial + ((size_t)b * (a.slabs[0] + a.slabs[1]) + (s ? a.slabs[0] : 0) + (TOK / 32) * lt + tt) * KV_PART_FLOATS;
     kv_slab_from_planes<NS>(ring, whi, wlo, XH + 32 * tt * ROWB, XL + 32 * tt * ROWB, tok0 + 32 * tt, L, out, fw, lane);
 }
 
@@ -206,10 +208,11 @@ __device__ __forceinline__ void layernorm_featrow(f32x16 (&m)[2][1], const float
         }
 }
 
-template <int NS>
-__global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void attn_apply_bf16_kernel(AttnBArgs a) {
+template <int NS, int TOK>
+__global__ __launch_bounds__(TOK * 8) OPHIP_WAVES_PER_SIMD(2, 2) void attn_apply_bf16_kernel(AttnBArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PL = NS == 3 ? 2 : 1;
+    constexpr int NT_ = TOK * 8;                     // threads: 4 waves per 32-token tile
     constexpr int XB = TOK * ROWB, HB = TOK * HROWB;
     char* XH = smem;
     char* XL = smem + (PL - 1) * XB;
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void attn_apply_bf1
     rq.fill(wq_hi, wq_lo, TS);                       // weights travel while the activation tile is staged
     const int wg = blockIdx.y * gridDim.x + blockIdx.x;
     OPHIP_STAMP(a.stamps, wg, 0);
-    load_rows_to_planes<NS, C, TOK>(XH, XL, xg, tok0, L, tid, 512);
+    load_rows_to_planes<NS, C, TOK>(XH, XL, xg, tok0, L, tid, NT_);
     __syncthreads();
     OPHIP_STAMP(a.stamps, wg, 1);
 
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void attn_apply_bf1
     // planes of the OUTPUT tile for the fused kv_reduce: behind the f32 stage (= the Y region in split mode)
     char* KH = smem + TOK * C * 4;
     char* KL = KH + (PL - 1) * XB;
-    for (int i = tid; i < TOK * (C / 4); i += 512) {
+    for (int i = tid; i < TOK * (C / 4); i += NT_) {
         const int row = i / (C / 4), ch = i % (C / 4);
         f32x4 yv = {0.f, 0.f, 0.f, 0.f};
         if (tok0 + row < L) {
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void attn_apply_bf1
         // ---- kv_reduce of the next layer on the tile that is still on chip (saves a launch and a re-read of the streams) ----
         __syncthreads();
         if (tok0 + 32 * tt < L) {
-            float* out = a.npartial + ((size_t)b * (a.slabs[0] + a.slabs[1]) + (s ? a.slabs[0] : 0) + 2 * lt + tt) * KV_PART_FLOATS;
+            float* out = a.npartial + ((size_t)b * (a.slabs[0] + a.slabs[1]) + (s ? a.slabs[0] : 0) + (TOK / 32) * lt + tt) * KV_PART_FLOATS;
             kv_slab_from_planes<NS>(rkv, nhi, nlo, KH + 32 * tt * ROWB, KL + 32 * tt * ROWB, tok0 + 32 * tt, L, out, fw, lane);
         }
     }
@@ -401,6 +404,11 @@ extern "C" int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, floa
     if (slot != 0 && slot != 1) return ophip_bad_arg(__func__, "slot must be 0 or 1");
     if (x3d == y3d || x2d == y2d) return ophip_bad_arg(__func__, "in-place layer is not supported (cross layers read the pre-update streams)");
     hipStream_t stream = (hipStream_t)stream_;
+    // tile size: 32-token workgroups (4 waves, 80 KiB LDS in split mode) -> two INDEPENDENT workgroups per CU whose
+    // barrier / epilogue gaps interleave: measured 69 vs 77 us per launch at c2 against one 64-token / 8-wave workgroup
+    // (which fetches the weights half as often but runs its 8 waves in barrier lock-step).  OPHIP_ENC_TOK=64 selects the latter.
+    static const int tok_env = [] { const char* e = getenv("OPHIP_ENC_TOK"); return e ? atoi(e) : 0; }();
+    const int TOK = tok_env == 64 ? 64 : 32;
     const int t3 = (L3d + TOK - 1) / TOK, t2 = (L2d + TOK - 1) / TOK;
     const int s3 = (L3d + 31) / 32, s2 = (L2d + 31) / 32;
     const size_t part_floats = (size_t)B * (s3 + s2) * KV_PART_FLOATS;
@@ -422,14 +430,18 @@ extern "C" int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, floa
         ka.w_hi = w_hi + C * C / 8; ka.w_lo = w_lo + C * C / 8;
         ka.partial = partial;
         const size_t lds_kv = (size_t)PL * TOK * ROWB;
-        static bool attr_kv[2] = {false, false};
-        if (nsplit == 3) {
-            if (!attr_kv[1]) { if (int rc = set_lds(kv_reduce_bf16_kernel<3>, lds_kv, "hipFuncSetAttribute(kv_reduce_bf16)")) return rc; attr_kv[1] = true; }
-            OPHIP_LAUNCH("kv_reduce", stream, kv_reduce_bf16_kernel<3>, dim3(t3 + t2, B), dim3(512), lds_kv, stream, ka);
-        } else {
-            if (!attr_kv[0]) { if (int rc = set_lds(kv_reduce_bf16_kernel<1>, lds_kv, "hipFuncSetAttribute(kv_reduce_bf16)")) return rc; attr_kv[0] = true; }
-            OPHIP_LAUNCH("kv_reduce", stream, kv_reduce_bf16_kernel<1>, dim3(t3 + t2, B), dim3(512), lds_kv, stream, ka);
+        static bool attr_kv[4] = {false, false, false, false};
+        const int vi = (nsplit == 3 ? 2 : 0) + (TOK == 64 ? 1 : 0);
+#define OPHIP_KV_CASE(NS_, TK_)                                                                                                  \
+        {                                                                                                                        \
+            if (!attr_kv[vi]) { if (int rc = set_lds(kv_reduce_bf16_kernel<NS_, TK_>, lds_kv, "hipFuncSetAttribute(kv_reduce_bf16)")) return rc; attr_kv[vi] = true; } \
+            OPHIP_LAUNCH("kv_reduce", stream, (kv_reduce_bf16_kernel<NS_, TK_>), dim3(t3 + t2, B), dim3(TK_ * 8), lds_kv, stream, ka);  \
         }
+        if (nsplit == 3 && TOK == 64) OPHIP_KV_CASE(3, 64)
+        else if (nsplit == 3) OPHIP_KV_CASE(3, 32)
+        else if (TOK == 64) OPHIP_KV_CASE(1, 64)
+        else OPHIP_KV_CASE(1, 32)
+#undef OPHIP_KV_CASE
         OPHIP_CHECK_LAUNCH();
     }
 
@@ -459,14 +471,18 @@ extern "C" int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, floa
     size_t lds_at = (size_t)PL * (2 * TOK * ROWB + TOK * HROWB);
     const size_t lds_fuse = (size_t)TOK * C * 4 + (size_t)PL * TOK * ROWB;
     if (lds_fuse > lds_at) lds_at = lds_fuse;
-    static bool attr_at[2] = {false, false};
-    if (nsplit == 3) {
-        if (!attr_at[1]) { if (int rc = set_lds(attn_apply_bf16_kernel<3>, lds_at, "hipFuncSetAttribute(attn_apply_bf16)")) return rc; attr_at[1] = true; }
-        OPHIP_LAUNCH("attn_apply", stream, attn_apply_bf16_kernel<3>, dim3(t3 + t2, B), dim3(512), lds_at, stream, aa);
-    } else {
-        if (!attr_at[0]) { if (int rc = set_lds(attn_apply_bf16_kernel<1>, lds_at, "hipFuncSetAttribute(attn_apply_bf16)")) return rc; attr_at[0] = true; }
-        OPHIP_LAUNCH("attn_apply", stream, attn_apply_bf16_kernel<1>, dim3(t3 + t2, B), dim3(512), lds_at, stream, aa);
+    static bool attr_at[4] = {false, false, false, false};
+    const int wi = (nsplit == 3 ? 2 : 0) + (TOK == 64 ? 1 : 0);
+#define OPHIP_AT_CASE(NS_, TK_)                                                                                                  \
+    {                                                                                                                            \
+        if (!attr_at[wi]) { if (int rc = set_lds(attn_apply_bf16_kernel<NS_, TK_>, lds_at, "hipFuncSetAttribute(attn_apply_bf16)")) return rc; attr_at[wi] = true; } \
+        OPHIP_LAUNCH("attn_apply", stream, (attn_apply_bf16_kernel<NS_, TK_>), dim3(t3 + t2, B), dim3(TK_ * 8), lds_at, stream, aa);    \
     }
+    if (nsplit == 3 && TOK == 64) OPHIP_AT_CASE(3, 64)
+    else if (nsplit == 3) OPHIP_AT_CASE(3, 32)
+    else if (TOK == 64) OPHIP_AT_CASE(1, 64)
+    else OPHIP_AT_CASE(1, 32)
+#undef OPHIP_AT_CASE
     OPHIP_CHECK_LAUNCH();
     return 0;
 }

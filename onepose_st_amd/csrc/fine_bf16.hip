@@ -15,10 +15,11 @@
 //   * a token attends to exactly one source set, so phi(Q) is masked per set on its token (lane) axis and both sets
 //     accumulate into one numerator / one denominator tile.
 #include "tile_bf16.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int CF = 128, TOK = 64, WIN = 25, TOK3D = 25;
+constexpr int CF = 128, WIN = 25, TOK3D = 25;
 constexpr int ROWB = CF * 2;              // X / Y plane pitch (256 B, 16 chunks)
 constexpr int HROWB = 2 * CF * 2;         // hidden plane pitch: 256 features (512 B)
 constexpr int KB = CF / 16, TS = KB * 64;              // K = 128
@@ -78,11 +79,13 @@ __device__ __forceinline__ void layernorm_featrow128(f32x16& m, const float* __r
     }
 }
 
-template <int NS>
-__global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void fine_refine_bf16_kernel(FineBArgs p) {
+// NM = matches per workgroup (1: 4 waves, 64 KiB LDS in split mode, two independent workgroups per CU; 2: 8 waves)
+template <int NS, int NM>
+__global__ __launch_bounds__(NM * 256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_refine_bf16_kernel(FineBArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PL = NS == 3 ? 2 : 1;
-    constexpr int XB = TOK * ROWB, HB = TOK * HROWB;   // 16 KiB / 32 KiB per plane
+    constexpr int TOK = 32 * NM, NT_ = 256 * NM;
+    constexpr int XB = TOK * ROWB, HB = TOK * HROWB;   // per plane
     char* XH = smem;
     char* XL = smem + (PL - 1) * XB;
     char* YH = smem + PL * XB;
@@ -93,10 +96,10 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void fine_refine_bf
     // LDS total: split 32 + 32 + 64 = 128 KiB, plain 64 KiB.
     char* stage = HH;
     float* scratch = reinterpret_cast<float*>(HH);
-    const int k0 = 2 * blockIdx.x;
+    const int k0 = NM * blockIdx.x;
     const int total = *p.count;
     if (k0 >= total) return;
-    // 8 waves: wave = 4 * tt + ft owns feature tile ft (features 32 ft .. 32 ft + 31) of match / token tile tt
+    // waves: wave = 4 * tt + ft owns feature tile ft (features 32 ft .. 32 ft + 31) of match / token tile tt
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ft = wave & 3, tt = wave >> 2;
     const int r = lane & 31, h = lane >> 5;
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void fine_refine_bf
     // ---- gather both matches into the f32 staging image --------------------------------------------
     // every load of both matches is issued before the first LDS write, so their latencies overlap
     // (named scalars + selects: a runtime-indexed array would live in scratch)
-    const bool live0 = k0 < total, live1 = k0 + 1 < total;
+    const bool live0 = k0 < total, live1 = NM > 1 && k0 + 1 < total;
     const int b0 = (int)p.b_ids[k0], i30 = (int)p.i_ids[k0], j0 = (int)p.j_ids[k0];
     const int b1 = live1 ? (int)p.b_ids[k0 + 1] : 0, i31 = live1 ? (int)p.i_ids[k0 + 1] : 0, j1 = live1 ? (int)p.j_ids[k0 + 1] : 0;
     const int cy0 = p.stride * (j0 / p.wc), cx0 = p.stride * (j0 % p.wc);
@@ -116,13 +119,13 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void fine_refine_bf
 #define MCY(mi) ((mi) ? cy1 : cy0)
 #define MCX(mi) ((mi) ? cx1 : cx0)
     if (p.fs_c == 1) {                   // channels-last: 512 B contiguous per pixel; 2 x 25 x 128 elements / 512 threads
-        constexpr int PER = (2 * WIN * CF + 511) / 512;
+        constexpr int PER = (NM * WIN * CF + NT_ - 1) / NT_;
         float v[PER];
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const int e = tid + 512 * u;
+            const int e = tid + NT_ * u;
             v[u] = 0.f;
-            if (e < 2 * WIN * CF) {
+            if (e < NM * WIN * CF) {
                 const int mi = e / (WIN * CF), e2 = e % (WIN * CF), rr = e2 >> 7, c = e2 & 127;
                 const int y = MCY(mi) + rr / 5 - 2, x = MCX(mi) + rr % 5 - 2;
                 if (MLIVE(mi) && y >= 0 && y < p.hf && x >= 0 && x < p.wf)
@@ -131,18 +134,18 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void fine_refine_bf
         }
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const int e = tid + 512 * u;
-            if (e < 2 * WIN * CF) {
+            const int e = tid + NT_ * u;
+            if (e < NM * WIN * CF) {
                 const int mi = e / (WIN * CF), e2 = e % (WIN * CF), rr = e2 >> 7, c = e2 & 127;
                 *reinterpret_cast<float*>(stage + stage_off(32 * mi + rr, c >> 2) + 4 * (c & 3)) = v[u];
             }
         }
     } else {                             // NCHW: one (match, channel, window row) run of 5 consecutive x per slot
-        constexpr int RUNS = 2 * CF * 5, PER = (RUNS + 511) / 512;
+        constexpr int RUNS = NM * CF * 5, PER = (RUNS + NT_ - 1) / NT_;
         float v[PER][5];
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const int q = tid + 512 * u;
+            const int q = tid + NT_ * u;
             const int mi = q / (CF * 5), q2 = q % (CF * 5), c = q2 / 5, ky = q2 % 5;
             const bool ok = q < RUNS && MLIVE(mi);
             const int m2 = mi < 2 ? mi : 0;
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void fine_refine_bf
         }
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const int q = tid + 512 * u;
+            const int q = tid + NT_ * u;
             if (q < RUNS) {
                 const int mi = q / (CF * 5), q2 = q % (CF * 5), c = q2 / 5, ky = q2 % 5;
 #pragma unroll
@@ -166,12 +169,12 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void fine_refine_bf
             }
         }
     }
-    if (tid < 2 * CF) {                  // the 3D fine descriptor (row 25) of both matches
+    if (tid < NM * CF) {                 // the 3D fine descriptor (row 25) of every match
         const int mi = tid >> 7, c = tid & 127;
         const float v = MLIVE(mi) ? p.desc_f[(size_t)MB(mi) * p.ds_b + (size_t)c * p.ds_c + MI3(mi)] : 0.f;
         *reinterpret_cast<float*>(stage + stage_off(32 * mi + TOK3D, c >> 2) + 4 * (c & 3)) = v;
     }
-    for (int e = tid; e < 2 * 6 * CF; e += 512) {      // padding rows 26..31
+    for (int e = tid; e < NM * 6 * CF; e += NT_) {      // padding rows 26..31
         const int mi = e / (6 * CF), e2 = e % (6 * CF), rr = 26 + (e2 >> 7), c = e2 & 127;
         *reinterpret_cast<float*>(stage + stage_off(32 * mi + rr, c >> 2) + 4 * (c & 3)) = 0.f;
     }
@@ -350,10 +353,10 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void fine_refine_bf
     }
     __syncthreads();
     if (p.dbg_win) {
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < NM; ++mi) {
             const int k = k0 + mi;
             if (k >= total) break;
-            for (int e = tid; e < WIN * CF; e += 512) {
+            for (int e = tid; e < WIN * CF; e += NT_) {
                 const int rr = e >> 7, c = e & 127;
                 p.dbg_win[(size_t)k * WIN * CF + e] = *reinterpret_cast<const float*>(stage + stage_off(32 * mi + rr, c >> 2) + 4 * (c & 3));
             }
@@ -424,16 +427,23 @@ extern "C" int ophip_fine_refine_bf16(const float* feat_f, long long fs_b, long 
     a.expec_f = expec_f; a.mkq_f = mkpts_f; a.dbg_win = dbg_win; a.dbg_f3 = dbg_f3;
     a.stamps = ophip_stamp_buffer();
     hipStream_t stream = (hipStream_t)stream_;
-    const int grid = (max_matches + 1) / 2;
-    const size_t lds = nsplit == 3 ? (size_t)(32 + 32 + 64) * 1024 : (size_t)(16 + 16 + 32) * 1024;
-    static bool attr[2] = {false, false};
-    if (nsplit == 3) {
-        if (!attr[1]) { if (int rc = set_lds(fine_refine_bf16_kernel<3>, lds, "hipFuncSetAttribute(fine_refine_bf16)")) return rc; attr[1] = true; }
-        OPHIP_LAUNCH("fine_refine", stream, fine_refine_bf16_kernel<3>, dim3(grid), dim3(512), lds, stream, a);
-    } else {
-        if (!attr[0]) { if (int rc = set_lds(fine_refine_bf16_kernel<1>, lds, "hipFuncSetAttribute(fine_refine_bf16)")) return rc; attr[0] = true; }
-        OPHIP_LAUNCH("fine_refine", stream, fine_refine_bf16_kernel<1>, dim3(grid), dim3(512), lds, stream, a);
+    // one match per 4-wave workgroup (two independent workgroups per CU) unless OPHIP_FINE_NM=2 asks for the 8-wave pairing
+    static const int nm_env = [] { const char* e = getenv("OPHIP_FINE_NM"); return e ? atoi(e) : 0; }();
+    const int NM = nm_env == 2 ? 2 : 1;
+    const int grid = (max_matches + NM - 1) / NM;
+    const size_t lds = (size_t)NM * (nsplit == 3 ? (16 + 16 + 32) : (8 + 8 + 16)) * 1024;
+    static bool attr[4] = {false, false, false, false};
+    const int vi = (nsplit == 3 ? 2 : 0) + (NM - 1);
+#define OPHIP_FINE_CASE(NS_, NM_)                                                                                               \
+    {                                                                                                                           \
+        if (!attr[vi]) { if (int rc = set_lds(fine_refine_bf16_kernel<NS_, NM_>, lds, "hipFuncSetAttribute(fine_refine_bf16)")) return rc; attr[vi] = true; } \
+        OPHIP_LAUNCH("fine_refine", stream, (fine_refine_bf16_kernel<NS_, NM_>), dim3(grid), dim3(NM_ * 256), lds, stream, a);  \
     }
+    if (nsplit == 3 && NM == 2) OPHIP_FINE_CASE(3, 2)
+    else if (nsplit == 3) OPHIP_FINE_CASE(3, 1)
+    else if (NM == 2) OPHIP_FINE_CASE(1, 2)
+    else OPHIP_FINE_CASE(1, 1)
+#undef OPHIP_FINE_CASE
     OPHIP_CHECK_LAUNCH();
     return 0;
 }
