@@ -225,9 +225,10 @@ def main():
     traffic = None
     try:
         pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))["kernels"]
-        key = {"bf16x3": "attn_apply_bf16_kernel<3>", "bf16": "attn_apply_bf16_kernel<1>", "f32": "attn_apply_kernel"}[args.precision]
-        if key in pmc and B == 1 and args.workload == "c2":
-            traffic = pmc[key]["hbm_bytes_per_launch"]
+        stem = {"bf16x3": "attn_apply_bf16_kernel<3", "bf16": "attn_apply_bf16_kernel<1", "f32": "attn_apply_kernel"}[args.precision]
+        hits = [v for k, v in pmc.items() if k.startswith(stem)]
+        if hits and B == 1 and args.workload == "c2":
+            traffic = hits[0]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
 
@@ -264,7 +265,7 @@ def main():
             "parallelism": f"frames sharded over {world} rank(s), one RCCL broadcast of weights + 3D block ({bcast_bytes} B)",
         },
         "roofline": {
-            "kernel": {"bf16x3": "attn_apply_bf16_kernel<3>", "bf16": "attn_apply_bf16_kernel<1>", "f32": "attn_apply_kernel"}[args.precision]
+            "kernel": {"bf16x3": "attn_apply_bf16_kernel<3, 32>", "bf16": "attn_apply_bf16_kernel<1, 32>", "f32": "attn_apply_kernel"}[args.precision]
                       + " (fused Q-proj + linear attention + merge + MLP + 2 LayerNorms" + (" + next layer's K/V reduce)" if args.precision != "f32" else ")"),
             "bound": "mfma",
             "achieved": achieved,

@@ -81,13 +81,16 @@ int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, float* y3d, flo
  * conf [B][N][M] receives the dual-softmax confidence matrix (data["conf_matrix"]).
  * Outputs (capacity B*N entries each, ascending (b, i)): b_ids/i_ids/j_ids int64, mconf, mkpts3d [.][3]
  * (= keypoints3d[b, i]), mkpts_c [.][2] (= (j % wc, j / wc) * scale); *count = K.
+ * m_bids (int64, = b_ids) and gt_mask (one byte per match, mconf == 0) are the two remaining keys of the reference's
+ * coarse_matches dict (coarse_matching.py:228-240); either may be NULL.
  * temperature is passed as double so that (float)(temperature + 1e-4) matches the reference's scalar.
  * nsplit selects the arithmetic of the similarity GEMM: 0 exact f32 MFMA, 1 bf16, 3 split-bf16. */
 size_t ophip_coarse_workspace_floats(int B, int N, int M);
 int ophip_coarse_match(const float* feat3d, const float* feat2d, const float* keypoints3d, long long kpts_bstride,
                        int B, int N, int M, int wc, double temperature, float thr, int border_rm, float scale,
                        float* conf, float* workspace, long long* b_ids, long long* i_ids, long long* j_ids,
-                       float* mconf, float* mkpts3d, float* mkpts_c, int* count, int nsplit, void* stream);
+                       float* mconf, float* mkpts3d, float* mkpts_c, long long* m_bids, unsigned char* gt_mask,
+                       int* count, int nsplit, void* stream);
 
 /* a9 + a10 + a11 -- FinePreprocess + fine LocalFeatureTransformer (d_model 128) + FineMatching
  * (loftr_module/fine_preprocess.py:32-55, loftr_module/transformer.py:133-171, utils/fine_matching.py:28-110).

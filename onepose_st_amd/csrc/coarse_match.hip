@@ -487,11 +487,19 @@ struct SelectArgs {
     float thr, scale;
     long long* b_ids; long long* i_ids; long long* j_ids;
     float* mconf; float* mk3d; float* mkq;
+    long long* m_bids;          // optional second copy of b_ids (the reference's 'm_bids')
+    unsigned char* gt_mask;     // optional mconf == 0 flags (the reference's 'gt_mask')
     int* count;
 };
 
+// One workgroup compacts the surviving rows in (b, i) order.  A thread owns SEL_IT rows of a chunk of 1024 * SEL_IT rows:
+// all its row-best records are loaded first, then all its column maxima (independent gathers, one memory round trip each
+// instead of one per 1024 rows), then one scan over the SEL_IT x 16 wave counts places every match.
+constexpr int SEL_IT = 8;
+
 __global__ __launch_bounds__(1024) void select_kernel(SelectArgs p) {
-    __shared__ int wcount[16];
+    __shared__ int wcount[SEL_IT * 16];
+    __shared__ int wpref[SEL_IT * 16 + 1];
     __shared__ int base_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) base_s = 0;
@@ -499,54 +507,79 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs p) {
     for (int b = 0; b < p.B; ++b) {
         const float* conf = p.conf + (size_t)b * p.N * p.M;
         const float* cmx = p.colmax + (size_t)b * p.M;
-        for (int ib = 0; ib < p.N; ib += 1024) {
-            const int i = ib + tid;
-            bool ok = false;
-            int j = 0;
-            float v = 0.f;
-            if (i < p.N) {
-                int c = 0;
-                v = -1.f; j = 0x7fffffff;
-                for (int sp = 0; sp < p.nspan; ++sp) {
-                    const float* q = p.rowbest + (((size_t)b * p.nspan + sp) * p.N + i) * 3;
-                    const float v2 = q[0];
-                    const int j2 = __float_as_int(q[1]), c2 = __float_as_int(q[2]);
-                    if (v2 > v) { v = v2; j = j2; c = c2; }
-                    else if (v2 == v) { j = min(j, j2); c += c2; }
-                }
-                auto passes = [&](int jj) {
-                    return (jj / p.wc >= p.border) && (jj % p.wc >= p.border) && (v == cmx[jj]);
-                };
-                if (v > p.thr) {
-                    ok = passes(j);
-                    if (!ok && c > 1) {
-                        // exact tie of the row maximum: the reference takes the first j whose mask is true
-                        const float* row = conf + (size_t)i * p.M;
-                        for (int jj = j + 1; jj < p.M; ++jj)
-                            if (row[jj] == v && passes(jj)) { j = jj; ok = true; break; }
+        const float* kpb = p.kpts + (size_t)b * p.kpts_bs;
+        for (int ib = 0; ib < p.N; ib += 1024 * SEL_IT) {
+            float v[SEL_IT], cm[SEL_IT], kx[SEL_IT], ky[SEL_IT], kz[SEL_IT];
+            int j[SEL_IT], c[SEL_IT];
+            bool ok[SEL_IT];
+#pragma unroll
+            for (int it = 0; it < SEL_IT; ++it) {
+                const int i = ib + it * 1024 + tid;
+                v[it] = -1.f; j[it] = 0x7fffffff; c[it] = 0;
+                if (i < p.N) {
+                    for (int sp = 0; sp < p.nspan; ++sp) {
+                        const float* q = p.rowbest + (((size_t)b * p.nspan + sp) * p.N + i) * 3;
+                        const float v2 = q[0];
+                        const int j2 = __float_as_int(q[1]), c2 = __float_as_int(q[2]);
+                        if (v2 > v[it]) { v[it] = v2; j[it] = j2; c[it] = c2; }
+                        else if (v2 == v[it]) { j[it] = min(j[it], j2); c[it] += c2; }
                     }
                 }
             }
-            const unsigned long long mask = __ballot(ok);
-            const int wpre = __popcll(mask & ((1ull << lane) - 1ull));
-            if (lane == 0) wcount[wave] = __popcll(mask);
-            __syncthreads();
-            int off = base_s, total = 0;
-            for (int w = 0; w < 16; ++w) {
-                if (w < wave) off += wcount[w];
-                total += wcount[w];
+#pragma unroll
+            for (int it = 0; it < SEL_IT; ++it) {
+                const int i = ib + it * 1024 + tid;
+                const bool live = i < p.N && v[it] > p.thr;
+                cm[it] = live ? cmx[j[it]] : 0.f;
+                kx[it] = live ? kpb[(size_t)i * 3] : 0.f;
+                ky[it] = live ? kpb[(size_t)i * 3 + 1] : 0.f;
+                kz[it] = live ? kpb[(size_t)i * 3 + 2] : 0.f;
             }
-            if (ok) {
-                const int pos = off + wpre;
-                p.b_ids[pos] = b; p.i_ids[pos] = i; p.j_ids[pos] = j;
-                p.mconf[pos] = v;
-                const float* kp = p.kpts + (size_t)b * p.kpts_bs + (size_t)i * 3;
-                p.mk3d[3 * pos] = kp[0]; p.mk3d[3 * pos + 1] = kp[1]; p.mk3d[3 * pos + 2] = kp[2];
-                p.mkq[2 * pos] = (float)(j % p.wc) * p.scale;
-                p.mkq[2 * pos + 1] = (float)(j / p.wc) * p.scale;
+#pragma unroll
+            for (int it = 0; it < SEL_IT; ++it) {
+                const int i = ib + it * 1024 + tid;
+                const float vv = v[it];
+                auto inside = [&](int jj) { return (jj / p.wc >= p.border) && (jj % p.wc >= p.border); };
+                bool o = false;
+                if (i < p.N && vv > p.thr) {
+                    o = inside(j[it]) && vv == cm[it];
+                    if (!o && c[it] > 1) {
+                        // exact tie of the row maximum: the reference takes the first j whose mask is true
+                        const float* row = conf + (size_t)i * p.M;
+                        for (int jj = j[it] + 1; jj < p.M; ++jj)
+                            if (row[jj] == vv && inside(jj) && vv == cmx[jj]) { j[it] = jj; o = true; break; }
+                    }
+                }
+                ok[it] = o;
+                const unsigned long long mask = __ballot(o);
+                if (lane == 0) wcount[it * 16 + wave] = __popcll(mask);
             }
             __syncthreads();
-            if (tid == 0) base_s += total;
+            if (tid < SEL_IT * 16) {
+                int acc = 0;
+                for (int u = 0; u < tid; ++u) acc += wcount[u];
+                wpref[tid] = acc;
+                if (tid == SEL_IT * 16 - 1) wpref[SEL_IT * 16] = acc + wcount[tid];
+            }
+            __syncthreads();
+            const int base = base_s;
+#pragma unroll
+            for (int it = 0; it < SEL_IT; ++it) {
+                const unsigned long long mask = __ballot(ok[it]);
+                if (ok[it]) {
+                    const int i = ib + it * 1024 + tid;
+                    const int pos = base + wpref[it * 16 + wave] + __popcll(mask & ((1ull << lane) - 1ull));
+                    p.b_ids[pos] = b; p.i_ids[pos] = i; p.j_ids[pos] = j[it];
+                    p.mconf[pos] = v[it];
+                    p.mk3d[3 * pos] = kx[it]; p.mk3d[3 * pos + 1] = ky[it]; p.mk3d[3 * pos + 2] = kz[it];
+                    p.mkq[2 * pos] = (float)(j[it] % p.wc) * p.scale;
+                    p.mkq[2 * pos + 1] = (float)(j[it] / p.wc) * p.scale;
+                    if (p.m_bids) p.m_bids[pos] = b;
+                    if (p.gt_mask) p.gt_mask[pos] = v[it] == 0.f ? 1 : 0;
+                }
+            }
+            __syncthreads();
+            if (tid == 0) base_s = base + wpref[SEL_IT * 16];
             __syncthreads();
         }
     }
@@ -572,7 +605,8 @@ extern "C" size_t ophip_coarse_workspace_floats(int B, int N, int M) {
 extern "C" int ophip_coarse_match(const float* feat3d, const float* feat2d, const float* keypoints3d, long long kpts_bstride,
                                   int B, int N, int M, int wc, double temperature, float thr, int border_rm, float scale,
                                   float* conf, float* workspace, long long* b_ids, long long* i_ids, long long* j_ids,
-                                  float* mconf, float* mkpts3d, float* mkpts_c, int* count, int nsplit, void* stream_) {
+                                  float* mconf, float* mkpts3d, float* mkpts_c, long long* m_bids, unsigned char* gt_mask,
+                                  int* count, int nsplit, void* stream_) {
     if (!feat3d || !feat2d || !keypoints3d || !conf || !workspace || !b_ids || !i_ids || !j_ids || !mconf || !mkpts3d || !mkpts_c || !count)
         return ophip_bad_arg(__func__, "null pointer");
     if (B < 1 || N < 1 || M < 1 || wc < 1 || M % wc != 0) return ophip_bad_arg(__func__, "bad sizes (need M == hc * wc)");
@@ -617,7 +651,7 @@ extern "C" int ophip_coarse_match(const float* feat3d, const float* feat2d, cons
     else OPHIP_LAUNCH("conf", stream, (conf_kernel<false, false>), dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
     OPHIP_CHECK_LAUNCH();
     SelectArgs se{conf, rowbest, colmax, keypoints3d, kpts_bstride, B, N, M, nspan, wc, border_rm, thr, scale,
-                  b_ids, i_ids, j_ids, mconf, mkpts3d, mkpts_c, count};
+                  b_ids, i_ids, j_ids, mconf, mkpts3d, mkpts_c, m_bids, gt_mask, count};
     OPHIP_LAUNCH("select", stream, select_kernel, dim3(1), dim3(1024), 0, stream, se);
     OPHIP_CHECK_LAUNCH();
     return 0;

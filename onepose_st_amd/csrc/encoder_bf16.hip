@@ -2,9 +2,11 @@
 // (tile_bf16.h).  Same three launches per layer and the same mathematics as csrc/encoder.hip (reference:
 // loftr_module/transformer.py:65-94,146-159, linear_attention.py:29-61); what changes is the mapping to the machine:
 //
-//   * a workgroup owns 64 tokens (two 32-token MFMA tiles) and runs 8 waves: wave (tt, fw) = feature group fw of token
-//     tile tt, so each SIMD holds two waves whose dependent chains cover each other; one launch at c2 is 185 workgroups
-//     = one resident wave of work on 256 CUs; weight rings are filled one phase ahead (tile_bf16.h WRing);
+//   * an attn_apply workgroup is 4 waves (one per SIMD); wave fw owns feature group fw (64 features = heads 2 fw,
+//     2 fw + 1) of the TT 32-token MFMA tiles of the workgroup, so a packed weight fragment pulled from L2 feeds TT
+//     matrix instructions.  TT = 1 by default: two independent 32-token workgroups per CU whose barrier / epilogue
+//     gaps interleave (c2: 369 workgroups, all resident at once).  Weight rings are filled one phase ahead and the
+//     activation fragments are read from LDS one k-block ahead (tile_bf16.h);
 //   * operands swap roles in attn_apply: A = packed weights, B = activations, so an accumulator holds
 //     D[feature][token] -- four consecutive features of one token per lane and register quad.  Epilogues therefore
 //     write 8-byte packed bf16 quads into the [token][feature] LDS planes, LayerNorm reduces over registers (plus a
@@ -37,48 +39,57 @@ struct KvRedArgs {
     float* partial;                 // [B][slabs0 + slabs1][KV_PART_FLOATS]
 };
 
-// K, V projection of one 32-token tile (rows 32 tt .. of the planes) for heads 2 fw, 2 fw + 1, then the tile's
-// KV = phi(K)^T V / Ksum partial slab straight from the accumulators.  `ring` must be filled from whi / wlo.
-template <int NS>
+// K, V projection of TT 32-token tiles (rows 0 .. 32 TT - 1 of the planes) for heads 2 fw, 2 fw + 1, then each tile's
+// KV = phi(K)^T V / Ksum partial slab straight from the accumulators (slab tt at out + tt * KV_PART_FLOATS; tiles that
+// start beyond L write nothing).  `ring` must be filled from whi / wlo.
+template <int NS, int TT>
 __device__ __forceinline__ void kv_slab_from_planes(WRing<4, 2, NS>& ring, const bf16x8* whi, const bf16x8* wlo, const char* xh, const char* xl,
                                                     int tok_base, int L, float* out, int fw, int lane) {
     const int r = lane & 31, h = lane >> 5;
     // D[token][feature]: t = 0,1 -> K of heads 2fw, 2fw+1;  t = 2,3 -> V of the same heads
-    f32x16 acc[4][1];
+    f32x16 acc[4][TT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t][0] = zero16();
-    gemm_bf16_ring<4, 1, NS, false, KB, 2>(acc, ring, whi, wlo, TS, xh, xl, ROWB, 0, lane);
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) acc[t][tt] = zero16();
+    gemm_bf16_ring<4, TT, NS, false, KB, 2>(acc, ring, whi, wlo, TS, xh, xl, ROWB, 0, lane);
     const float inv_len = 1.0f / (float)L;
     const bf16x8 zeros = zero_bf8();
     bf16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
-    auto f_k = [&](int reg, float v) { return tok_base + acc_row(reg, h) < L ? elu_plus_one_fast(v) : 0.f; };   // padded tokens drop out
-    auto f_v = [&](int reg, float v) { return v * inv_len; };                                                 // values / v_length
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        f32x16 kv = zero16(), ks = zero16();
+    for (int tt = 0; tt < TT; ++tt) {
+        const int tb = tok_base + 32 * tt;
+        if (tb >= L) break;                                                                                   // wave-uniform
+        auto f_k = [&](int reg, float v) { return tb + acc_row(reg, h) < L ? elu_plus_one_fast(v) : 0.f; };   // padded tokens drop out
+        auto f_v = [&](int reg, float v) { return v * inv_len; };                                             // values / v_length
+        float* outt = out + (size_t)tt * KV_PART_FLOATS;
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            bf16x8 khi, klo, vhi, vlo;
-            acc_frag_map<NS>(acc[t][0], st, f_k, khi, klo);
-            acc_frag_map<NS>(acc[2 + t][0], st, f_v, vhi, vlo);
-            kv = mma_bf16<NS>(khi, klo, vhi, vlo, kv);        // KV[d][v] += sum_tok phi(K)[tok][d] V[tok][v]
-            ks = mma_bf16<NS>(khi, klo, ones, zeros, ks);     // Ksum[d] replicated over v
-        }
-        const int head = 2 * fw + t;
+        for (int t = 0; t < 2; ++t) {
+            f32x16 kv = zero16(), ks = zero16();
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            float* o = out + ((size_t)(head * 2 + st) * 64 + lane) * 8;
-            f32x4 v0 = {kv[8 * st], kv[8 * st + 1], kv[8 * st + 2], kv[8 * st + 3]};
-            f32x4 v1 = {kv[8 * st + 4], kv[8 * st + 5], kv[8 * st + 6], kv[8 * st + 7]};
-            *reinterpret_cast<f32x4*>(o) = v0;
-            *reinterpret_cast<f32x4*>(o + 4) = v1;
-        }
-        if (r == 0) {
-            float* o = out + NH * 2 * 64 * 8 + head * 32 + h * 16;
+            for (int st = 0; st < 2; ++st) {
+                bf16x8 khi, klo, vhi, vlo;
+                acc_frag_map<NS>(acc[t][tt], st, f_k, khi, klo);
+                acc_frag_map<NS>(acc[2 + t][tt], st, f_v, vhi, vlo);
+                kv = mma_bf16<NS>(khi, klo, vhi, vlo, kv);        // KV[d][v] += sum_tok phi(K)[tok][d] V[tok][v]
+                ks = mma_bf16<NS>(khi, klo, ones, zeros, ks);     // Ksum[d] replicated over v
+            }
+            const int head = 2 * fw + t;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) o[reg] = ks[reg];
+            for (int st = 0; st < 2; ++st) {
+                float* o = outt + ((size_t)(head * 2 + st) * 64 + lane) * 8;
+                f32x4 v0 = {kv[8 * st], kv[8 * st + 1], kv[8 * st + 2], kv[8 * st + 3]};
+                f32x4 v1 = {kv[8 * st + 4], kv[8 * st + 5], kv[8 * st + 6], kv[8 * st + 7]};
+                *reinterpret_cast<f32x4*>(o) = v0;
+                *reinterpret_cast<f32x4*>(o + 4) = v1;
+            }
+            if (r == 0) {
+                float* o = outt + NH * 2 * 64 * 8 + head * 32 + h * 16;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) o[reg] = ks[reg];
+            }
         }
     }
 }
@@ -90,11 +101,9 @@ __global__ __launch_bounds__(TOK * 8) OPHIP_WAVES_PER_SIMD(1, 2) void kv_reduce_
     constexpr int NT_ = TOK * 8;                     // threads: 4 waves per 32-token tile
     char* XH = smem;
     char* XL = smem + (PL - 1) * TOK * ROWB;
-    // 8 waves: wave = 4 * tt + fw owns heads 2 fw, 2 fw + 1 (K and V tiles) of token tile tt -> one partial slab per
-    // 32 tokens; two waves per SIMD cover each other's MFMA -> VALU latencies
+    // wave = 4 * tt + fw owns heads 2 fw, 2 fw + 1 (K and V tiles) of token tile tt -> one partial slab per 32 tokens
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fw = wave & 3, tt = wave >> 2;
-    const int r = lane & 31, h = lane >> 5;
     const int tile = blockIdx.x, b = blockIdx.y;
     const int s = tile >= a.tiles[0] ? 1 : 0;
     const int lt = s ? tile - a.tiles[0] : tile;
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(TOK * 8) OPHIP_WAVES_PER_SIMD(1, 2) void kv_reduce_
     if (tok0 + 32 * tt >= L) return;                 // second half of a ragged last tile: no tokens, no slab
 
     float* out = a.partial + ((size_t)b * (a.slabs[0] + a.slabs[1]) + (s ? a.slabs[0] : 0) + (TOK / 32) * lt + tt) * KV_PART_FLOATS;
-    kv_slab_from_planes<NS>(ring, whi, wlo, XH + 32 * tt * ROWB, XL + 32 * tt * ROWB, tok0 + 32 * tt, L, out, fw, lane);
+    kv_slab_from_planes<NS, 1>(ring, whi, wlo, XH + 32 * tt * ROWB, XL + 32 * tt * ROWB, tok0 + 32 * tt, L, out, fw, lane);
 }
 
 struct KvSumBArgs {
@@ -167,52 +176,65 @@ struct AttnBArgs {
     unsigned long long* stamps;
 };
 
-// LayerNorm over the 256 features of a token held as D[feature][token] accumulators by the 4 feature-group waves of
-// its token tile (wave (tt, fw): features 64 fw .. 64 fw + 63).  Two-pass; partial sums cross waves through `scratch`
+// LayerNorm over the 256 features of a token held as D[feature][token] accumulators by the 4 feature-group waves
+// (wave fw: features 64 fw .. 64 fw + 63 of all TT token tiles).  Two-pass; partial sums cross waves through `scratch`
 // ([2][4][64] floats).  Contains 2 workgroup barriers.
-__device__ __forceinline__ void layernorm_featrow(f32x16 (&m)[2][1], const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                  float* scratch, int fw, int tt, int lane) {
+template <int TT>
+__device__ __forceinline__ void layernorm_featrow(f32x16 (&m)[2][TT], const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  float* scratch, int fw, int lane) {
     const int r = lane & 31, h = lane >> 5;
-    const int tok = 32 * tt + r;
-    float s = 0.f;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int tt = 0; tt < TT; ++tt) {
+        float s = 0.f;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) s += m[t][0][reg];
-    s += __shfl_xor(s, 32, 64);
-    if (h == 0) scratch[fw * 64 + tok] = s;
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) s += m[t][tt][reg];
+        s += __shfl_xor(s, 32, 64);
+        if (h == 0) scratch[fw * 64 + 32 * tt + r] = s;
+    }
     __syncthreads();
-    const float mean = ((scratch[tok] + scratch[64 + tok]) + (scratch[128 + tok] + scratch[192 + tok])) * (1.0f / C);
-    float q = 0.f;
+    float mean[TT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int tt = 0; tt < TT; ++tt) {
+        const int tok = 32 * tt + r;
+        mean[tt] = ((scratch[tok] + scratch[64 + tok]) + (scratch[128 + tok] + scratch[192 + tok])) * (1.0f / C);
+        float q = 0.f;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const float d = m[t][0][reg] - mean;
-            q += d * d;
-        }
-    q += __shfl_xor(q, 32, 64);
-    if (h == 0) scratch[256 + fw * 64 + tok] = q;
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float d = m[t][tt][reg] - mean[tt];
+                q += d * d;
+            }
+        q += __shfl_xor(q, 32, 64);
+        if (h == 0) scratch[256 + fw * 64 + tok] = q;
+    }
     __syncthreads();
-    const float var = ((scratch[256 + tok] + scratch[320 + tok]) + (scratch[384 + tok] + scratch[448 + tok])) * (1.0f / C);
-    const float rstd = 1.0f / sqrtf(var + 1e-5f);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int tt = 0; tt < TT; ++tt) {
+        const int tok = 32 * tt + r;
+        const float var = ((scratch[256 + tok] + scratch[320 + tok]) + (scratch[384 + tok] + scratch[448 + tok])) * (1.0f / C);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int f0 = 64 * fw + 32 * t + 8 * g + 4 * h;
-            const f32x4 gv = *reinterpret_cast<const f32x4*>(gamma + f0);
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(beta + f0);
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) m[t][0][4 * g + j] = (m[t][0][4 * g + j] - mean) * rstd * gv[j] + bv[j];
-        }
+            for (int g = 0; g < 4; ++g) {
+                const int f0 = 64 * fw + 32 * t + 8 * g + 4 * h;
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(gamma + f0);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(beta + f0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[t][tt][4 * g + j] = (m[t][tt][4 * g + j] - mean[tt]) * rstd * gv[j] + bv[j];
+            }
+    }
 }
 
-template <int NS, int TOK>
-__global__ __launch_bounds__(TOK * 8) OPHIP_WAVES_PER_SIMD(2, 2) void attn_apply_bf16_kernel(AttnBArgs a) {
+template <int NS, int TT>
+__global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(TT == 1 ? 2 : 1, TT == 1 ? 2 : 1) void attn_apply_bf16_kernel(AttnBArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PL = NS == 3 ? 2 : 1;
-    constexpr int NT_ = TOK * 8;                     // threads: 4 waves per 32-token tile
+    constexpr int TOK = 32 * TT;
+    constexpr int NT_ = 256;
     constexpr int XB = TOK * ROWB, HB = TOK * HROWB;
     char* XH = smem;
     char* XL = smem + (PL - 1) * XB;
@@ -221,10 +243,8 @@ __global__ __launch_bounds__(TOK * 8) OPHIP_WAVES_PER_SIMD(2, 2) void attn_apply
     char* HH = smem + 2 * PL * XB;
     char* HL = HH + (PL - 1) * HB;
     float* scratch = reinterpret_cast<float*>(HH);          // LayerNorm exchange; H is idle whenever a LayerNorm runs
-    // 8 waves: wave = 4 * tt + fw owns feature group fw (features 64 fw .. 64 fw + 63 = heads 2 fw, 2 fw + 1) of token
-    // tile tt; the two token tiles' dependent chains share each SIMD (2 waves / SIMD)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fw = wave & 3, tt = wave >> 2;
+    // 4 waves: wave fw owns feature group fw (features 64 fw .. 64 fw + 63 = heads 2 fw, 2 fw + 1) of all TT token tiles
+    const int tid = threadIdx.x, lane = tid & 63, fw = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int tile = blockIdx.x, b = blockIdx.y;
     const int s = tile >= a.tiles[0] ? 1 : 0;
@@ -236,10 +256,6 @@ __global__ __launch_bounds__(TOK * 8) OPHIP_WAVES_PER_SIMD(2, 2) void attn_apply
     const bf16x8 *wm_hi = a.w_hi + 3 * C * C / 8 + (size_t)(2 * fw) * TS + lane, *wm_lo = a.w_lo + 3 * C * C / 8 + (size_t)(2 * fw) * TS + lane;
     const bf16x8 *w0_hi = a.w_hi + 4 * C * C / 8 + lane, *w0_lo = a.w_lo + 4 * C * C / 8 + lane;
     const bf16x8 *w2_hi = a.w_hi + 8 * C * C / 8 + (size_t)(2 * fw) * TS2 + lane, *w2_lo = a.w_lo + 8 * C * C / 8 + (size_t)(2 * fw) * TS2 + lane;
-    // this wave's token rows inside the planes
-    const char *xh = XH + 32 * tt * ROWB, *xl = XL + 32 * tt * ROWB;
-    const char *yh = YH + 32 * tt * ROWB, *yl = YL + 32 * tt * ROWB;
-    const char *hh = HH + 32 * tt * HROWB, *hl = HL + 32 * tt * HROWB;
 
     WRing<2, 4, NS> rq;
     rq.fill(wq_hi, wq_lo, TS);                       // weights travel while the activation tile is staged
@@ -252,8 +268,12 @@ __global__ __launch_bounds__(TOK * 8) OPHIP_WAVES_PER_SIMD(2, 2) void attn_apply
     // ---- Q projection (heads 2fw, 2fw+1), phi, linear attention from registers -----------------------------
     WRing<2, 4, NS> rm;
     {
-        f32x16 q[2][1] = {{zero16()}, {zero16()}};
-        gemm_bf16_ring<2, 1, NS, true, KB, 4>(q, rq, wq_hi, wq_lo, TS, xh, xl, ROWB, 0, lane);
+        f32x16 q[2][TT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) q[t][tt] = zero16();
+        gemm_bf16_ring<2, TT, NS, true, KB, 4>(q, rq, wq_hi, wq_lo, TS, XH, XL, ROWB, 0, lane);
         OPHIP_STAMP(a.stamps, wg, 2);
         rm.fill(wm_hi, wm_lo, TS);                   // merge weights: in flight during the attention below
         const char* kvb = a.kv[s] + (size_t)b * a.kvbs;
@@ -262,15 +282,19 @@ __global__ __launch_bounds__(TOK * 8) OPHIP_WAVES_PER_SIMD(2, 2) void attn_apply
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int head = 2 * fw + t;
-            f32x16 num = zero16(), den = zero16();
+            f32x16 num[TT], den[TT];
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) q[t][0][reg] = elu_plus_one_fast(q[t][0][reg]);
+            for (int tt = 0; tt < TT; ++tt) {
+                num[tt] = zero16(); den[tt] = zero16();
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) q[t][tt][reg] = elu_plus_one_fast(q[t][tt][reg]);
+            }
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 const bf16x8 kvh = *reinterpret_cast<const bf16x8*>(kvb + ((size_t)((head * 2 + st) * 2 + 0) * 64 + lane) * 16);
                 const bf16x8 kvl = (NS == 3) ? *reinterpret_cast<const bf16x8*>(kvb + ((size_t)((head * 2 + st) * 2 + 1) * 64 + lane) * 16) : zero_bf8();
                 const float* kp = ksum + head * 32 + h * 16 + 8 * st;
-                bf16x8 ksh, ksl, qh, ql;
+                bf16x8 ksh, ksl;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     __bf16 hh2, ll2;
@@ -278,13 +302,20 @@ __global__ __launch_bounds__(TOK * 8) OPHIP_WAVES_PER_SIMD(2, 2) void attn_apply
                     ksh[j] = hh2;
                     ksl[j] = (NS == 3) ? ll2 : (__bf16)0.f;
                 }
-                acc_frag<NS>(q[t][0], st, qh, ql);
-                num = mma_bf16<NS>(kvh, kvl, qh, ql, num);      // num^T[v][tok] = sum_d KV[d][v] phiQ[tok][d]
-                den = mma_bf16<NS>(ksh, ksl, qh, ql, den);      // den[tok] replicated over v
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) {
+                    bf16x8 qh, ql;
+                    acc_frag<NS>(q[t][tt], st, qh, ql);
+                    num[tt] = mma_bf16<NS>(kvh, kvl, qh, ql, num[tt]);      // num^T[v][tok] = sum_d KV[d][v] phiQ[tok][d]
+                    den[tt] = mma_bf16<NS>(ksh, ksl, qh, ql, den[tt]);      // den[tok] replicated over v
+                }
             }
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) num[reg] = num[reg] * rcp_fast(den[reg] + 1e-6f) * S;
-            store_featrow_acc<NS>(num, YH, YL, ROWB, 32 * head, 32 * tt, lane);
+            for (int tt = 0; tt < TT; ++tt) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) num[tt][reg] = num[tt][reg] * rcp_fast(den[tt][reg] + 1e-6f) * S;
+                store_featrow_acc<NS>(num[tt], YH, YL, ROWB, 32 * head, 32 * tt, lane);
+            }
         }
     }
     __syncthreads();
@@ -292,49 +323,66 @@ __global__ __launch_bounds__(TOK * 8) OPHIP_WAVES_PER_SIMD(2, 2) void attn_apply
     // ---- merge + LayerNorm 1 -> Y ----------------------------------------------------------------
     WRing<1, 4, NS> r0;
     {
-        f32x16 m[2][1] = {{zero16()}, {zero16()}};
-        gemm_bf16_ring<2, 1, NS, true, KB, 4>(m, rm, wm_hi, wm_lo, TS, yh, yl, ROWB, 0, lane);
+        f32x16 m[2][TT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) m[t][tt] = zero16();
+        gemm_bf16_ring<2, TT, NS, true, KB, 4>(m, rm, wm_hi, wm_lo, TS, YH, YL, ROWB, 0, lane);
         OPHIP_STAMP(a.stamps, wg, 4);
         r0.fill(w0_hi + (size_t)fw * TS2, w0_lo + (size_t)fw * TS2, TS2);          // MLP-up weights of chunk 0
-        layernorm_featrow(m, a.ln, a.ln + C, scratch, fw, tt, lane);     // its first barrier also fences the reads of Y above
+        layernorm_featrow<TT>(m, a.ln, a.ln + C, scratch, fw, lane);     // its first barrier also fences the reads of Y above
 #pragma unroll
-        for (int t = 0; t < 2; ++t) store_featrow_acc<NS>(m[t][0], YH, YL, ROWB, 64 * fw + 32 * t, 32 * tt, lane);
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) store_featrow_acc<NS>(m[t][tt], YH, YL, ROWB, 64 * fw + 32 * t, 32 * tt, lane);
     }
     __syncthreads();
     OPHIP_STAMP(a.stamps, wg, 5);
     // ---- MLP: hidden = relu([x, msg] W0^T) in four 128-feature chunks, o += hidden_chunk W2[:, chunk]^T ---------
-    f32x16 o[2][1] = {{zero16()}, {zero16()}};
+    f32x16 o[2][TT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) o[t][tt] = zero16();
     for (int c = 0; c < 4; ++c) {
-        f32x16 hd[1][1] = {{zero16()}};
+        f32x16 hd[1][TT];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) hd[0][tt] = zero16();
         const size_t wt = (size_t)(4 * c + fw) * TS2;
-        gemm_bf16_ring_cat<1, 1, NS, KB2, 4>(hd, r0, w0_hi + wt, w0_lo + wt, TS2, xh, xl, yh, yl, ROWB, lane);
+        gemm_bf16_ring_cat<1, TT, NS, KB2, 4>(hd, r0, w0_hi + wt, w0_lo + wt, TS2, XH, XL, YH, YL, ROWB, lane);
         OPHIP_STAMP(a.stamps, wg, 6 + 4 * c);
         WRing<2, 4, NS> r2;
         r2.fill(w2_hi + (size_t)(8 * c) * 64, w2_lo + (size_t)(8 * c) * 64, TS2);
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) hd[0][0][reg] = fmaxf(hd[0][0][reg], 0.f);
-        store_featrow_acc<NS>(hd[0][0], HH, HL, HROWB, 32 * fw, 32 * tt, lane);
+        for (int tt = 0; tt < TT; ++tt) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) hd[0][tt][reg] = fmaxf(hd[0][tt][reg], 0.f);
+            store_featrow_acc<NS>(hd[0][tt], HH, HL, HROWB, 32 * fw, 32 * tt, lane);
+        }
         __syncthreads();
         OPHIP_STAMP(a.stamps, wg, 7 + 4 * c);
-        gemm_bf16_ring<2, 1, NS, true, 8, 4>(o, r2, w2_hi + (size_t)(8 * c) * 64, w2_lo + (size_t)(8 * c) * 64, TS2, hh, hl, HROWB, 0, lane);
+        gemm_bf16_ring<2, TT, NS, true, 8, 4>(o, r2, w2_hi + (size_t)(8 * c) * 64, w2_lo + (size_t)(8 * c) * 64, TS2, HH, HL, HROWB, 0, lane);
         OPHIP_STAMP(a.stamps, wg, 8 + 4 * c);
         if (c + 1 < 4) r0.fill(w0_hi + wt + (size_t)4 * TS2, w0_lo + wt + (size_t)4 * TS2, TS2);
         __syncthreads();
         OPHIP_STAMP(a.stamps, wg, 9 + 4 * c);
     }
-    layernorm_featrow(o, a.ln + 2 * C, a.ln + 3 * C, scratch, fw, tt, lane);
+    layernorm_featrow<TT>(o, a.ln + 2 * C, a.ln + 3 * C, scratch, fw, lane);
     OPHIP_STAMP(a.stamps, wg, 22);
-    // ---- stage LN2 output as f32 [64][256] over the (now dead) X / Y planes, then x + msg with whole-row stores ----
+    // ---- stage LN2 output as f32 [TOK][256] over the (now dead) X / Y planes, then x + msg with whole-row stores ----
     char* stage = smem;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int row = 32 * tt + r;
-            const int ch = 16 * fw + 8 * t + 2 * g + h;          // 16-byte chunk of the f32 row
-            f32x4 v = {o[t][0][4 * g], o[t][0][4 * g + 1], o[t][0][4 * g + 2], o[t][0][4 * g + 3]};
-            *reinterpret_cast<f32x4*>(stage + row * (C * 4) + ((ch ^ (row & 15)) << 4)) = v;
-        }
+        for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int row = 32 * tt + r;
+                const int ch = 16 * fw + 8 * t + 2 * g + h;          // 16-byte chunk of the f32 row
+                f32x4 v = {o[t][tt][4 * g], o[t][tt][4 * g + 1], o[t][tt][4 * g + 2], o[t][tt][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(stage + row * (C * 4) + ((ch ^ (row & 15)) << 4)) = v;
+            }
     __syncthreads();
     float* yg = a.y[s] + (size_t)b * a.ybs[s];
     const bool fuse = a.nkv_hi != nullptr;
@@ -372,10 +420,8 @@ __global__ __launch_bounds__(TOK * 8) OPHIP_WAVES_PER_SIMD(2, 2) void attn_apply
     if (fuse) {
         // ---- kv_reduce of the next layer on the tile that is still on chip (saves a launch and a re-read of the streams) ----
         __syncthreads();
-        if (tok0 + 32 * tt < L) {
-            float* out = a.npartial + ((size_t)b * (a.slabs[0] + a.slabs[1]) + (s ? a.slabs[0] : 0) + (TOK / 32) * lt + tt) * KV_PART_FLOATS;
-            kv_slab_from_planes<NS>(rkv, nhi, nlo, KH + 32 * tt * ROWB, KL + 32 * tt * ROWB, tok0 + 32 * tt, L, out, fw, lane);
-        }
+        float* out = a.npartial + ((size_t)b * (a.slabs[0] + a.slabs[1]) + (s ? a.slabs[0] : 0) + TT * lt) * KV_PART_FLOATS;
+        kv_slab_from_planes<NS, TT>(rkv, nhi, nlo, KH, KL, tok0, L, out, fw, lane);
     }
     OPHIP_STAMP(a.stamps, wg, 31);
 }
@@ -404,11 +450,13 @@ extern "C" int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, floa
     if (slot != 0 && slot != 1) return ophip_bad_arg(__func__, "slot must be 0 or 1");
     if (x3d == y3d || x2d == y2d) return ophip_bad_arg(__func__, "in-place layer is not supported (cross layers read the pre-update streams)");
     hipStream_t stream = (hipStream_t)stream_;
-    // tile size: 32-token workgroups (4 waves, 80 KiB LDS in split mode) -> two INDEPENDENT workgroups per CU whose
-    // barrier / epilogue gaps interleave: measured 69 vs 77 us per launch at c2 against one 64-token / 8-wave workgroup
-    // (which fetches the weights half as often but runs its 8 waves in barrier lock-step).  OPHIP_ENC_TOK=64 selects the latter.
-    static const int tok_env = [] { const char* e = getenv("OPHIP_ENC_TOK"); return e ? atoi(e) : 0; }();
-    const int TOK = tok_env == 64 ? 64 : 32;
+    // token tiles per attn_apply workgroup (see the header).  Measured at c2 (split mode): TT = 1 (32-token workgroups,
+    // two per CU, 2 waves per SIMD) 69 us per launch at B = 1 and 51 us per frame at B = 4; TT = 2 (64 tokens, one
+    // workgroup per CU, weights fetched half as often but a single wave per SIMD, so nothing covers its epilogues)
+    // 70 / 52 us.  TT = 1 is the default, OPHIP_ENC_TT=2 selects the other.  kv_reduce always works on 32-token tiles.
+    static const int tt_env = [] { const char* e = getenv("OPHIP_ENC_TT"); return e ? atoi(e) : 0; }();
+    const int TT = tt_env == 2 ? 2 : 1;
+    const int TOK = 32 * TT;
     const int t3 = (L3d + TOK - 1) / TOK, t2 = (L2d + TOK - 1) / TOK;
     const int s3 = (L3d + 31) / 32, s2 = (L2d + 31) / 32;
     const size_t part_floats = (size_t)B * (s3 + s2) * KV_PART_FLOATS;
@@ -426,21 +474,19 @@ extern "C" int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, floa
         KvRedArgs ka;
         ka.x[0] = x3d; ka.x[1] = x2d;
         ka.xbs[0] = (long long)L3d * C; ka.xbs[1] = (long long)L2d * C;
-        ka.L[0] = L3d; ka.L[1] = L2d; ka.tiles[0] = t3; ka.tiles[1] = t2; ka.slabs[0] = s3; ka.slabs[1] = s2;
+        ka.L[0] = L3d; ka.L[1] = L2d; ka.tiles[0] = s3; ka.tiles[1] = s2; ka.slabs[0] = s3; ka.slabs[1] = s2;
         ka.w_hi = w_hi + C * C / 8; ka.w_lo = w_lo + C * C / 8;
         ka.partial = partial;
-        const size_t lds_kv = (size_t)PL * TOK * ROWB;
-        static bool attr_kv[4] = {false, false, false, false};
-        const int vi = (nsplit == 3 ? 2 : 0) + (TOK == 64 ? 1 : 0);
-#define OPHIP_KV_CASE(NS_, TK_)                                                                                                  \
+        const size_t lds_kv = (size_t)PL * 32 * ROWB;
+        static bool attr_kv[2] = {false, false};
+        const int vi = nsplit == 3 ? 1 : 0;
+#define OPHIP_KV_CASE(NS_)                                                                                                       \
         {                                                                                                                        \
-            if (!attr_kv[vi]) { if (int rc = set_lds(kv_reduce_bf16_kernel<NS_, TK_>, lds_kv, "hipFuncSetAttribute(kv_reduce_bf16)")) return rc; attr_kv[vi] = true; } \
-            OPHIP_LAUNCH("kv_reduce", stream, (kv_reduce_bf16_kernel<NS_, TK_>), dim3(t3 + t2, B), dim3(TK_ * 8), lds_kv, stream, ka);  \
+            if (!attr_kv[vi]) { if (int rc = set_lds(kv_reduce_bf16_kernel<NS_, 32>, lds_kv, "hipFuncSetAttribute(kv_reduce_bf16)")) return rc; attr_kv[vi] = true; } \
+            OPHIP_LAUNCH("kv_reduce", stream, (kv_reduce_bf16_kernel<NS_, 32>), dim3(s3 + s2, B), dim3(256), lds_kv, stream, ka);  \
         }
-        if (nsplit == 3 && TOK == 64) OPHIP_KV_CASE(3, 64)
-        else if (nsplit == 3) OPHIP_KV_CASE(3, 32)
-        else if (TOK == 64) OPHIP_KV_CASE(1, 64)
-        else OPHIP_KV_CASE(1, 32)
+        if (nsplit == 3) OPHIP_KV_CASE(3)
+        else OPHIP_KV_CASE(1)
 #undef OPHIP_KV_CASE
         OPHIP_CHECK_LAUNCH();
     }
@@ -472,16 +518,16 @@ extern "C" int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, floa
     const size_t lds_fuse = (size_t)TOK * C * 4 + (size_t)PL * TOK * ROWB;
     if (lds_fuse > lds_at) lds_at = lds_fuse;
     static bool attr_at[4] = {false, false, false, false};
-    const int wi = (nsplit == 3 ? 2 : 0) + (TOK == 64 ? 1 : 0);
-#define OPHIP_AT_CASE(NS_, TK_)                                                                                                  \
+    const int wi = (nsplit == 3 ? 2 : 0) + (TT == 2 ? 1 : 0);
+#define OPHIP_AT_CASE(NS_, TT_)                                                                                                  \
     {                                                                                                                            \
-        if (!attr_at[wi]) { if (int rc = set_lds(attn_apply_bf16_kernel<NS_, TK_>, lds_at, "hipFuncSetAttribute(attn_apply_bf16)")) return rc; attr_at[wi] = true; } \
-        OPHIP_LAUNCH("attn_apply", stream, (attn_apply_bf16_kernel<NS_, TK_>), dim3(t3 + t2, B), dim3(TK_ * 8), lds_at, stream, aa);    \
+        if (!attr_at[wi]) { if (int rc = set_lds(attn_apply_bf16_kernel<NS_, TT_>, lds_at, "hipFuncSetAttribute(attn_apply_bf16)")) return rc; attr_at[wi] = true; } \
+        OPHIP_LAUNCH("attn_apply", stream, (attn_apply_bf16_kernel<NS_, TT_>), dim3(t3 + t2, B), dim3(256), lds_at, stream, aa);    \
     }
-    if (nsplit == 3 && TOK == 64) OPHIP_AT_CASE(3, 64)
-    else if (nsplit == 3) OPHIP_AT_CASE(3, 32)
-    else if (TOK == 64) OPHIP_AT_CASE(1, 64)
-    else OPHIP_AT_CASE(1, 32)
+    if (nsplit == 3 && TT == 2) OPHIP_AT_CASE(3, 2)
+    else if (nsplit == 3) OPHIP_AT_CASE(3, 1)
+    else if (TT == 2) OPHIP_AT_CASE(1, 2)
+    else OPHIP_AT_CASE(1, 1)
 #undef OPHIP_AT_CASE
     OPHIP_CHECK_LAUNCH();
     return 0;

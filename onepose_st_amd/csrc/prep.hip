@@ -33,12 +33,15 @@ __global__ __launch_bounds__(256) void pe_add_transpose_kernel(const float* __re
 // ---------------------------------------------------------------------------------------------
 // stats[4*b .. 4*b+2] = mean of keypoints3d[b];  stats[4*B] = 0.6 * max extent of batch element 0
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void kpt_stats_kernel(const float* __restrict__ kpts, long long bs, float* __restrict__ stats, int B, int N) {
-    __shared__ float red[4][9];
+constexpr int KS_THREADS = 1024, KS_WAVES = KS_THREADS / 64;
+
+__global__ __launch_bounds__(KS_THREADS) void kpt_stats_kernel(const float* __restrict__ kpts, long long bs, float* __restrict__ stats, int B, int N) {
+    __shared__ float red[KS_WAVES][9];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* k = kpts + (size_t)b * bs;
     float s[3] = {0.f, 0.f, 0.f}, mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = tid; i < N; i += 256) {
+#pragma unroll 4
+    for (int i = tid; i < N; i += KS_THREADS) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const float v = k[(size_t)i * 3 + d];
@@ -59,10 +62,13 @@ __global__ __launch_bounds__(256) void kpt_stats_kernel(const float* __restrict_
     if (tid == 0) {
         float ext = 0.f;
         for (int d = 0; d < 3; ++d) {
-            const float sum = (red[0][d] + red[1][d]) + (red[2][d] + red[3][d]);
+            float sum = 0.f, lo = INFINITY, hi = -INFINITY;
+            for (int w = 0; w < KS_WAVES; ++w) {         // fixed order: the mean is run-to-run reproducible
+                sum += red[w][d];
+                lo = fminf(lo, red[w][3 + d]);
+                hi = fmaxf(hi, red[w][6 + d]);
+            }
             stats[4 * b + d] = sum / (float)N;
-            const float lo = fminf(fminf(red[0][3 + d], red[1][3 + d]), fminf(red[2][3 + d], red[3][3 + d]));
-            const float hi = fmaxf(fmaxf(red[0][6 + d], red[1][6 + d]), fmaxf(red[2][6 + d], red[3][6 + d]));
             ext = fmaxf(ext, hi - lo);
         }
         stats[4 * b + 3] = 0.f;
@@ -245,7 +251,7 @@ extern "C" int ophip_kpt_encode(const float* keypoints3d, long long kpts_bstride
     if (!keypoints3d || !desc_bcn || !wpack || !stats || !out_bnc) return ophip_bad_arg(__func__, "null pointer");
     if (B < 1 || N < 1) return ophip_bad_arg(__func__, "bad sizes");
     hipStream_t stream = (hipStream_t)stream_;
-    OPHIP_LAUNCH("kpt_stats", stream, kpt_stats_kernel, dim3(B), dim3(256), 0, stream, keypoints3d, kpts_bstride, stats, B, N);
+    OPHIP_LAUNCH("kpt_stats", stream, kpt_stats_kernel, dim3(B), dim3(KS_THREADS), 0, stream, keypoints3d, kpts_bstride, stats, B, N);
     OPHIP_CHECK_LAUNCH();
     // packed block (floats): W1[32x8] | W2[64x32] | W3[128x64] | W4[256x128] | b1 | b2 | b3 | b4
     KptArgs a;

@@ -109,25 +109,32 @@ template <int NT, int TT, int NS, bool W_IS_A, int KBLOCKS, int PD>
 __device__ __forceinline__ void gemm_bf16_ring(f32x16 (&acc)[NT][TT], WRing<NT, PD, NS>& ring, const bf16x8* __restrict__ whi,
                                                const bf16x8* __restrict__ wlo, int tstride, const char* act_hi, const char* act_lo,
                                                int rowb, int chunk0, int lane, int swz = 15) {
-    static_assert(KBLOCKS % PD == 0, "k-blocks must be a multiple of the prefetch depth");
+    static_assert(KBLOCKS % PD == 0 && (PD % 2 == 0 || PD == 1), "k-blocks must be a multiple of the (even) prefetch depth");
     const int r = lane & 31, h = lane >> 5;
+    // activation fragments are read one k-block ahead (two register sets), so the LDS round trip of k-block kb + 1
+    // runs under the MFMAs of k-block kb even with a single wave on the SIMD
+    bf16x8 x_hi[2][TT], x_lo[2][TT];
+    auto read_x = [&](int kb, int set) {
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            const int off = plane_off(32 * tt + r, chunk0 + 2 * kb + h, rowb, swz);
+            x_hi[set][tt] = *reinterpret_cast<const bf16x8*>(act_hi + off);
+            x_lo[set][tt] = (NS == 3) ? *reinterpret_cast<const bf16x8*>(act_lo + off) : zero_bf8();
+        }
+    };
+    read_x(0, 0);
     for (int kb0 = 0; kb0 < KBLOCKS; kb0 += PD) {
 #pragma unroll
         for (int p = 0; p < PD; ++p) {
             const int kb = kb0 + p;
-            bf16x8 x_hi[TT], x_lo[TT];
-#pragma unroll
-            for (int tt = 0; tt < TT; ++tt) {
-                const int off = plane_off(32 * tt + r, chunk0 + 2 * kb + h, rowb, swz);
-                x_hi[tt] = *reinterpret_cast<const bf16x8*>(act_hi + off);
-                x_lo[tt] = (NS == 3) ? *reinterpret_cast<const bf16x8*>(act_lo + off) : zero_bf8();
-            }
+            const int cur = p & 1;                  // PD is even or 1: the parity of kb is the parity of p
+            if (kb + 1 < KBLOCKS) read_x(kb + 1, cur ^ 1);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int tt = 0; tt < TT; ++tt)
-                    acc[t][tt] = W_IS_A ? mma_bf16<NS>(ring.hi[p][t], ring.lo[p][t], x_hi[tt], x_lo[tt], acc[t][tt])
-                                        : mma_bf16<NS>(x_hi[tt], x_lo[tt], ring.hi[p][t], ring.lo[p][t], acc[t][tt]);
+                    acc[t][tt] = W_IS_A ? mma_bf16<NS>(ring.hi[p][t], ring.lo[p][t], x_hi[cur][tt], x_lo[cur][tt], acc[t][tt])
+                                        : mma_bf16<NS>(x_hi[cur][tt], x_lo[cur][tt], ring.hi[p][t], ring.lo[p][t], acc[t][tt]);
             // refill this slot with k-block kb + PD (nothing to fetch at the tail)
             if (kb + PD < KBLOCKS) {
 #pragma unroll
@@ -149,25 +156,30 @@ __device__ __forceinline__ void gemm_bf16_ring_cat(f32x16 (&acc)[NT][TT], WRing<
                                                    const char* b_hi, const char* b_lo, int rowb, int lane) {
     static_assert(KBLOCKS % (2 * PD) == 0, "each half must be a multiple of the prefetch depth");
     const int r = lane & 31, h = lane >> 5;
-    for (int kb0 = 0; kb0 < KBLOCKS; kb0 += PD) {
-        const bool second = kb0 >= KBLOCKS / 2;
+    bf16x8 x_hi[2][TT], x_lo[2][TT];
+    auto read_x = [&](int kb, int set) {
+        const bool second = kb >= KBLOCKS / 2;
         const char* s_hi = second ? b_hi : a_hi;
         const char* s_lo = second ? b_lo : a_lo;
-        const int kbase = second ? kb0 - KBLOCKS / 2 : kb0;
+        const int kk = second ? kb - KBLOCKS / 2 : kb;
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            const int off = plane_off(32 * tt + r, 2 * kk + h, rowb);
+            x_hi[set][tt] = *reinterpret_cast<const bf16x8*>(s_hi + off);
+            x_lo[set][tt] = (NS == 3) ? *reinterpret_cast<const bf16x8*>(s_lo + off) : zero_bf8();
+        }
+    };
+    read_x(0, 0);
+    for (int kb0 = 0; kb0 < KBLOCKS; kb0 += PD) {
 #pragma unroll
         for (int p = 0; p < PD; ++p) {
             const int kb = kb0 + p;
-            bf16x8 x_hi[TT], x_lo[TT];
-#pragma unroll
-            for (int tt = 0; tt < TT; ++tt) {
-                const int off = plane_off(32 * tt + r, 2 * (kbase + p) + h, rowb);
-                x_hi[tt] = *reinterpret_cast<const bf16x8*>(s_hi + off);
-                x_lo[tt] = (NS == 3) ? *reinterpret_cast<const bf16x8*>(s_lo + off) : zero_bf8();
-            }
+            const int cur = p & 1;
+            if (kb + 1 < KBLOCKS) read_x(kb + 1, cur ^ 1);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int tt = 0; tt < TT; ++tt) acc[t][tt] = mma_bf16<NS>(ring.hi[p][t], ring.lo[p][t], x_hi[tt], x_lo[tt], acc[t][tt]);
+                for (int tt = 0; tt < TT; ++tt) acc[t][tt] = mma_bf16<NS>(ring.hi[p][t], ring.lo[p][t], x_hi[cur][tt], x_lo[cur][tt], acc[t][tt]);
             if (kb + PD < KBLOCKS) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {

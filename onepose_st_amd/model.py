@@ -257,23 +257,27 @@ class OnePosePlus_model(nn.Module):
         conf = torch.empty(B, N, M, **f32)
         cws = torch.empty(hip.load().ophip_coarse_workspace_floats(B, N, M), **f32)
         i64 = dict(device=dev, dtype=torch.int64)
-        b_ids, i_ids, j_ids = torch.empty(cap, **i64), torch.empty(cap, **i64), torch.empty(cap, **i64)
-        mconf, mk3d, mkc = torch.empty(cap, **f32), torch.empty(cap, 3, **f32), torch.empty(cap, 2, **f32)
-        count = torch.zeros(1, device=dev, dtype=torch.int32)
+        # what the host reads back (count, b_ids, 3D points, refined 2D points) lives in one block: one D2H copy per frame
+        blob, count, b_ids, mk3d, mk2d = _result_block(dev, cap)
+        i_ids, j_ids, m_bids = torch.empty(cap, **i64), torch.empty(cap, **i64), torch.empty(cap, **i64)
+        gt_mask = torch.empty(cap, device=dev, dtype=torch.bool)
+        fine_on = bool(cfg["fine_matching"]["enable"])
+        mconf = torch.empty(cap, **f32)
+        mkc = torch.empty(cap, 2, **f32) if fine_on else mk2d
         scale = data["q_hw_i"][0] / hc
         with self.profiler.record_function("LoFTR/coarse-matching/get_coarse_match"):
             lib_call("ophip_coarse_match", P(x3d), P(x2d), P(kpts_d), bstride(kpts_d), B, N, M, wc,
                      float(cm["dual_softmax"]["temperature"]), float(cm["thr"]), int(cm["border_rm"]), float(scale),
                      P(conf), P(cws), P(b_ids, torch.int64), P(i_ids, torch.int64), P(j_ids, torch.int64),
-                     P(mconf), P(mk3d), P(mkc), P(count, torch.int32), {"f32": 0, "bf16": 1, "bf16x3": 3}[self.precision], S)
+                     P(mconf), P(mk3d), P(mkc), P(m_bids, torch.int64), P(gt_mask, torch.bool), P(count, torch.int32),
+                     {"f32": 0, "bf16": 1, "bf16x3": 3}[self.precision], S)
         data["conf_matrix"] = conf
 
-        fine_on = bool(cfg["fine_matching"]["enable"])
         if fine_on:
             # ---- a9-a11: fine refinement (grid sized by capacity, device-side count: no sync yet) ----
             cf = cfg["loftr_fine"]
             expec = torch.empty(cap, 3, **f32)
-            mkf = torch.empty(cap, 2, **f32)
+            mkf = mk2d
             dbg_w = torch.empty(cap, 25, 128, **f32) if want_fine_debug else None
             dbg_3 = torch.empty(cap, 128, **f32) if want_fine_debug else None
             names_f = self.loftr_fine.layer_names
@@ -304,10 +308,22 @@ class OnePosePlus_model(nn.Module):
                          wc, stride, float(fine_scale), P(expec), P(mkf), P(dbg_w), P(dbg_3), S)
 
         pend = PendingFrame(self, data, dev, B, N, M, cap, fine_on, want_fine_debug,
-                            dict(b_ids=b_ids, i_ids=i_ids, j_ids=j_ids, mconf=mconf, mk3d=mk3d, mkc=mkc, count=count,
+                            dict(blob=blob, b_ids=b_ids, i_ids=i_ids, j_ids=j_ids, mconf=mconf, mk3d=mk3d, mkc=mkc, count=count,
+                                 m_bids=m_bids, gt_mask=gt_mask,
                                  expec=expec if fine_on else None, mkf=mkf if fine_on else None,
                                  dbg_w=dbg_w if fine_on else None, dbg_3=dbg_3 if fine_on else None), host_copy)
         return pend
+
+
+def _result_views(blob, cap):
+    """(blob, count int32[1], b_ids int64[cap], mkpts3d f32[cap,3], mkpts2d f32[cap,2]) views of one byte block."""
+    o_b, o_3, o_2 = 16, 16 + 8 * cap, 16 + 20 * cap
+    return (blob, blob[:4].view(torch.int32), blob[o_b:o_3].view(torch.int64),
+            blob[o_3:o_2].view(torch.float32).view(cap, 3), blob[o_2:o_2 + 8 * cap].view(torch.float32).view(cap, 2))
+
+
+def _result_block(dev, cap):
+    return _result_views(torch.empty(16 + 28 * cap, dtype=torch.uint8, device=dev), cap)
 
 
 class PendingFrame:
@@ -322,39 +338,27 @@ class PendingFrame:
         self.host = None
         key = (cap, bool(host_copy))
         pool = PendingFrame._pinned_pool.setdefault(key, [])
-        self._pin = pool.pop() if pool else self._alloc_pinned(cap, host_copy)
-        self._key = key
-        self._pin["count"].copy_(bufs["count"], non_blocking=True)
-        if host_copy:
-            self._pin["mk3d"].copy_(bufs["mk3d"], non_blocking=True)
-            self._pin["mk2d"].copy_(bufs["mkf"] if fine_on else bufs["mkc"], non_blocking=True)
-            self._pin["b_ids"].copy_(bufs["b_ids"], non_blocking=True)
+        nbytes = bufs["blob"].numel() if host_copy else 16
+        self._pin = pool.pop() if pool else torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        self._key, self._host_copy = key, bool(host_copy)
+        self._pin.copy_(bufs["blob"][:nbytes], non_blocking=True)
         self.event = torch.cuda.Event()
         self.event.record()
         self.done = False
-
-    @staticmethod
-    def _alloc_pinned(cap, host_copy):
-        pin = {"count": torch.empty(1, dtype=torch.int32).pin_memory()}
-        if host_copy:
-            pin["mk3d"] = torch.empty(cap, 3, dtype=torch.float32).pin_memory()
-            pin["mk2d"] = torch.empty(cap, 2, dtype=torch.float32).pin_memory()
-            pin["b_ids"] = torch.empty(cap, dtype=torch.int64).pin_memory()
-        return pin
 
     def finish(self):
         """Wait for this frame (event), read K, fill ``data`` exactly like the reference's ``forward``."""
         if self.done:
             return self.data
         self.event.synchronize()                    # the one host wait of the frame
-        K = int(self._pin["count"][0])
+        K = int(self._pin[:4].view(torch.int32)[0])
         B, N, M, cap = self.B, self.N, self.M, self.cap
         if self.fine_on and K > min(cap, B * min(N, M) + 64):
             raise RuntimeError("more coarse matches than the fine grid covers (exact confidence ties); "
                                "re-run with a larger grid is not implemented")
-        if "mk3d" in self._pin:
-            self.host = {"K": K, "mkpts_3d_db": self._pin["mk3d"][:K].numpy().copy(), "mkpts_2d": self._pin["mk2d"][:K].numpy().copy(),
-                         "b_ids": self._pin["b_ids"][:K].numpy().copy()}
+        if self._host_copy:
+            _, _, hb, h3, h2 = _result_views(self._pin, cap)
+            self.host = {"K": K, "mkpts_3d_db": h3[:K].numpy().copy(), "mkpts_2d": h2[:K].numpy().copy(), "b_ids": hb[:K].numpy().copy()}
         PendingFrame._pinned_pool[self._key].append(self._pin)
         bf = self.bufs
         data, dev = self.data, self.dev
@@ -362,7 +366,7 @@ class PendingFrame:
         mconf, mk3d, mkc = bf["mconf"][:K], bf["mk3d"][:K], bf["mkc"][:K]
         data.update({
             "b_ids": b_ids, "i_ids": i_ids, "j_ids": j_ids,
-            "gt_mask": mconf == 0, "m_bids": b_ids.clone(),
+            "gt_mask": bf["gt_mask"][:K], "m_bids": bf["m_bids"][:K],
             "mkpts_3d_db": mk3d, "mkpts_query_c": mkc, "mconf": mconf,
         })
         self.done = True

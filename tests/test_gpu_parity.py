@@ -151,11 +151,15 @@ def _coarse_match(dev, f3, f2, kp, wc, thr=0.1, border=2, temp=0.08, scale=8.0, 
     ids = [torch.empty(cap, dtype=torch.int64, device=dev) for _ in range(3)]
     mconf, mk3, mkc = torch.empty(cap, device=dev), torch.empty(cap, 3, device=dev), torch.empty(cap, 2, device=dev)
     cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    m_bids, gt_mask = torch.full((cap,), -1, dtype=torch.int64, device=dev), torch.full((cap,), 7, dtype=torch.uint8, device=dev)
     kd, f3d, f2d = kp.to(dev), f3.to(dev), f2.to(dev)      # keep the device copies alive across the call
     hip.call("ophip_coarse_match", hip.ptr(f3d), hip.ptr(f2d), hip.ptr(kd), kd.stride(0), B, N, M, wc,
              temp, thr, border, scale, hip.ptr(conf), hip.ptr(ws), *[hip.ptr(t, torch.int64) for t in ids],
-             hip.ptr(mconf), hip.ptr(mk3), hip.ptr(mkc), hip.ptr(cnt, torch.int32), nsplit, hip.stream_handle())
+             hip.ptr(mconf), hip.ptr(mk3), hip.ptr(mkc), hip.ptr(m_bids, torch.int64), hip.ptr(gt_mask, torch.uint8),
+             hip.ptr(cnt, torch.int32), nsplit, hip.stream_handle())
     K = int(cnt.item())
+    assert torch.equal(m_bids[:K], ids[0][:K]) and bool((m_bids[K:] == -1).all())      # second copy of b_ids, nothing past K
+    assert torch.equal(gt_mask[:K].bool(), mconf[:K] == 0) and bool((gt_mask[K:] == 7).all())
     return conf, [t[:K] for t in ids], mconf[:K], mk3[:K], mkc[:K]
 
 

@@ -13,17 +13,19 @@ y3, y2 = torch.empty_like(x3), torch.empty_like(x2)
 w = packing.pack_coarse_layer_bf16(sd, "loftr_coarse.layers.0.").to(dev)
 ws = torch.empty(hip.load().ophip_encoder_bf16_workspace_bytes(1, L3, L2), dtype=torch.uint8, device=dev)
 def run():
-    hip.call("ophip_encoder_layer_bf16", hip.ptr(x3), hip.ptr(x2), hip.ptr(y3), hip.ptr(y2), 1, L3, L2, hip.ptr(w, None), None, nsplit, 0, 0, 0, hip.ptr(ws, None), hip.stream_handle())
+    hip.call("ophip_encoder_layer_bf16", hip.ptr(x3), hip.ptr(x2), hip.ptr(y3), hip.ptr(y2), 1, L3, L2, hip.ptr(w, None), (hip.ptr(w, None) if __import__('os').environ.get('FUSE') else None), nsplit, 0, 0, 0, hip.ptr(ws, None), hip.stream_handle())
 for _ in range(3): run()
 buf = torch.zeros(1024 * 32, dtype=torch.int64, device=dev)
 hip.call("ophip_debug_stamps", ctypes.c_void_p(buf.data_ptr())); run(); torch.cuda.synchronize(); hip.call("ophip_debug_stamps", None)
-nwg = (L3 + 63) // 64 + (L2 + 63) // 64
+TOK = 32 * int(__import__('os').environ.get('OPHIP_ENC_TT', '1'))
+nwg = (L3 + TOK - 1) // TOK + (L2 + TOK - 1) // TOK
 s = buf.view(-1, 32)[:nwg].cpu().numpy().astype(np.int64)
-names = {0: "start", 1: "X load+sync", 2: "Q gemm", 3: "attention+store+sync", 4: "merge gemm", 5: "LN1+store+sync", 22: "LN2", 31: "stage+residual store"}
+names = {0: "start", 1: "X load+sync", 2: "Q gemm", 3: "attention+store+sync", 4: "merge gemm", 5: "LN1+store+sync", 22: "LN2", 30: "stage+residual store", 31: "fused next-layer kv slabs"}
 for c in range(4):
     names[6 + 4 * c] = f"c{c} mlp0 gemm"; names[7 + 4 * c] = f"c{c} relu+H store+sync"; names[8 + 4 * c] = f"c{c} mlp2 gemm"; names[9 + 4 * c] = f"c{c} sync"
 prev = s[:, 0]
-print("workgroups", nwg, "median WG cycles", np.median(s[:, 31] - s[:, 0]), "span", s[:, 31].max() - s[:, 0].min())
+d = s[:, 31] - s[:, 0]
+print("workgroups", nwg, "WG cycles p10/p50/p90", np.percentile(d, 10), np.median(d), np.percentile(d, 90), "span", s[:, 31].max() - s[:, 0].min())
 for k in sorted(names)[1:]:
     print(f"{names[k]:24s} {np.median(s[:, k] - prev):9.0f}")
     prev = s[:, k]

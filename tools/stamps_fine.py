@@ -20,7 +20,7 @@ hip.call("ophip_debug_stamps", ctypes.c_void_p(buf.data_ptr()))
 data = dict(d); m.forward_features(data, fc, ff, inp["image_hw"])
 torch.cuda.synchronize()
 hip.call("ophip_debug_stamps", None)
-K = data["i_ids"].numel(); nwg = (K + 1) // 2
+K = data["i_ids"].numel(); nwg = K
 s = buf.view(-1, 32)[:nwg].cpu().numpy().astype(np.int64)
 names = {0: "start", 1: "gather", 31: "end"}
 for l in range(2):

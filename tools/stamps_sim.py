@@ -13,7 +13,7 @@ mconf, mk3, mkc = torch.empty(N, device=dev), torch.empty(N, 3, device=dev), tor
 cnt = torch.zeros(1, dtype=torch.int32, device=dev)
 def run():
     hip.call("ophip_coarse_match", hip.ptr(f3), hip.ptr(f2), hip.ptr(kp), kp.stride(0), 1, N, M, wc, 0.08, 0.1, 2, 8.0, hip.ptr(conf), hip.ptr(ws),
-             *[hip.ptr(t, torch.int64) for t in ids], hip.ptr(mconf), hip.ptr(mk3), hip.ptr(mkc), hip.ptr(cnt, torch.int32), 3, hip.stream_handle())
+             *[hip.ptr(t, torch.int64) for t in ids], hip.ptr(mconf), hip.ptr(mk3), hip.ptr(mkc), None, None, hip.ptr(cnt, torch.int32), 3, hip.stream_handle())
 for _ in range(3): run()
 nwg = 38 * 55
 buf = torch.zeros(nwg * 32, dtype=torch.int64, device=dev)
