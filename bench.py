@@ -86,6 +86,9 @@ def main():
                     help="HIP streams the frames alternate over.  Default 1: kernels never overlap, so the HIP-event time of the "
                          "roofline kernel is its own.  2 overlaps consecutive (independent) frames: +18..27 %% frames/s at c2, but "
                          "per-kernel event times then include co-scheduled kernels")
+    ap.add_argument("--with-backbone", action="store_true",
+                    help="also run the ResNet-FPN backbone (SURVEY 8f-1, HIP convolution kernels) on a synthetic image in every step; "
+                         "its maps are then replaced by the planted feature maps (a random image has no matches)")
     ap.add_argument("--no-pnp", action="store_true", help="time the matcher only (no host PnP)")
     ap.add_argument("--pnp-threads", type=int, default=3)
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
@@ -165,10 +168,14 @@ def main():
     # kernels and launch tails of one frame (select, kpt_stats, kv_sum ...) overlap the wide kernels of the next
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
 
+    image = torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(7)).to(dev) if args.with_backbone else None
+
     def step(i):
         """enqueue batch i, then finish batch i - len(streams): the GPU always has queued work"""
         fc, ff = batches[i % len(batches)]
         with torch.cuda.stream(streams[i % len(streams)]):
+            if image is not None:
+                model.backbone_features(image)
             inflight.append(model.enqueue_features(dict(obj_b), fc, ff, image_hw, host_copy=pool is not None))
         if len(inflight) > len(streams):
             return complete(inflight.pop(0))
@@ -259,7 +266,7 @@ def main():
             "timed_region": "rows a1-a11 (PE, keypoint encoding, 6-layer coarse encoder, dual-softmax + mutual-NN incl. the "
                             "N x M conf_matrix write, fine refinement)" + ("" if args.no_pnp else " + host PnP/RANSAC of every frame "
                             f"(C++, {args.pnp_threads} host threads, overlapped with the next frame, all joined before the clock stops)")
-                            + "; backbone outside",
+                            + ("; backbone (HIP convolutions) inside, on a synthetic image" if args.with_backbone else "; backbone outside"),
             "pnp_inliers_per_frame": n_inliers,
             "streams": len(streams),
             "parallelism": f"frames sharded over {world} rank(s), one RCCL broadcast of weights + 3D block ({bcast_bytes} B)",

@@ -115,6 +115,27 @@ int ophip_fine_refine_bf16(const float* feat_f, long long fs_b, long long fs_c, 
                            int wc, int stride, float fine_scale, float* expec_f, float* mkpts_f,
                            float* dbg_win, float* dbg_f3, void* stream);
 
+/* Row f-1 -- ResNetFPN_8_2 image backbone (backbone/resnet.py:20-44 BasicBlock, :85-164; called at
+ * OnePosePlusModel.py:121-131) as implicit-GEMM convolutions on the bf16 matrix pipe.
+ * Feature maps between layers are channels-last bf16 plane pairs (hi, lo) [B][H][W][c_pad], c_pad = channels rounded up
+ * to 32 with zero padding; in plain-bf16 mode (nsplit 1) the lo pointers are unused.
+ *
+ * ophip_stem_conv7: conv1 7x7 stride 2 pad 3 (1 -> 128) + folded bn1 + ReLU (resnet.py:100-102,140), exact f32.
+ *   image [B][1][H][W] f32; wpack = folded weights [49][128] f32 then bias [128]; out planes [B][H/2][W/2][128].
+ * ophip_conv2d_bf16: one 3x3 / 1x1 convolution, stride 1 / 2, padding ks/2, no bias in the reference (BatchNorm is folded
+ *   into wpack on the host: packing.pack_conv_bf16, ophip_conv_wpack_bytes bytes = hi fragments | lo fragments | bias f32).
+ *   Epilogue in this order, each part optional: + bias, + residual planes (BasicBlock shortcut, resnet.py:41-43),
+ *   + bilinear x2 upsampling with align_corners=True of `up` [B][Hup][Wup][cout_pad] f32 (FPN top-down, resnet.py:155-160),
+ *   + `table` [Hout][Wout][cout_pad] f32 shared by all batch elements (the positional encoding of the coarse map, a1),
+ *   activation (0 none, 1 ReLU, 2 LeakyReLU 0.01), then planes (out_hi/out_lo) and / or f32 channels-last
+ *   out_f32 [B][Hout][Wout][out_c] (out_c <= cout_pad, multiple of 4). */
+size_t ophip_conv_wpack_bytes(int cin_pad, int cout_pad, int ks);
+int ophip_stem_conv7(const float* image, int B, int H, int W, const float* wpack, void* out_hi, void* out_lo, int nsplit, void* stream);
+int ophip_conv2d_bf16(const void* in_hi, const void* in_lo, int B, int Hin, int Win, int cin_pad,
+                      const void* wpack, int cout_pad, int ks, int stride, int act,
+                      const void* res_hi, const void* res_lo, const float* up, int Hup, int Wup, const float* table,
+                      void* out_hi, void* out_lo, float* out_f32, int out_c, int nsplit, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

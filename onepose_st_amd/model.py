@@ -13,9 +13,10 @@ Mirrors the reference interface (``src/models/OnePosePlus/OnePosePlusModel.py:24
 
 The ``nn`` sub-modules below only *hold parameters* under the reference's names; the
 arithmetic of rows a1-a11 is done by ``libonepose_hip.so`` through its C ABI
-(``include/onepose_hip.h``).  The ResNet-FPN backbone stays on PyTorch-ROCm
-(SURVEY.md section 8f-1).  There is no CPU fallback: calling the model without the HIP
-library or with CPU tensors raises.
+(``include/onepose_hip.h``).  The ResNet-FPN backbone runs on the
+hand-written convolution kernels as well (``backbone_hip.py``; ``config["hip_backbone"] = False``
+or the exact-f32 mode keep it on PyTorch-ROCm / MIOpen).  There is no CPU fallback: calling the
+model without the HIP library or with CPU tensors raises.
 """
 from __future__ import annotations
 
@@ -29,6 +30,7 @@ import torch.nn as nn
 
 from . import hip, host_math, packing
 from .backbone import build_backbone
+from .backbone_hip import HipBackbone, pack_backbone
 from .config import encoder_layer_names, validate_config
 
 
@@ -112,7 +114,10 @@ class OnePosePlus_model(nn.Module):
         self.precision = str(config.get("hip_precision", os.environ.get("OPHIP_PRECISION", "bf16x3")))
         if self.precision not in ("f32", "bf16x3", "bf16"):
             raise ValueError(f"hip_precision {self.precision!r}: expected 'f32', 'bf16x3' or 'bf16'")
+        # backbone on the HIP convolution kernels (bf16 pipe modes only; exact-f32 mode keeps MIOpen's fp32 convolutions)
+        self.hip_backbone = bool(config.get("hip_backbone", True)) and self.precision != "f32"
         self._packed = None          # (key, dict of device weight blocks)
+        self._packed_bb = None       # (key, backbone conv blocks)
         self._pe_cache = {}          # (h, w, device) -> [M, C] device table
 
         pretrained = config["loftr_backbone"]["pretrained"]
@@ -149,6 +154,13 @@ class OnePosePlus_model(nn.Module):
         self._packed = (key, blocks)
         return blocks
 
+    def _backbone_blocks(self, device):
+        tensors = list(self.backbone.state_dict().values())
+        key = (str(device),) + tuple((t.data_ptr(), t._version) for t in tensors)
+        if self._packed_bb is None or self._packed_bb[0] != key:
+            self._packed_bb = (key, pack_backbone(self.backbone.state_dict(), device))
+        return self._packed_bb[1]
+
     def _pe_table(self, h, w, device):
         k = (h, w, str(device))
         if k not in self._pe_cache:
@@ -160,15 +172,37 @@ class OnePosePlus_model(nn.Module):
     # ------------------------------------------------------------------------------------------
     def forward(self, data):
         """Same contract as the reference ``forward`` (OnePosePlusModel.py:95-203)."""
+        self.enqueue(data).finish()
+
+    def enqueue(self, data, host_copy=False):
+        """``forward`` without the final wait: backbone + rows a1-a11 enqueued on the current stream; returns the
+        :class:`PendingFrame` (see :meth:`enqueue_features`)."""
         if self.training:
             raise NotImplementedError("the HIP path implements inference; call .eval() (training padding "
                                       "of coarse_matching.py:177-217 is out of scope)")
         if "query_image_mask" in data or "query_image_scale" in data or "mask0" in data:
             raise NotImplementedError("query_image_mask / query_image_scale are not supported (img_pad: False path)")
         data.update({"bs": data["query_image"].size(0), "q_hw_i": data["query_image"].shape[2:]})
+        img = data["query_image"]
+        if self.hip_backbone:
+            feat_c, feat_f = self.backbone_features(img)
+            return self.enqueue_features(data, feat_c, feat_f, host_copy=host_copy, _pe_applied=True)
         with torch.no_grad():
-            feat_c, feat_f = self.backbone(data["query_image"])
-        self.forward_features(data, feat_c, feat_f)
+            feat_c, feat_f = self.backbone(img)
+        return self.enqueue_features(data, feat_c, feat_f, host_copy=host_copy)
+
+    def backbone_features(self, img):
+        """Row f-1 on the HIP convolution kernels: ``[B, 1, H, W]`` image -> ``(feat_c, feat_f)`` with the reference's
+        ``[B, C, h, w]`` shapes over channels-last memory; the positional encoding (row a1) is already added to ``feat_c``."""
+        if not self.hip_backbone:
+            raise RuntimeError("hip_backbone is disabled for this model (exact-f32 mode or config['hip_backbone'] = False)")
+        if not img.is_cuda:
+            raise hip.HipLibraryError("OnePosePlus_model runs on the HIP device only (no CPU fallback): move the "
+                                      "model and its inputs to 'cuda'")
+        B, _, H, W = img.shape
+        pe = self._pe_table(H // 8, W // 8, img.device) if self._pe_enable else None
+        fc, ff = HipBackbone(self.precision).forward(self._backbone_blocks(img.device), img, pe)
+        return (fc.view(B, H // 8, W // 8, fc.shape[2]).permute(0, 3, 1, 2), ff.view(B, H // 2, W // 2, ff.shape[2]).permute(0, 3, 1, 2))
 
     def forward_features(self, data, feat_c, feat_f, image_hw=None, want_fine_debug=False):
         """The north_star path: everything after the backbone.  ``feat_c [B,256,H/8,W/8]``,
@@ -176,7 +210,7 @@ class OnePosePlus_model(nn.Module):
         self.enqueue_features(data, feat_c, feat_f, image_hw, want_fine_debug).finish()
 
     @torch.no_grad()
-    def enqueue_features(self, data, feat_c, feat_f, image_hw=None, want_fine_debug=False, host_copy=False):
+    def enqueue_features(self, data, feat_c, feat_f, image_hw=None, want_fine_debug=False, host_copy=False, _pe_applied=False):
         """Enqueue the whole path for one batch on the current stream WITHOUT synchronising and return a
         :class:`PendingFrame`; ``.finish()`` waits for that frame only (an event, not the stream) and fills ``data``.
         A pipeline enqueues frame t + 1 before finishing frame t, so the GPU never idles on the host
@@ -219,9 +253,14 @@ class OnePosePlus_model(nn.Module):
                 raise ValueError(f"{name}: batch {t.shape[0]} does not match the query batch {B}")
 
         # ---- a1: positional encoding + flatten ------------------------------------------------
-        x2d = torch.empty(B, M, C, **f32)
-        pe = self._pe_table(hc, wc, dev) if self._pe_enable else None
-        lib_call("ophip_pe_add_transpose", P(dense(feat_c)), P(pe), P(x2d), B, C, M, S)
+        if _pe_applied:          # the HIP backbone wrote [B, M, C] with the encoding added; the encoder may reuse that buffer
+            x2d = feat_c.permute(0, 2, 3, 1).reshape(B, M, C)
+            if x2d.data_ptr() != feat_c.data_ptr() or not x2d.is_contiguous():
+                raise ValueError("internal: the HIP backbone's coarse map must be dense channels-last")
+        else:
+            x2d = torch.empty(B, M, C, **f32)
+            pe = self._pe_table(hc, wc, dev) if self._pe_enable else None
+            lib_call("ophip_pe_add_transpose", P(dense(feat_c)), P(pe), P(x2d), B, C, M, S)
         # ---- a2 + a3: keypoint encoding ---------------------------------------------------------
         x3d = torch.empty(B, N, C, **f32)
         if self.kpt_3d_pos_encoding is not None:

@@ -127,3 +127,40 @@ def pack_fine_layers_bf16(sd: dict, prefix: str, n_layers: int) -> torch.Tensor:
     out = torch.cat(blocks)
     assert out.numel() == n_layers * (2 * 2 * 10 * 128 * 128 + 16 * 128)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# backbone convolutions (csrc/conv.hip): BatchNorm folded in, weights as A-operand fragments in the order the kernel
+# walks K: (32-channel chunk, tap, 16-channel k-block)
+# ---------------------------------------------------------------------------------------------------
+def pad32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+def fold_bn(w: torch.Tensor, sd: dict, bn_prefix: str | None, eps: float = 1e-5):
+    """Eval-mode ``BatchNorm2d`` after a bias-free convolution: ``w * s``, ``beta - mean * s`` with ``s = gamma / sqrt(var + eps)``."""
+    w = w.detach().to(torch.float32).cpu()
+    if bn_prefix is None:
+        return w, torch.zeros(w.shape[0])
+    g, b = sd[bn_prefix + "weight"].float().cpu(), sd[bn_prefix + "bias"].float().cpu()
+    m, v = sd[bn_prefix + "running_mean"].float().cpu(), sd[bn_prefix + "running_var"].float().cpu()
+    s = g / torch.sqrt(v + eps)
+    return w * s.view(-1, 1, 1, 1), b - m * s
+
+
+def pack_conv_bf16(w: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """``[cout, cin, k, k]`` f32 (+ bias) -> bytes: hi fragments | lo fragments | bias f32 (``ophip_conv_wpack_bytes``)."""
+    cout, cin, k, _ = w.shape
+    cop, cip, T = pad32(cout), pad32(cin), k * k
+    wp = torch.zeros(cop, cip, T)
+    wp[:cout, :cin] = w.reshape(cout, cin, T)
+    wm = wp.view(cop, cip // 32, 2, 16, T).permute(0, 1, 4, 2, 3).reshape(cop, cip * T)      # K order: chunk, tap, k-block, 16
+    hi, lo = split_planes(pack_linear_frag16(wm))
+    bp = torch.zeros(cop)
+    bp[:cout] = bias
+    return _bytes(hi, lo, bp)
+
+
+def pack_stem(w: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """``[128, 1, 7, 7]`` folded stem weights -> f32 ``[49][128]`` followed by the bias."""
+    return torch.cat([w.reshape(w.shape[0], 49).t().contiguous().reshape(-1), bias.reshape(-1)]).to(torch.float32)
