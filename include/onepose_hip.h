@@ -136,6 +136,12 @@ int ophip_conv2d_bf16(const void* in_hi, const void* in_lo, int B, int Hin, int 
                       const void* res_hi, const void* res_lo, const float* up, int Hup, int Wup, const float* table,
                       void* out_hi, void* out_lo, float* out_f32, int out_c, int nsplit, void* stream);
 
+/* Row f-2 -- the query crop of the frame loop (local_feature_2D_detector.py:164-190 crop_img_by_bbox, called from
+ * detect :208-247 and previous_pose_detect :249-280): box [x0, y0, x1, y1) of a grayscale uint8 frame [H][W] -> out [S][S]
+ * float in [0, 1] (= the reference's two cv2.warpAffine passes + astype(float32) / 255: integer-shift crop, then isotropic
+ * bilinear resize by S / (x1 - x0) about the crop centre, zero border, rounded to uint8 levels). */
+int ophip_crop_resize_gray(const unsigned char* image, int H, int W, int x0, int y0, int x1, int y1, int S, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

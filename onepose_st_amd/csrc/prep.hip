@@ -223,7 +223,40 @@ __global__ __launch_bounds__(256) void transpose_c128_kernel(const float* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// query crop: bbox [x0, y0, x1, y1) of a full-resolution grayscale frame -> S x S float image in [0, 1]
+// (row f-2; local_feature_2D_detector.py:164-190 crop_img_by_bbox = two cv2.warpAffine calls: an integer-shift crop to the
+// box, then an isotropic resize by S / box_width about the crop centre with zero border).  One bilinear pass here.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void crop_resize_kernel(const unsigned char* __restrict__ img, int H, int W, int x0, int y0, int wb, int hb,
+                                                          int S, float* __restrict__ out) {
+    const int X = blockIdx.x * 32 + (threadIdx.x & 31), Y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (X >= S || Y >= S) return;
+    const float inv = (float)wb / (float)S;                    // 1 / scale of the second warp
+    const float u = ((float)X - 0.5f * (float)S) * inv + 0.5f * (float)wb;
+    const float v = ((float)Y - 0.5f * (float)S) * inv + 0.5f * (float)hb;
+    const float fu = floorf(u), fv = floorf(v);
+    const int i0 = (int)fu, j0 = (int)fv;
+    const float a = u - fu, b = v - fv;
+    auto px = [&](int i, int j) -> float {                     // the box crop with zeros outside it and outside the frame
+        if (i < 0 || i >= wb || j < 0 || j >= hb) return 0.f;
+        const int x = x0 + i, y = y0 + j;
+        return (x >= 0 && x < W && y >= 0 && y < H) ? (float)img[(size_t)y * W + x] : 0.f;
+    };
+    const float val = (1.f - b) * ((1.f - a) * px(i0, j0) + a * px(i0 + 1, j0)) + b * ((1.f - a) * px(i0, j0 + 1) + a * px(i0 + 1, j0 + 1));
+    out[(size_t)Y * S + X] = fminf(fmaxf(rintf(val), 0.f), 255.f) / 255.0f;      // cv2 writes uint8; astype(float32) / 255 is a true division
+}
+
 }  // namespace
+
+extern "C" int ophip_crop_resize_gray(const unsigned char* image, int H, int W, int x0, int y0, int x1, int y1, int S, float* out, void* stream) {
+    if (!image || !out) return ophip_bad_arg(__func__, "null pointer");
+    if (H < 1 || W < 1 || S < 1 || x1 <= x0 || y1 <= y0) return ophip_bad_arg(__func__, "bad sizes (need x1 > x0, y1 > y0)");
+    OPHIP_LAUNCH("crop_resize", (hipStream_t)stream, crop_resize_kernel, dim3((S + 31) / 32, (S + 7) / 8), dim3(256), 0, (hipStream_t)stream,
+                 image, H, W, x0, y0, x1 - x0, y1 - y0, S, out);
+    OPHIP_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int ophip_pe_add_transpose(const float* feat_nchw, const float* pe_nlc, float* out_nlc, int B, int C, int M, void* stream) {
     if (!feat_nchw || !out_nlc) return ophip_bad_arg(__func__, "null pointer");

@@ -46,6 +46,7 @@ _SIGNATURES = {
     "ophip_stem_conv7": (c_i, [c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_i, ctypes.c_void_p]),
     "ophip_conv2d_bf16": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_i, c_i, c_f,
                                 c_f, c_f, c_f, c_i, c_i, ctypes.c_void_p]),
+    "ophip_crop_resize_gray": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, ctypes.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
