@@ -45,26 +45,30 @@ struct ConvArgs {
 
 __device__ __forceinline__ int patch_off(int p, int c) { return p * PIXB + ((c ^ ((p >> 2) & 3)) << 4); }
 
-template <int KS, int STRIDE, int NS, int TH, int NT>
-__global__ __launch_bounds__(128) OPHIP_WAVES_PER_SIMD((TH * NT <= 4 && !(TH == 1 && NT == 2)) ? 3 : 2, (TH * NT >= 8) ? 2 : 3) void conv_mfma_kernel(ConvArgs a) {
+template <int KS, int STRIDE, int NS, int TH, int NT, int WR>
+__global__ __launch_bounds__(128 * WR) OPHIP_WAVES_PER_SIMD((TH * NT <= 4 && !(TH == 1 && NT == 2)) ? 3 : 2, (TH * NT >= 8) ? 2 : 3) void conv_mfma_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = KS * KS, PAD = KS / 2;
-    constexpr int PW = STRIDE * (TW - 1) + KS, PH = STRIDE * (TH - 1) + KS, PIX = PW * PH;
-    constexpr int WGT = 2 * NT;                      // 32-channel tiles per workgroup (2 waves x NT)
+    constexpr int ROWS = TH * WR;                    // output rows of the workgroup tile: WR wave rows of TH
+    constexpr int NTHR = 128 * WR;
+    constexpr int PW = STRIDE * (TW - 1) + KS, PH = STRIDE * (ROWS - 1) + KS, PIX = PW * PH;
+    constexpr int WGT = 2 * NT;                      // 32-channel tiles per workgroup (2 wave columns x NT)
     char* LH = smem;
     char* LL = smem + (NS == 3 ? PIX * PIXB : 0);
-    const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave & 1, wr = wave >> 1;         // wave column (channels) and wave row (pixel rows TH wr .. TH wr + TH - 1)
     const int r = lane & 31, h = lane >> 5;
     const int cgroups = (a.ctiles + WGT - 1) / WGT;
     const int b = blockIdx.z / cgroups, cg = blockIdx.z % cgroups;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * ROWS;
     const int ct0 = WGT * cg + NT * wc;              // this wave's first 32-channel tile
     const int S = a.ncc * T * 2;                     // k-blocks in a tile's weight stream
+    // tiles beyond the padded channel count (the last group of a 7-tile layer) are computed on a clamped weight tile and
+    // dropped in the epilogue: the k-loop stays one straight-line block (a wave-uniform branch around the MFMAs splits it
+    // into basic blocks and costs more than the idle tile)
     const bf16x8 *wh[NT], *wl[NT];
-    bool live[NT];                                   // wave-uniform: tiles beyond the padded channel count do nothing
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        live[t] = ct0 + t < a.ctiles;
         const int ct = min(ct0 + t, a.ctiles - 1);
         wh[t] = a.w_hi + (size_t)ct * S * 64 + lane;
         wl[t] = a.w_lo + (size_t)ct * S * 64 + lane;
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(128) OPHIP_WAVES_PER_SIMD((TH * NT <= 4 && !(TH == 
     for (int cc = 0; cc < a.ncc; ++cc) {
         __syncthreads();                             // everyone is done reading the previous chunk's image
         if (cc < 8) OPHIP_STAMP(a.stamps, wg, 1 + 3 * cc);
-        for (int i = tid; i < PIX * 4; i += 128) {
+        for (int i = tid; i < PIX * 4; i += NTHR) {
             const int p = i >> 2, c = i & 3;
             const int py = p / PW, px = p - py * PW;
             const int iy = iy0 + py, ix = ix0 + px;
@@ -109,36 +113,39 @@ __global__ __launch_bounds__(128) OPHIP_WAVES_PER_SIMD((TH * NT <= 4 && !(TH == 
         }
         __syncthreads();
         if (cc < 8) OPHIP_STAMP(a.stamps, wg, 2 + 3 * cc);
-#pragma unroll
-        for (int tap = 0; tap < T; ++tap) {
+        // activation fragments are read one k-block ahead (two register sets): the LDS round trip of step i + 1 runs under the
+        // MFMAs of step i
+        bf16x8 xh[2][TH], xl[2][TH];
+        auto read_x = [&](int step, int set) {
+            const int tap = step >> 1, kbl = step & 1;
             const int dy = tap / KS, dx = tap % KS;
 #pragma unroll
-            for (int kbl = 0; kbl < 2; ++kbl) {
-                bf16x8 xh[TH], xl[TH];
+            for (int tt = 0; tt < TH; ++tt) {
+                const int p = (STRIDE * (TH * wr + tt) + dy) * PW + STRIDE * r + dx;
+                const int off = patch_off(p, 2 * kbl + h);
+                xh[set][tt] = *reinterpret_cast<const bf16x8*>(LH + off);
+                xl[set][tt] = (NS == 3) ? *reinterpret_cast<const bf16x8*>(LL + off) : zero_bf8();
+            }
+        };
+        read_x(0, 0);
 #pragma unroll
-                for (int tt = 0; tt < TH; ++tt) {
-                    const int p = (STRIDE * tt + dy) * PW + STRIDE * r + dx;
-                    const int off = patch_off(p, 2 * kbl + h);
-                    xh[tt] = *reinterpret_cast<const bf16x8*>(LH + off);
-                    xl[tt] = (NS == 3) ? *reinterpret_cast<const bf16x8*>(LL + off) : zero_bf8();
-                }
+        for (int step = 0; step < 2 * T; ++step) {
+            const int kbl = step & 1, cur = step & 1;
+            if (step + 1 < 2 * T) read_x(step + 1, cur ^ 1);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int tt = 0; tt < TH; ++tt) acc[t][tt] = mma_bf16<NS>(rh[kbl][t], rl[kbl][t], xh[cur][tt], xl[cur][tt], acc[t][tt]);
+            {
+                const size_t nx = (size_t)min(s + 2, S - 1) * 64;        // the last two refills re-read the final k-block (unused)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    if (live[t]) {
-#pragma unroll
-                        for (int tt = 0; tt < TH; ++tt) acc[t][tt] = mma_bf16<NS>(rh[kbl][t], rl[kbl][t], xh[tt], xl[tt], acc[t][tt]);
-                    }
+                    rh[kbl][t] = wh[t][nx];
+                    if (NS == 3) rl[kbl][t] = wl[t][nx];
                 }
-                if (s + 2 < S) {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        rh[kbl][t] = wh[t][(size_t)(s + 2) * 64];
-                        if (NS == 3) rl[kbl][t] = wl[t][(size_t)(s + 2) * 64];
-                    }
-                }
-                ++s;
-                __builtin_amdgcn_sched_barrier(0);
             }
+            ++s;
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (cc < 8) OPHIP_STAMP(a.stamps, wg, 3 + 3 * cc);
     }
@@ -152,19 +159,22 @@ __global__ __launch_bounds__(128) OPHIP_WAVES_PER_SIMD((TH * NT <= 4 && !(TH == 
     constexpr int CH16 = WCH / 4;                    // 16-byte chunks per stage row
     char* stage = smem;
     const int cbase = 32 * WGT * cg;                 // first channel of the workgroup tile
-#pragma unroll
-    for (int tt = 0; tt < TH; ++tt) {
-        const int y = y0 + tt;
+    for (int row = 0; row < ROWS; ++row) {
+        const int y = y0 + row;
         __syncthreads();                             // the patch image / the previous row's stage is no longer read
-        if (y < a.Hout) {                            // block-uniform
+        if (y < a.Hout && row / TH == wr) {          // the wave row that owns this output row
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int tt = 0; tt < TH; ++tt) {
+                if (tt != row % TH) continue;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int ch = (32 * (NT * wc + t) + 8 * g + 4 * h) >> 2;
-                    const f32x4 v = {acc[t][tt][4 * g], acc[t][tt][4 * g + 1], acc[t][tt][4 * g + 2], acc[t][tt][4 * g + 3]};
-                    *reinterpret_cast<f32x4*>(stage + r * SROW + ((ch ^ (r & 15)) << 4)) = v;
-                }
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int ch = (32 * (NT * wc + t) + 8 * g + 4 * h) >> 2;
+                        const f32x4 v = {acc[t][tt][4 * g], acc[t][tt][4 * g + 1], acc[t][tt][4 * g + 2], acc[t][tt][4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(stage + r * SROW + ((ch ^ (r & 15)) << 4)) = v;
+                    }
+            }
         }
         __syncthreads();
         if (y >= a.Hout) continue;
@@ -176,7 +186,7 @@ __global__ __launch_bounds__(128) OPHIP_WAVES_PER_SIMD((TH * NT <= 4 && !(TH == 
             uy1 = uy0 + (uy0 < a.Hup - 1 ? 1 : 0);
             upy_l = fminf(fmaxf(fy - (float)uy0, 0.f), 1.f);
         }
-        for (int i = tid; i < 32 * CH16; i += 128) {
+        for (int i = tid; i < 32 * CH16; i += NTHR) {
             const int pr = i / CH16, q = i - pr * CH16;
             const int x = x0 + pr, c0 = cbase + 4 * q;
             if (x >= a.Wout || c0 >= a.cout_p) continue;
@@ -242,7 +252,7 @@ __global__ __launch_bounds__(128) OPHIP_WAVES_PER_SIMD((TH * NT <= 4 && !(TH == 
 // ---------------------------------------------------------------------------------------------
 // stem: 7x7 stride-2 convolution of the 1-channel image + folded BatchNorm + ReLU (resnet.py:100-102,140), exact f32 on
 // the vector ALU (0.3 % of the backbone's FLOPs; K = 49 is no MFMA shape).  A thread owns one output pixel: its 49
-// taps sit in registers, the folded weights are read from LDS as broadcasts, 16 channels at a time.
+// taps sit in registers, the folded weights are read from LDS as broadcasts, 8 channels at a time.
 // ---------------------------------------------------------------------------------------------
 struct StemArgs {
     const float* img;                // [B][H][W]
@@ -254,7 +264,7 @@ struct StemArgs {
 
 constexpr int SW = 2 * (TW - 1) + 7, SH = 2 * (8 - 1) + 7;       // 69 x 21 input patch of a 32 x 8 output tile
 
-__global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
+__global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(3, 4) void stem_kernel(StemArgs a) {
     __shared__ float patch[SH][SW + 1];
     __shared__ __attribute__((aligned(16))) float wl[49 * 128 + 128];      // folded weights [tap][channel] + bias: broadcast reads
     const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
@@ -275,48 +285,45 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
     const int x = x0 + tx, y = y0 + ty;
     if (x >= a.Wout || y >= a.Hout) return;
     const size_t pix = ((size_t)b * a.Hout + y) * a.Wout + x;
-    for (int cg = 0; cg < 8; ++cg) {                 // 16 channels at a time
-        f32x4 acc[4];
+    for (int cg = 0; cg < 16; ++cg) {                // 8 channels at a time: 49 taps + 8 accumulators keep 3 waves per SIMD resident
+        f32x4 acc[2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = *reinterpret_cast<const f32x4*>(wl + 49 * 128 + 16 * cg + 4 * q);
+        for (int q = 0; q < 2; ++q) acc[q] = *reinterpret_cast<const f32x4*>(wl + 49 * 128 + 8 * cg + 4 * q);
 #pragma unroll
         for (int t = 0; t < 49; ++t) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wl + t * 128 + 16 * cg + 4 * q);
+            for (int q = 0; q < 2; ++q) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wl + t * 128 + 8 * cg + 4 * q);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[q][j] = fmaf(w4[j], v[t], acc[q][j]);
             }
         }
+        bf16x8 vh, vl;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            bf16x8 vh, vl;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                __bf16 hh, ll;
-                split_bf16(fmaxf(acc[2 * q + (j >> 2)][j & 3], 0.f), hh, ll);
-                vh[j] = hh; vl[j] = ll;
-            }
-            *reinterpret_cast<bf16x8*>(a.out_hi + pix * 128 + 16 * cg + 8 * q) = vh;
-            if (a.nsplit == 3) *reinterpret_cast<bf16x8*>(a.out_lo + pix * 128 + 16 * cg + 8 * q) = vl;
+        for (int j = 0; j < 8; ++j) {
+            __bf16 hh, ll;
+            split_bf16(fmaxf(acc[j >> 2][j & 3], 0.f), hh, ll);
+            vh[j] = hh; vl[j] = ll;
         }
+        *reinterpret_cast<bf16x8*>(a.out_hi + pix * 128 + 8 * cg) = vh;
+        if (a.nsplit == 3) *reinterpret_cast<bf16x8*>(a.out_lo + pix * 128 + 8 * cg) = vl;
     }
 }
 
-template <int KS, int STRIDE, int NS, int TH, int NT>
+template <int KS, int STRIDE, int NS, int TH, int NT, int WR>
 int launch_conv_tile(const ConvArgs& a, int B, hipStream_t stream) {
-    constexpr int PW = STRIDE * (TW - 1) + KS, PH = STRIDE * (TH - 1) + KS;
+    constexpr int PW = STRIDE * (TW - 1) + KS, PH = STRIDE * (TH * WR - 1) + KS;
     size_t lds = (size_t)(NS == 3 ? 2 : 1) * PW * PH * PIXB;
     const size_t stage = (size_t)32 * 64 * NT * 4;           // one output row of the workgroup tile in f32
     if (stage > lds) lds = stage;
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<KS, STRIDE, NS, TH, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<KS, STRIDE, NS, TH, NT, WR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return ophip_fail(e, "hipFuncSetAttribute(conv_mfma)");
         attr = true;
     }
-    const dim3 grid((a.Wout + TW - 1) / TW, (a.Hout + TH - 1) / TH, B * ((a.ctiles + 2 * NT - 1) / (2 * NT)));
-    OPHIP_LAUNCH("conv", stream, (conv_mfma_kernel<KS, STRIDE, NS, TH, NT>), grid, dim3(128), lds, stream, a);
+    const dim3 grid((a.Wout + TW - 1) / TW, (a.Hout + TH * WR - 1) / (TH * WR), B * ((a.ctiles + 2 * NT - 1) / (2 * NT)));
+    OPHIP_LAUNCH("conv", stream, (conv_mfma_kernel<KS, STRIDE, NS, TH, NT, WR>), grid, dim3(128 * WR), lds, stream, a);
     OPHIP_CHECK_LAUNCH();
     return 0;
 }
@@ -337,20 +344,25 @@ int launch_conv(const ConvArgs& a, int B, hipStream_t stream) {
         if (w22 < 2000) nt = 1;
         if (2 * w22 < 2000) th = 1;
     } else if (KS == 3) {
-        if (w22 < 1000) { th = 1; nt = 1; }
+        if (w22 < 2000) th = 1;
+        if (w22 < 1000) nt = 1;
     } else if (w22 < 2000) {
         th = 1;
     }
     if (th_env == 1 || th_env == 2 || th_env == 4) th = th_env;
     if (nt_env == 1 || nt_env == 2) nt = nt_env;
-    if (nt == 2) {
-        if (th == 4) return launch_conv_tile<KS, STRIDE, NS, 4, 2>(a, B, stream);
-        if (th == 2) return launch_conv_tile<KS, STRIDE, NS, 2, 2>(a, B, stream);
-        return launch_conv_tile<KS, STRIDE, NS, 1, 2>(a, B, stream);
-    }
-    if (th == 4) return launch_conv_tile<KS, STRIDE, NS, 4, 1>(a, B, stream);
-    if (th == 2) return launch_conv_tile<KS, STRIDE, NS, 2, 1>(a, B, stream);
-    return launch_conv_tile<KS, STRIDE, NS, 1, 1>(a, B, stream);
+    // wave rows per workgroup: 2 (a 4-wave workgroup on a shared patch: halo 1.6x instead of 2.1x at TH = 2) when the map is
+    // tall enough to keep the grid full; OPHIP_CONV_WR forces it
+    static const int wr_env = [] { const char* e = getenv("OPHIP_CONV_WR"); return e ? atoi(e) : 0; }();
+    int wrows = (th <= 2 && KS == 3 && STRIDE == 1 && w22 >= 2000) ? 2 : 1;
+    if (wr_env == 1 || wr_env == 2) wrows = wr_env;
+    if (th == 4) wrows = 1;
+#define OPHIP_CONV_CASE(TH_, NT_, WR_) if (th == TH_ && nt == NT_ && wrows == WR_) return launch_conv_tile<KS, STRIDE, NS, TH_, NT_, WR_>(a, B, stream);
+    OPHIP_CONV_CASE(4, 2, 1) OPHIP_CONV_CASE(4, 1, 1)
+    OPHIP_CONV_CASE(2, 2, 1) OPHIP_CONV_CASE(2, 1, 1) OPHIP_CONV_CASE(1, 2, 1) OPHIP_CONV_CASE(1, 1, 1)
+    OPHIP_CONV_CASE(2, 2, 2) OPHIP_CONV_CASE(2, 1, 2) OPHIP_CONV_CASE(1, 2, 2) OPHIP_CONV_CASE(1, 1, 2)
+#undef OPHIP_CONV_CASE
+    return ophip_bad_arg("ophip_conv2d_bf16", "no kernel for this tile shape");
 }
 
 }  // namespace
