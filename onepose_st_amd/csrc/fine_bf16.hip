@@ -105,6 +105,20 @@ __global__ __launch_bounds__(NM * 256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_refi
     const int r = lane & 31, h = lane >> 5;
     OPHIP_STAMP(p.stamps, blockIdx.x, 0);
 
+    const int nl = p.enc_enable ? p.nlayers : 0;
+    constexpr size_t LAYER_BYTES = (size_t)2 * W_ELEMS * 2 + 4 * CF * 4;
+    // plane offsets in fragments: Wq | Wkv (per feature tile: K tile, V tile) | Wm | W0 | W2
+    constexpr int OQ = 0, OKV = CF * CF / 8, OM = 3 * CF * CF / 8, O0 = 4 * CF * CF / 8, O2 = 8 * CF * CF / 8;
+    // the first layer's Q / K|V weight fragments do not depend on the match: they travel under the gather below
+    WRing<1, 2, NS> rq;
+    WRing<2, 2, NS> rkv;
+    if (nl > 0) {
+        const bf16x8* w_hi = reinterpret_cast<const bf16x8*>(p.wpack);
+        const bf16x8* w_lo = w_hi + W_ELEMS / 8;
+        rq.fill(w_hi + OQ + (size_t)ft * TS + lane, w_lo + OQ + (size_t)ft * TS + lane, TS);
+        rkv.fill(w_hi + OKV + (size_t)(2 * ft) * TS + lane, w_lo + OKV + (size_t)(2 * ft) * TS + lane, TS);
+    }
+
     // ---- gather both matches into the f32 staging image --------------------------------------------
     // every load of both matches is issued before the first LDS write, so their latencies overlap
     // (named scalars + selects: a runtime-indexed array would live in scratch)
@@ -119,25 +133,25 @@ __global__ __launch_bounds__(NM * 256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_refi
 #define MCY(mi) ((mi) ? cy1 : cy0)
 #define MCX(mi) ((mi) ? cx1 : cx0)
     if (p.fs_c == 1) {                   // channels-last: 512 B contiguous per pixel; 2 x 25 x 128 elements / 512 threads
-        constexpr int PER = (NM * WIN * CF + NT_ - 1) / NT_;
-        float v[PER];
+        constexpr int NQ = NM * WIN * (CF / 4), PER = (NQ + NT_ - 1) / NT_;      // float4 items: (match, window row, 4 channels)
+        f32x4 v[PER];
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int e = tid + NT_ * u;
-            v[u] = 0.f;
-            if (e < NM * WIN * CF) {
-                const int mi = e / (WIN * CF), e2 = e % (WIN * CF), rr = e2 >> 7, c = e2 & 127;
+            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (e < NQ) {
+                const int mi = e / (WIN * (CF / 4)), e2 = e % (WIN * (CF / 4)), rr = e2 >> 5, c4 = e2 & 31;
                 const int y = MCY(mi) + rr / 5 - 2, x = MCX(mi) + rr % 5 - 2;
                 if (MLIVE(mi) && y >= 0 && y < p.hf && x >= 0 && x < p.wf)
-                    v[u] = p.feat_f[(size_t)MB(mi) * p.fs_b + (size_t)y * p.fs_y + (size_t)x * p.fs_x + c];
+                    v[u] = *reinterpret_cast<const f32x4*>(p.feat_f + (size_t)MB(mi) * p.fs_b + (size_t)y * p.fs_y + (size_t)x * p.fs_x + 4 * c4);
             }
         }
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int e = tid + NT_ * u;
-            if (e < NM * WIN * CF) {
-                const int mi = e / (WIN * CF), e2 = e % (WIN * CF), rr = e2 >> 7, c = e2 & 127;
-                *reinterpret_cast<float*>(stage + stage_off(32 * mi + rr, c >> 2) + 4 * (c & 3)) = v[u];
+            if (e < NQ) {
+                const int mi = e / (WIN * (CF / 4)), e2 = e % (WIN * (CF / 4)), rr = e2 >> 5, c4 = e2 & 31;
+                *reinterpret_cast<f32x4*>(stage + stage_off(32 * mi + rr, c4)) = v[u];
             }
         }
     } else {                             // NCHW: one (match, channel, window row) run of 5 consecutive x per slot
@@ -192,10 +206,6 @@ __global__ __launch_bounds__(NM * 256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_refi
     store_featrow_acc<NS>(xres, XH, XL, ROWB, 32 * ft, 32 * tt, lane);
     __syncthreads();
 
-    const int nl = p.enc_enable ? p.nlayers : 0;
-    constexpr size_t LAYER_BYTES = (size_t)2 * W_ELEMS * 2 + 4 * CF * 4;
-    // plane offsets in fragments: Wq | Wkv (per feature tile: K tile, V tile) | Wm | W0 | W2
-    constexpr int OQ = 0, OKV = CF * CF / 8, OM = 3 * CF * CF / 8, O0 = 4 * CF * CF / 8, O2 = 8 * CF * CF / 8;
     const bf16x8 zeros = zero_bf8();
     bf16x8 ones;
 #pragma unroll
@@ -205,14 +215,6 @@ __global__ __launch_bounds__(NM * 256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_refi
     const char* yh = YH + 32 * tt * ROWB; const char* yl = YL + 32 * tt * ROWB;
     const char* hh = HH + 32 * tt * HROWB; const char* hl = HL + 32 * tt * HROWB;
 
-    WRing<1, 2, NS> rq;
-    WRing<2, 2, NS> rkv;
-    if (nl > 0) {
-        const bf16x8* w_hi = reinterpret_cast<const bf16x8*>(p.wpack);
-        const bf16x8* w_lo = w_hi + W_ELEMS / 8;
-        rq.fill(w_hi + OQ + (size_t)ft * TS + lane, w_lo + OQ + (size_t)ft * TS + lane, TS);
-        rkv.fill(w_hi + OKV + (size_t)(2 * ft) * TS + lane, w_lo + OKV + (size_t)(2 * ft) * TS + lane, TS);
-    }
     for (int l = 0; l < nl; ++l) {
         const char* wl = p.wpack + (size_t)l * LAYER_BYTES;
         const bf16x8* w_hi = reinterpret_cast<const bf16x8*>(wl);
@@ -416,6 +418,8 @@ extern "C" int ophip_fine_refine_bf16(const float* feat_f, long long fs_b, long 
         return ophip_bad_arg(__func__, "null pointer");
     if (encoder_enable && (!wpack || nlayers < 1 || nlayers > 32)) return ophip_bad_arg(__func__, "encoder enabled without weights");
     if (nsplit != 1 && nsplit != 3) return ophip_bad_arg(__func__, "nsplit must be 1 (bf16) or 3 (split bf16)");
+    if (fs_c == 1 && ((reinterpret_cast<uintptr_t>(feat_f) & 15) || (fs_b & 3) || (fs_y & 3) || (fs_x & 3)))
+        return ophip_bad_arg(__func__, "channels-last feat_f needs 16-byte aligned pixels (strides multiples of 4 floats)");
     if ((dbg_win == nullptr) != (dbg_f3 == nullptr)) return ophip_bad_arg(__func__, "dbg_win and dbg_f3 go together");
     if (max_matches <= 0) return 0;
     FineBArgs a;
