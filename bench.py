@@ -151,9 +151,17 @@ def main():
 
     inflight = []
 
+    host_t = {"enqueue": 0.0, "wait": 0.0, "finish": 0.0, "submit": 0.0}       # host-side seconds, printed with OPHIP_BENCH_TRACE=1
+
     def complete(pend):
         """finish one frame (waits on ITS event only) and hand its matches to the host PnP pool"""
+        t = time.perf_counter()
+        pend.event.synchronize()
+        host_t["wait"] += time.perf_counter() - t
+        t = time.perf_counter()
         data = pend.finish()
+        host_t["finish"] += time.perf_counter() - t
+        t = time.perf_counter()
         if pool is not None:
             hst = pend.host
             if B == 1:
@@ -162,6 +170,7 @@ def main():
                 for bb in range(B):
                     sel = hst["b_ids"] == bb
                     pending.append(pool.submit(hst["mkpts_2d"][sel], hst["mkpts_3d_db"][sel]))
+        host_t["submit"] += time.perf_counter() - t
         return data
 
     # frames alternate over `--streams` HIP streams: consecutive frames are independent, so the single-workgroup
@@ -173,10 +182,12 @@ def main():
     def step(i):
         """enqueue batch i, then finish batch i - len(streams): the GPU always has queued work"""
         fc, ff = batches[i % len(batches)]
+        t = time.perf_counter()
         with torch.cuda.stream(streams[i % len(streams)]):
             if image is not None:
                 model.backbone_features(image)
             inflight.append(model.enqueue_features(dict(obj_b), fc, ff, image_hw, host_copy=pool is not None))
+        host_t["enqueue"] += time.perf_counter() - t
         if len(inflight) > len(streams):
             return complete(inflight.pop(0))
         return None
@@ -213,6 +224,8 @@ def main():
         st.synchronize()
     hip.timing_select("attn_apply")
     sync_all()
+    for k in host_t:
+        host_t[k] = 0.0
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -220,6 +233,8 @@ def main():
     join_poses()
     sync_all()
     dt = time.perf_counter() - t0
+    if os.environ.get("OPHIP_BENCH_TRACE") and rank == 0:
+        print("host us/step: " + ", ".join(f"{k} {1e6 * v / args.steps:.0f}" for k, v in host_t.items()) + f"; wall {1e6 * dt / args.steps:.0f}", file=sys.stderr)
     launches, kern_ms = hip.timing_read()
     hip.timing_select("")
     if world > 1:

@@ -369,6 +369,7 @@ class PendingFrame:
     """A batch whose kernels are enqueued but whose match count has not been read yet."""
 
     _pinned_pool = {}
+    _copy_streams = {}          # (device, compute stream) -> side stream for the result read-back
 
     def __init__(self, model, data, dev, B, N, M, cap, fine_on, want_dbg, bufs, host_copy):
         self.model, self.data, self.dev = model, data, dev
@@ -380,9 +381,19 @@ class PendingFrame:
         nbytes = bufs["blob"].numel() if host_copy else 16
         self._pin = pool.pop() if pool else torch.empty(nbytes, dtype=torch.uint8).pin_memory()
         self._key, self._host_copy = key, bool(host_copy)
-        self._pin.copy_(bufs["blob"][:nbytes], non_blocking=True)
+        # the D2H of the result block runs on a side stream behind an event: on the compute stream the PCIe round trip
+        # (~40 us per frame) would sit between this frame's last kernel and the next frame's first one
+        main = torch.cuda.current_stream(dev)
+        side = PendingFrame._copy_streams.get((dev, main.cuda_stream))
+        if side is None:
+            side = PendingFrame._copy_streams[(dev, main.cuda_stream)] = torch.cuda.Stream(device=dev)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        side.wait_event(ready)
         self.event = torch.cuda.Event()
-        self.event.record()
+        with torch.cuda.stream(side):
+            self._pin.copy_(bufs["blob"][:nbytes], non_blocking=True)      # bufs (kept until finish) outlive the copy
+            self.event.record(side)
         self.done = False
 
     def finish(self):
