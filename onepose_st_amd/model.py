@@ -118,6 +118,11 @@ class OnePosePlus_model(nn.Module):
         self.hip_backbone = bool(config.get("hip_backbone", True)) and self.precision != "f32"
         self._packed = None          # (key, dict of device weight blocks)
         self._packed_bb = None       # (key, backbone conv blocks)
+        # fine stage (+ result read-back) on a second HIP stream: frame t's refinement then overlaps frame t + 1's input
+        # kernels (PE add, transposes, keypoint encoding, backbone); frame t + 1's encoder waits for it, so the two
+        # MFMA-heavy stages never share the chip
+        self.overlap_fine = bool(config.get("hip_overlap_fine", True))
+        self._fine_streams = {}      # (device, compute stream) -> (fine stream, last fine-done event)
         self._pe_cache = {}          # (h, w, device) -> [M, C] device table
 
         pretrained = config["loftr_backbone"]["pretrained"]
@@ -214,7 +219,8 @@ class OnePosePlus_model(nn.Module):
         """Enqueue the whole path for one batch on the current stream WITHOUT synchronising and return a
         :class:`PendingFrame`; ``.finish()`` waits for that frame only (an event, not the stream) and fills ``data``.
         A pipeline enqueues frame t + 1 before finishing frame t, so the GPU never idles on the host
-        (``bench.py``).  ``host_copy=True`` also queues the D2H of the match buffers into pinned memory, which
+        (``bench.py``).  The fine stage runs on a second stream (``config["hip_overlap_fine"]``, default on): the inputs
+        must stay unmodified until ``finish()``.  ``host_copy=True`` also queues the D2H of the match buffers into pinned memory, which
         ``finish()`` exposes as numpy arrays (``pending.host``) for host PnP."""
         if not feat_c.is_cuda:
             raise hip.HipLibraryError("OnePosePlus_model runs on the HIP device only (no CPU fallback): move the "
@@ -261,6 +267,18 @@ class OnePosePlus_model(nn.Module):
             x2d = torch.empty(B, M, C, **f32)
             pe = self._pe_table(hc, wc, dev) if self._pe_enable else None
             lib_call("ophip_pe_add_transpose", P(dense(feat_c)), P(pe), P(x2d), B, C, M, S)
+        # ---- fine map to channels-last (input kernel of the fine stage; here so that it runs under the previous frame's
+        #      fine stage instead of in front of this frame's) ------------------------------------------------------
+        ff = ff_strides = None
+        if bool(cfg["fine_matching"]["enable"]):
+            ff = feat_f if feat_f.dtype == torch.float32 else feat_f.float()
+            if ff.stride(1) == 1:                      # channels-last memory already: strides as they are
+                ff_strides = (ff.stride(0), 1, ff.stride(2), ff.stride(3))
+            else:                                      # NCHW: one streaming transpose, then every window pixel is a 512-byte row
+                ff = ff.contiguous()
+                ff_cl = torch.empty(B, hf * wf, ff.shape[1], **f32)
+                lib_call("ophip_transpose_cl", P(ff), P(ff_cl), B, ff.shape[1], hf * wf, S)
+                ff, ff_strides = ff_cl, (hf * wf * ff_cl.shape[2], 1, wf * ff_cl.shape[2], ff_cl.shape[2])
         # ---- a2 + a3: keypoint encoding ---------------------------------------------------------
         x3d = torch.empty(B, N, C, **f32)
         if self.kpt_3d_pos_encoding is not None:
@@ -271,8 +289,15 @@ class OnePosePlus_model(nn.Module):
             src = desc_in_d if desc_in_d.shape[0] == B else desc_in_d.expand(B, -1, -1).contiguous()
             lib_call("ophip_transpose_cl", P(src), P(x3d), B, C, N, S)
         # ---- a4-a6: coarse encoder ----------------------------------------------------------------
+        main = torch.cuda.current_stream(dev)
+        fkey = (str(dev), main.cuda_stream)
         y3d, y2d = torch.empty_like(x3d), torch.empty_like(x2d)
+
+        def wait_previous_fine():                                 # the previous frame's fine stage is done
+            if self.overlap_fine and fkey in self._fine_streams and self._fine_streams[fkey][1] is not None:
+                main.wait_event(self._fine_streams[fkey][1])
         if self.precision == "f32":
+            wait_previous_fine()
             ws = torch.empty(hip.load().ophip_encoder_workspace_floats(B, N, M), **f32)
             for li, name in enumerate(self.loftr_coarse.layer_names):
                 lib_call("ophip_encoder_layer", P(x3d), P(x2d), P(y3d), P(y2d), B, N, M, P(W["coarse"][li]),
@@ -285,6 +310,8 @@ class OnePosePlus_model(nn.Module):
             for li, name in enumerate(names_c):
                 # layer li's attn_apply also emits layer li+1's K/V partial slabs from the on-chip output tile
                 nxt = W["coarse_bf16"][li + 1] if li + 1 < len(names_c) else None
+                if li == 0:
+                    wait_previous_fine()                          # attn_apply, the roofline kernel, never shares the chip with fine
                 lib_call("ophip_encoder_layer_bf16", P(x3d), P(x2d), P(y3d), P(y2d), B, N, M, P(W["coarse_bf16"][li], None), P(nxt, None),
                          nsplit, 1 if name == "cross" else 0, 1 if li > 0 else 0, li & 1, P(ws, None), S)
                 x3d, y3d, x2d, y2d = y3d, x3d, y2d, x2d
@@ -312,45 +339,54 @@ class OnePosePlus_model(nn.Module):
                      {"f32": 0, "bf16": 1, "bf16x3": 3}[self.precision], S)
         data["conf_matrix"] = conf
 
-        if fine_on:
-            # ---- a9-a11: fine refinement (grid sized by capacity, device-side count: no sync yet) ----
-            cf = cfg["loftr_fine"]
-            expec = torch.empty(cap, 3, **f32)
-            mkf = mk2d
-            dbg_w = torch.empty(cap, 25, 128, **f32) if want_fine_debug else None
-            dbg_3 = torch.empty(cap, 128, **f32) if want_fine_debug else None
-            names_f = self.loftr_fine.layer_names
-            cross_bits = sum(1 << i for i, n in enumerate(names_f) if n == "cross")
-            ff = feat_f if feat_f.dtype == torch.float32 else feat_f.float()
-            if ff.stride(1) == 1:                      # channels-last memory already: strides as they are
-                ff_strides = (ff.stride(0), 1, ff.stride(2), ff.stride(3))
-            else:                                      # NCHW: one streaming transpose, then every window pixel is a 512-byte row
-                ff = ff.contiguous()
-                ff_cl = torch.empty(B, hf * wf, ff.shape[1], **f32)
-                lib_call("ophip_transpose_cl", P(ff), P(ff_cl), B, ff.shape[1], hf * wf, S)
-                ff, ff_strides = ff_cl, (hf * wf * ff_cl.shape[2], 1, wf * ff_cl.shape[2], ff_cl.shape[2])
-            stride = hf // hc
-            fine_scale = (cf["window_size"] // 2) * (data["q_hw_i"][0] / hf)
-            max_matches = min(cap, B * min(N, M) + 64)      # mutual matches are one per row and (barring exact ties) per column
-            if self.precision == "f32":
-                lib_call("ophip_fine_refine", P(ff), *ff_strides, hf, wf,
-                         P(desc_fine_d), bstride(desc_fine_d), desc_fine_d.stride(1),
-                         P(b_ids, torch.int64), P(i_ids, torch.int64), P(j_ids, torch.int64), P(count, torch.int32), max_matches,
-                         P(mkc), P(W["fine"]), len(names_f), ctypes.c_uint(cross_bits), 1 if cf["enable"] else 0,
-                         wc, stride, float(fine_scale), P(expec), P(mkf), P(dbg_w), P(dbg_3), S)
-            else:
-                lib_call("ophip_fine_refine_bf16", P(ff), *ff_strides, hf, wf,
-                         P(desc_fine_d), bstride(desc_fine_d), desc_fine_d.stride(1),
-                         P(b_ids, torch.int64), P(i_ids, torch.int64), P(j_ids, torch.int64), P(count, torch.int32), max_matches,
-                         P(mkc), P(W["fine_bf16"], None), len(names_f), ctypes.c_uint(cross_bits), 1 if cf["enable"] else 0,
-                         3 if self.precision == "bf16x3" else 1,
-                         wc, stride, float(fine_scale), P(expec), P(mkf), P(dbg_w), P(dbg_3), S)
+        fine_ctx = contextlib.nullcontext()
+        if fine_on and self.overlap_fine:
+            if fkey not in self._fine_streams:
+                self._fine_streams[fkey] = [torch.cuda.Stream(device=dev), None]
+            sfine = self._fine_streams[fkey][0]
+            coarse_done = torch.cuda.Event()
+            coarse_done.record(main)
+            sfine.wait_event(coarse_done)
+            fine_ctx = torch.cuda.stream(sfine)
+        keep = [desc_fine_d, W]      # inputs of the side-stream kernels stay referenced until finish()
+        with fine_ctx:
+            S = hip.stream_handle()
+            if fine_on:
+                # ---- a9-a11: fine refinement (grid sized by capacity, device-side count: no sync yet) ----
+                cf = cfg["loftr_fine"]
+                expec = torch.empty(cap, 3, **f32)
+                mkf = mk2d
+                dbg_w = torch.empty(cap, 25, 128, **f32) if want_fine_debug else None
+                dbg_3 = torch.empty(cap, 128, **f32) if want_fine_debug else None
+                names_f = self.loftr_fine.layer_names
+                cross_bits = sum(1 << i for i, n in enumerate(names_f) if n == "cross")
+                keep.append(ff)
+                stride = hf // hc
+                fine_scale = (cf["window_size"] // 2) * (data["q_hw_i"][0] / hf)
+                max_matches = min(cap, B * min(N, M) + 64)      # mutual matches are one per row and (barring exact ties) per column
+                if self.precision == "f32":
+                    lib_call("ophip_fine_refine", P(ff), *ff_strides, hf, wf,
+                             P(desc_fine_d), bstride(desc_fine_d), desc_fine_d.stride(1),
+                             P(b_ids, torch.int64), P(i_ids, torch.int64), P(j_ids, torch.int64), P(count, torch.int32), max_matches,
+                             P(mkc), P(W["fine"]), len(names_f), ctypes.c_uint(cross_bits), 1 if cf["enable"] else 0,
+                             wc, stride, float(fine_scale), P(expec), P(mkf), P(dbg_w), P(dbg_3), S)
+                else:
+                    lib_call("ophip_fine_refine_bf16", P(ff), *ff_strides, hf, wf,
+                             P(desc_fine_d), bstride(desc_fine_d), desc_fine_d.stride(1),
+                             P(b_ids, torch.int64), P(i_ids, torch.int64), P(j_ids, torch.int64), P(count, torch.int32), max_matches,
+                             P(mkc), P(W["fine_bf16"], None), len(names_f), ctypes.c_uint(cross_bits), 1 if cf["enable"] else 0,
+                             3 if self.precision == "bf16x3" else 1,
+                             wc, stride, float(fine_scale), P(expec), P(mkf), P(dbg_w), P(dbg_3), S)
 
-        pend = PendingFrame(self, data, dev, B, N, M, cap, fine_on, want_fine_debug,
-                            dict(blob=blob, b_ids=b_ids, i_ids=i_ids, j_ids=j_ids, mconf=mconf, mk3d=mk3d, mkc=mkc, count=count,
-                                 m_bids=m_bids, gt_mask=gt_mask,
-                                 expec=expec if fine_on else None, mkf=mkf if fine_on else None,
-                                 dbg_w=dbg_w if fine_on else None, dbg_3=dbg_3 if fine_on else None), host_copy)
+            if fine_on and self.overlap_fine:
+                fine_done = torch.cuda.Event()
+                fine_done.record()
+                self._fine_streams[fkey][1] = fine_done
+            pend = PendingFrame(self, data, dev, B, N, M, cap, fine_on, want_fine_debug,
+                                dict(blob=blob, b_ids=b_ids, i_ids=i_ids, j_ids=j_ids, mconf=mconf, mk3d=mk3d, mkc=mkc, count=count,
+                                     m_bids=m_bids, gt_mask=gt_mask,
+                                     expec=expec if fine_on else None, mkf=mkf if fine_on else None,
+                                     dbg_w=dbg_w if fine_on else None, dbg_3=dbg_3 if fine_on else None, keep=keep), host_copy)
         return pend
 
 
