@@ -485,3 +485,44 @@ def test_fine_disabled_and_encoder_disabled(sd, cfg, dev):
         ref = orc.forward_from_features(sd, c3, inp, inp["feat_c"], inp["feat_f"], inp["image_hw"])
     assert torch.equal(d3["i_ids"].cpu(), ref["i_ids"])
     close(d3["mkpts_query_f"], ref["mkpts_query_f"])
+
+
+def test_pipelined_frames_match_sequential_runs(model, sd, cfg, dev):
+    """Several frames in flight (fine stage and read-back on side streams, frame t + 1's input kernels under frame t's
+    refinement), finished out of order: every frame is bit-identical to its own stand-alone run, with the fine overlap on and
+    off, and the host copies of the read-back block equal the device tensors."""
+    frames = [make_synthetic_inputs(sd, n_points=1500, image_hw=(160, 224), n_plant=500, seed=21, config=cfg, frame=f) for f in range(4)]
+    obj = {k: frames[0][k].to(dev) for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db")}
+    feats = [(f["feat_c"].to(dev), f["feat_f"].to(dev)) for f in frames]
+    keys = ("i_ids", "j_ids", "mconf", "mkpts_query_c", "mkpts_query_f", "expec_f", "mkpts_3d_db", "m_bids", "gt_mask")
+    alone = []
+    for fc, ff in feats:
+        d = dict(obj)
+        model.enqueue_features(d, fc, ff, frames[0]["image_hw"]).finish()
+        torch.cuda.synchronize()
+        alone.append({k: d[k].clone() for k in keys})
+    assert len(alone[0]["i_ids"]) > 300 and not torch.equal(alone[0]["j_ids"], alone[1]["j_ids"])
+    for rep in range(3):
+        pend, datas = [], []
+        for fc, ff in feats:
+            d = dict(obj)
+            datas.append(d)
+            pend.append(model.enqueue_features(d, fc, ff, frames[0]["image_hw"], host_copy=True))
+        for idx in (2, 0, 3, 1):
+            pend[idx].finish()
+        for d, p, ref in zip(datas, pend, alone):
+            for k in keys:
+                assert torch.equal(d[k], ref[k]), (rep, k)
+            K = len(ref["i_ids"])
+            assert p.host["K"] == K
+            np.testing.assert_array_equal(p.host["mkpts_2d"], ref["mkpts_query_f"].cpu().numpy())
+            np.testing.assert_array_equal(p.host["mkpts_3d_db"], ref["mkpts_3d_db"].cpu().numpy())
+    saved = model.overlap_fine
+    try:
+        model.overlap_fine = False
+        d = dict(obj)
+        model.enqueue_features(d, *feats[1], frames[0]["image_hw"]).finish()
+        for k in keys:
+            assert torch.equal(d[k], alone[1][k]), k
+    finally:
+        model.overlap_fine = saved
