@@ -268,9 +268,11 @@ void refine_lm(const Problem& P, const unsigned char* mask, double* pose, int it
             }
             for (int a = 0; a < 6; ++a) {
                 g[a] -= ju[a] * ru + jv[a] * rv;
-                for (int b2 = 0; b2 < 6; ++b2) H[a * 6 + b2] += ju[a] * ju[b2] + jv[a] * jv[b2];
+                for (int b2 = a; b2 < 6; ++b2) H[a * 6 + b2] += ju[a] * ju[b2] + jv[a] * jv[b2];      // upper triangle
             }
         }
+        for (int a = 1; a < 6; ++a)
+            for (int b2 = 0; b2 < a; ++b2) H[a * 6 + b2] = H[b2 * 6 + a];
         bool improved = false;
         for (int tries = 0; tries < 8 && !improved; ++tries) {
             double Hd[36], dx[6];
@@ -292,7 +294,7 @@ void refine_lm(const Problem& P, const unsigned char* mask, double* pose, int it
                 cur = nc;
                 lambda = lambda > 1e-9 ? lambda * 0.3 : lambda;
                 improved = true;
-                if (rel < 1e-14) return;
+                if (rel < 1e-12) return;       // cost converged to 12 digits: the pose is stationary to ~1e-6 relative
             } else {
                 lambda *= 10.0;
             }
@@ -363,8 +365,9 @@ extern "C" int oppnp_ransac(const double* K, const float* pts2d, const float* pt
     // local optimisation: LM on the inliers, re-evaluate the inlier set, LM again
     for (int round = 0; round < 2; ++round) {
         refine_lm(P, best_mask.data(), best_pose, 20);
+        mask = best_mask;
         best_cnt = count_inliers(P, best_pose, thr2, best_mask.data(), nullptr);
-        if (best_cnt < 6) break;
+        if (best_cnt < 6 || mask == best_mask) break;     // same inlier set: the pose is already its optimum
     }
     std::memcpy(pose_out, best_pose, sizeof(best_pose));
     if (inlier_mask) std::memcpy(inlier_mask, best_mask.data(), (size_t)n);
