@@ -287,15 +287,17 @@ __device__ __forceinline__ void layernorm_featrow8(f32x16 (&m)[1][TT], const flo
 // form has the same traffic but one wave per SIMD).  The MLP's first GEMM has only 4 output tiles per 128-wide hidden chunk:
 // wave (t, khalf) contracts tile t over the x half (khalf 0) or the msg half (khalf 1) of K = 512; the msg halves hand their
 // partial sums over through the (idle) hidden-chunk planes as f32.
-// Measured at c2 (OPHIP_ENC_F8=1, parity-green): 76 us per launch against 68 us for the default 32-token form and 70 us for
-// the 4-wave TT = 2 form -- halving the weight stream does not pay at c2's 185 workgroups (it spills 44 VGPRs at the 256
-// cap of an 8-wave workgroup and adds two barriers per MLP chunk), so it stays an option, not the default.
+// Measured at c2 (OPHIP_ENC_F8=1, parity-green): 70 us per launch, the same as the default 32-token form (two independent
+// workgroups per CU, 69-71 us) and the 4-wave TT = 2 form (70 us), also at 4 frames per step: halving the weight stream buys
+// nothing because the eight waves of one workgroup move through GEMM and epilogue phases in barrier lock-step, so MFMA and
+// VALU / LDS phases do not overlap inside it -- what two independent workgroups get for free.  It stays an option.
 // ---------------------------------------------------------------------------------------------------------------------------
 template <int NS>
 __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void attn_apply_f8_kernel(AttnBArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PL = NS == 3 ? 2 : 1;
     constexpr int TT = 2, TOK = 64, NT_ = 512;
+    constexpr int F8PD = 4;                          // weight-ring depth (k-blocks)
     constexpr int XB = TOK * ROWB, HB = TOK * HROWB;
     char* XH = smem;
     char* XL = smem + (PL - 1) * XB;
@@ -319,18 +321,18 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void attn_apply_f8_
     const bf16x8 *w0_lo = a.w_lo + 4 * C * C / 8 + (size_t)mt * TS2 + (size_t)khalf * 16 * 64 + lane;
     const bf16x8 *w2_hi = a.w_hi + 8 * C * C / 8 + (size_t)w * TS2 + lane, *w2_lo = a.w_lo + 8 * C * C / 8 + (size_t)w * TS2 + lane;
 
-    WRing<1, 4, NS> rq;
+    WRing<1, F8PD, NS> rq;
     rq.fill(wq_hi, wq_lo, TS);
     load_rows_to_planes<NS, C, TOK>(XH, XL, xg, tok0, L, tid, NT_);
     __syncthreads();
 
     // ---- Q projection of head w, phi, linear attention from registers ----------------------------------------
-    WRing<1, 4, NS> rm;
+    WRing<1, F8PD, NS> rm;
     {
         f32x16 q[1][TT];
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) q[0][tt] = zero16();
-        gemm_bf16_ring<1, TT, NS, true, KB, 4>(q, rq, wq_hi, wq_lo, TS, XH, XL, ROWB, 0, lane);
+        gemm_bf16_ring<1, TT, NS, true, KB, F8PD>(q, rq, wq_hi, wq_lo, TS, XH, XL, ROWB, 0, lane);
         rm.fill(wm_hi, wm_lo, TS);
         const char* kvb = a.kv[s] + (size_t)b * a.kvbs;
         const float* ksum = reinterpret_cast<const float*>(kvb + KV_FRAG_BYTES);
@@ -373,12 +375,12 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void attn_apply_f8_
     }
     __syncthreads();
     // ---- merge + LayerNorm 1 -> Y --------------------------------------------------------------------------
-    WRing<1, 4, NS> r0;
+    WRing<1, F8PD, NS> r0;
     {
         f32x16 m[1][TT];
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) m[0][tt] = zero16();
-        gemm_bf16_ring<1, TT, NS, true, KB, 4>(m, rm, wm_hi, wm_lo, TS, YH, YL, ROWB, 0, lane);
+        gemm_bf16_ring<1, TT, NS, true, KB, F8PD>(m, rm, wm_hi, wm_lo, TS, YH, YL, ROWB, 0, lane);
         r0.fill(w0_hi, w0_lo, TS2);
         layernorm_featrow8<TT>(m, a.ln, a.ln + C, scratch, w, lane);      // its first barrier also fences the reads of Y above
 #pragma unroll
@@ -394,8 +396,8 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void attn_apply_f8_
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) hd[0][tt] = zero16();
         const size_t wt = (size_t)(4 * c) * TS2;
-        gemm_bf16_ring<1, TT, NS, true, 16, 4>(hd, r0, w0_hi + wt, w0_lo + wt, TS2, khalf ? YH : XH, khalf ? YL : XL, ROWB, 0, lane);
-        WRing<1, 4, NS> r2;
+        gemm_bf16_ring<1, TT, NS, true, 16, F8PD>(hd, r0, w0_hi + wt, w0_lo + wt, TS2, khalf ? YH : XH, khalf ? YL : XL, ROWB, 0, lane);
+        WRing<1, F8PD, NS> r2;
         r2.fill(w2_hi + (size_t)(8 * c) * 64, w2_lo + (size_t)(8 * c) * 64, TS2);
         // partial sums of the msg halves -> f32 scratch [tile][tt][quad][lane] (conflict-free 16-byte slots)
         char* part = HH;
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void attn_apply_f8_
             for (int tt = 0; tt < TT; ++tt) store_featrow_acc<NS>(hd[0][tt], HH, HL, HROWB, 32 * mt, 32 * tt, lane);
         }
         __syncthreads();
-        gemm_bf16_ring<1, TT, NS, true, 8, 4>(o, r2, w2_hi + (size_t)(8 * c) * 64, w2_lo + (size_t)(8 * c) * 64, TS2, HH, HL, HROWB, 0, lane);
+        gemm_bf16_ring<1, TT, NS, true, 8, F8PD>(o, r2, w2_hi + (size_t)(8 * c) * 64, w2_lo + (size_t)(8 * c) * 64, TS2, HH, HL, HROWB, 0, lane);
         if (c + 1 < 4) r0.fill(w0_hi + wt + (size_t)4 * TS2, w0_lo + wt + (size_t)4 * TS2, TS2);
         __syncthreads();
     }
@@ -476,7 +478,13 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void attn_apply_f8_
     if (fuse) {
         __syncthreads();
         float* out = a.npartial + ((size_t)b * (a.slabs[0] + a.slabs[1]) + (s ? a.slabs[0] : 0) + TT * lt) * KV_PART_FLOATS;
-        kv_slab_from_planes<NS, TT, 1>(rkv, nhi, nlo, KH, KL, tok0, L, out, 0, lane, 2 * TS, w);
+        // one token tile at a time (the two-tile form needs 64 accumulator registers more than the 256 an 8-wave workgroup
+        // leaves per lane; the K|V fragments of one head are fetched twice instead: +64 KB of the 2.5 MB per workgroup)
+        kv_slab_from_planes<NS, 1, 1>(rkv, nhi, nlo, KH, KL, tok0, L, out, 0, lane, 2 * TS, w);
+        if (tok0 + 32 < L) {
+            rkv.fill(nhi, nlo, 2 * TS);
+            kv_slab_from_planes<NS, 1, 1>(rkv, nhi, nlo, KH + 32 * ROWB, KL + 32 * ROWB, tok0 + 32, L, out + KV_PART_FLOATS, 0, lane, 2 * TS, w);
+        }
     }
 }
 
