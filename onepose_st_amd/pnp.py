@@ -39,7 +39,7 @@ def load():
 
 
 def ransac_PnP(K, pts_2d, pts_3d, scale=1, pnp_reprojection_error=5, img_hw=None, use_pycolmap_ransac=False,
-               confidence=0.99, min_iters=8, max_iters=10000, seed=1):
+               confidence=0.99, min_iters=4, max_iters=10000, seed=1):
     """-> ``(pose [3,4], pose_homo [4,4], inliers [k] int64)`` like the reference.  ``scale`` multiplies the 3D points
     for the solve and divides the translation afterwards (the reference's OpenCV branch, ``metric_utils.py:186,200``);
     ``img_hw`` / ``use_pycolmap_ransac`` are accepted for signature compatibility and ignored."""
@@ -67,7 +67,7 @@ def ransac_PnP(K, pts_2d, pts_3d, scale=1, pnp_reprojection_error=5, img_hw=None
 class PnPPool:
     """Library-owned worker threads: ``submit`` copies the matches and returns a ticket immediately."""
 
-    def __init__(self, K, threads=3, pnp_reprojection_error=7, confidence=0.99, min_iters=8, max_iters=10000, seed=1):
+    def __init__(self, K, threads=3, pnp_reprojection_error=7, confidence=0.99, min_iters=4, max_iters=10000, seed=1):
         self._lib = load()
         self._K = np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(3, 3))
         self._args = (float(pnp_reprojection_error), float(confidence), int(min_iters), int(max_iters), int(seed))
