@@ -352,7 +352,7 @@ struct ConfArgs {
 
 constexpr int CONF_ROWS = 32;      // rows per workgroup (measured at c2: 16 -> 106 us, 32 -> 90, 48 -> 114, 64 -> 132: fewer, less contended column atomics vs grid fill)
 constexpr int CONF_RB = 2;         // rows per pipeline stage (two stages in flight)
-constexpr int CONF_U = 4;          // float4 groups per thread per row  => span <= 4096 columns
+constexpr int CONF_U = 3;          // float4 groups per thread per row  => span <= 3072 columns (164 VGPRs, 3 waves per SIMD; 4 -> 212 VGPRs, 2 -> more spans: 87 / 90 / 94 us at c2)
 
 template <bool VEC, bool FAST>
 __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs p) {
     if (tid == 0) *p.count = base_s;
 }
 
-inline int conf_nspan(int M) { return (M + 4095) / 4096; }
+inline int conf_nspan(int M) { return (M + 3071) / 3072; }
 inline int conf_spanw(int M) { const int ns = conf_nspan(M); return (((M + ns - 1) / ns) + 3) / 4 * 4; }
 
 }  // namespace
