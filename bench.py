@@ -83,9 +83,9 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("OPHIP_PRECISION", "bf16x3"), choices=["f32", "bf16x3", "bf16"],
                     help="matrix arithmetic of the encoder kernels (see DESIGN.md section 4)")
     ap.add_argument("--streams", type=int, default=1,
-                    help="HIP streams the frames alternate over.  Default 1: kernels never overlap, so the HIP-event time of the "
-                         "roofline kernel is its own.  2 overlaps consecutive (independent) frames: +18..27 %% frames/s at c2, but "
-                         "per-kernel event times then include co-scheduled kernels")
+                    help="compute streams the frames alternate over.  Default 1: the model already runs the fine stage and the result "
+                         "read-back on side streams (frame t's refinement under frame t + 1's input kernels) while attn_apply never shares "
+                         "the chip, so its HIP-event time is its own; 2 measured no gain on top of that")
     ap.add_argument("--with-backbone", action="store_true",
                     help="also run the ResNet-FPN backbone (SURVEY 8f-1, HIP convolution kernels) on a synthetic image in every step; "
                          "its maps are then replaced by the planted feature maps (a random image has no matches)")
