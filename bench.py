@@ -2,7 +2,9 @@
 
     python bench.py --gpus N --steps K --warmup W [--batch B] [--workload c2|c1|c4] [--no-cpu-baseline]
 
-One process per GPU (``torch.distributed.run`` for N > 1, RCCL).  A *step* is one pass of the hot path over
+One process per GPU over RCCL: for N > 1 either ``torch.distributed.run`` starts the ranks, or -- when ``python bench.py
+--gpus N`` is run directly -- this process starts them itself as children (``onepose_st_amd/launch.py``) and relays
+rank 0's JSON line.  A *step* is one pass of the hot path over
 one batch of ``--batch`` frames (default 1) whose inputs are already resident in HBM: backbone-output feature
 maps of a frame (``feat_c [B,256,60,80]``, ``feat_f [B,128,240,320]``) + the shared 3D object block -> match
 indices, confidences and sub-pixel keypoints (rows a1-a11 of SURVEY.md section 8a; the ResNet backbone and PnP
@@ -32,6 +34,7 @@ sys.path.insert(0, REPO)
 
 from onepose_st_amd import hip  # noqa: E402
 from onepose_st_amd.config import default_config  # noqa: E402
+from onepose_st_amd.launch import launched_by_torchrun, spawn_ranks  # noqa: E402
 from onepose_st_amd.model import OnePosePlus_model  # noqa: E402
 from onepose_st_amd.pnp import PnPPool  # noqa: E402
 from onepose_st_amd.sharding import OBJECT_KEYS as OBJ_KEYS, broadcast_object_block, frame_chunk  # noqa: E402
@@ -97,11 +100,32 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
 
+    # ---- N > 1 without a launcher: this process becomes the driver and starts one child per GPU (it never touches the GPU
+    #      itself and never exec's; the reference fans out from its driver too, inference_OnePosePlus.py:81-98) --------------
+    if args.gpus > 1 and not launched_by_torchrun():
+        if not args.share_device and torch.cuda.device_count() < args.gpus:      # device_count() does not initialise HIP
+            raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible "
+                             "(one-GPU rehearsal: --share-device --dist-backend gloo)")
+        raise SystemExit(spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
+                                     keep=lambda ln: ln.lstrip().startswith("{")))      # stdout carries the ONE JSON line only
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("OPHIP_BENCH_LAUNCH_PROBE"):
+        # launcher rehearsal without a GPU (tests/test_launch.py): rendezvous over gloo, one all-reduce, one JSON line from rank 0
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group("gloo")
+        seen = torch.tensor([float(rank + 1)])
+        if world > 1:
+            dist.all_reduce(seen)
+        if rank == 0:
+            print(json.dumps({"probe": True, "n_gpus": world, "rank_sum": float(seen.item()), "local_rank": local}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if args.share_device:
         local = 0
     torch.cuda.set_device(local)

@@ -1,0 +1,64 @@
+"""The driver-side fan-out of ``bench.py --gpus N`` (onepose_st_amd/launch.py) on CPU: child processes with the
+torch.distributed rendezvous variables, rank 0's stdout relayed, failures propagated, and bench.py's own launcher
+branch rehearsed over gloo with the GPU part stubbed out (OPHIP_BENCH_LAUNCH_PROBE)."""
+import io
+import json
+import os
+import subprocess
+import sys
+import time
+
+from onepose_st_amd.launch import launched_by_torchrun, rank_env, spawn_ranks
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+_GLOO = r"""
+import json, os, torch, torch.distributed as dist
+torch.set_num_threads(1)
+dist.init_process_group("gloo")
+t = torch.tensor([float(dist.get_rank() + 1)])
+dist.all_reduce(t)
+print("noise from rank", dist.get_rank())
+if dist.get_rank() == 0:
+    print(json.dumps({"world": dist.get_world_size(), "sum": t.item(), "addr": os.environ["MASTER_ADDR"]}))
+dist.destroy_process_group()
+"""
+
+
+def test_rank_env_and_detection():
+    env = rank_env(1, 4, 29511, base={})
+    assert env["RANK"] == "1" and env["LOCAL_RANK"] == "1" and env["WORLD_SIZE"] == "4"
+    assert env["MASTER_ADDR"] == "127.0.0.1" and env["MASTER_PORT"] == "29511"
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert launched_by_torchrun(env) and not launched_by_torchrun({})
+
+
+def test_spawn_ranks_gloo_world2_relays_rank0_only():
+    out = io.StringIO()
+    rc = spawn_ranks([sys.executable, "-c", _GLOO], 2, timeout=240, stdout=out)
+    assert rc == 0
+    lines = [ln for ln in out.getvalue().strip().splitlines() if not ln.startswith("[Gloo]")]
+    assert lines[0] == "noise from rank 0" and len(lines) == 2          # rank 1's stdout is not relayed
+    rec = json.loads(lines[1])
+    assert rec == {"world": 2, "sum": 3.0, "addr": "127.0.0.1"}
+
+
+def test_spawn_ranks_propagates_failure_and_stops_the_others():
+    code = "import os, sys, time\nif os.environ['RANK'] == '1': sys.exit(7)\ntime.sleep(120)\n"
+    t0 = time.monotonic()
+    rc = spawn_ranks([sys.executable, "-c", code], 2, timeout=100, stdout=io.StringIO())
+    assert rc == 7 and time.monotonic() - t0 < 60
+
+
+def test_bench_self_launch_probe_world2():
+    """python bench.py --gpus 2 (no torchrun): the parent fans out, never touches the GPU, relays ONE JSON line."""
+    env = dict(os.environ, OPHIP_BENCH_LAUNCH_PROBE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--share-device", "--dist-backend", "gloo",
+                        "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = p.stdout.splitlines()
+    assert len(lines) == 1, p.stdout                                     # banners of rank 0 went to stderr
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rank_sum"] == 3.0 and rec["probe"] is True
