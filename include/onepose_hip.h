@@ -75,6 +75,17 @@ int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, float* y3d, flo
                              const void* wpack, const void* wpack_next, int nsplit, int is_cross, int kv_from_prev, int slot,
                              void* workspace, void* stream);
 
+/* The same layer, split-bf16 only, second-generation mapping (csrc/encoder_x3.hip): v_mfma_f32_16x16x32_bf16 on 48-token
+ * workgroups (one per CU), the layer's weights pre-ordered into one linear stream per wave (packing.pack_coarse_layer_x3,
+ * ophip_encoder_x3_wpack_bytes() bytes, 16-byte aligned), epilogues overlapped with the next GEMM inside a wave.
+ * Arguments and layer chaining (wpack_next / kv_from_prev / slot) as ophip_encoder_layer_bf16;
+ * workspace: ophip_encoder_x3_workspace_bytes() bytes.  Replaces transformer.py:65-94 + linear_attention.py:29-61. */
+size_t ophip_encoder_x3_workspace_bytes(int B, int L3d, int L2d);
+size_t ophip_encoder_x3_wpack_bytes(void);
+int ophip_encoder_layer_x3(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
+                           const void* wpack, const void* wpack_next, int is_cross, int kv_from_prev, int slot,
+                           void* workspace, void* stream);
+
 /* a7 + a8 -- CoarseMatching.forward + get_coarse_match, inference branch
  * (utils/coarse_matching.py:76-123, :125-242, mask_border :10-20).
  * feat3d [B][N][256], feat2d [B][M][256] (encoder outputs), M = hc * wc.

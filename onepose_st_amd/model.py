@@ -155,6 +155,9 @@ class OnePosePlus_model(nn.Module):
         if self.precision != "f32":
             blocks["coarse_bf16"] = [packing.pack_coarse_layer_bf16(sd, f"loftr_coarse.layers.{i}.").to(device)
                                      for i in range(len(self.loftr_coarse.layer_names))]
+            if self.precision == "bf16x3":
+                blocks["coarse_x3"] = [packing.pack_coarse_layer_x3(sd, f"loftr_coarse.layers.{i}.").to(device)
+                                       for i in range(len(self.loftr_coarse.layer_names))]
             blocks["fine_bf16"] = packing.pack_fine_layers_bf16(sd, "loftr_fine.layers.", len(self.loftr_fine.layer_names)).to(device)
         self._packed = (key, blocks)
         return blocks
@@ -302,6 +305,17 @@ class OnePosePlus_model(nn.Module):
             for li, name in enumerate(self.loftr_coarse.layer_names):
                 lib_call("ophip_encoder_layer", P(x3d), P(x2d), P(y3d), P(y2d), B, N, M, P(W["coarse"][li]),
                          1 if name == "cross" else 0, P(ws), S)
+                x3d, y3d, x2d, y2d = y3d, x3d, y2d, x2d
+        elif self.precision == "bf16x3" and not os.environ.get("OPHIP_ENC_V1"):
+            # 16-token tiles, one workgroup per CU, per-wave weight streams (csrc/encoder_x3.hip)
+            ws = torch.empty(hip.load().ophip_encoder_x3_workspace_bytes(B, N, M), device=dev, dtype=torch.uint8)
+            names_c = self.loftr_coarse.layer_names
+            for li, name in enumerate(names_c):
+                nxt = W["coarse_x3"][li + 1] if li + 1 < len(names_c) else None
+                if li == 0:
+                    wait_previous_fine()
+                lib_call("ophip_encoder_layer_x3", P(x3d), P(x2d), P(y3d), P(y2d), B, N, M, P(W["coarse_x3"][li], None), P(nxt, None),
+                         1 if name == "cross" else 0, 1 if li > 0 else 0, li & 1, P(ws, None), S)
                 x3d, y3d, x2d, y2d = y3d, x3d, y2d, x2d
         else:
             nsplit = 3 if self.precision == "bf16x3" else 1

@@ -111,6 +111,53 @@ def pack_coarse_layer_bf16(sd: dict, prefix: str) -> torch.Tensor:
     return out
 
 
+# ----------------------------------------------------------------------------------------------
+# split-bf16 coarse layer as per-wave STREAMS (csrc/encoder_x3.hip): v_mfma_f32_16x16x32_bf16 fragments
+#   frag(W, row0, k0)[lane = 16 q + c16][j] = W[row0 + c16][k0 + 8 q + j]      (1 KiB per plane)
+# in exactly the order wave fw consumes them, hi then lo per fragment.
+# ----------------------------------------------------------------------------------------------
+X3_MAIN_FRAGS, X3_KV_FRAGS = 512, 128         # per wave, hi and lo counted separately
+
+
+def x3_program(fw: int):
+    """-> (main, kv): lists of (matrix, row0, k0) in consumption order for wave ``fw`` (each entry = one hi + one lo fragment).
+    main: Q | merge | W0c0 | W0c1 | W2c0 | W0c2 | W2c1 | W0c3 | W2c2 | W2c3 (MLP chunk c = hidden features 128c..128c+127,
+    the chunk's first GEMM pipelined one chunk ahead of its second); kv: K|V projection of heads 2fw, 2fw+1."""
+    def gemm(mat, rows, k0, ksteps):
+        return [(mat, r0, k0 + 32 * ks) for ks in range(ksteps) for r0 in rows]
+    rows64 = [64 * fw + 16 * ft for ft in range(4)]
+    main = gemm("q", rows64, 0, 8) + gemm("m", rows64, 0, 8)
+    w0 = [gemm("w0", [128 * c + 32 * fw + 16 * ft for ft in range(2)], 0, 16) for c in range(4)]
+    w2 = [gemm("w2", rows64, 128 * c, 4) for c in range(4)]
+    main += w0[0] + w0[1] + w2[0] + w0[2] + w2[1] + w0[3] + w2[2] + w2[3]
+    kv = [(("k" if ft < 4 else "v"), 64 * fw + 16 * (ft & 3), 32 * ks) for ks in range(8) for ft in range(8)]
+    assert 2 * len(main) == X3_MAIN_FRAGS and 2 * len(kv) == X3_KV_FRAGS
+    return main, kv
+
+
+def x3_frag(w: torch.Tensor, row0: int, k0: int) -> torch.Tensor:
+    """``[64 lanes][8]`` A/B-operand fragment of ``W[row0:row0+16, k0:k0+32]``."""
+    return w[row0:row0 + 16, k0:k0 + 32].reshape(16, 4, 8).permute(1, 0, 2).reshape(64, 8)
+
+
+def pack_coarse_layer_x3(sd: dict, prefix: str) -> torch.Tensor:
+    """uint8 block ``[main streams: 4 waves x 512 KiB][K|V streams: 4 x 128 KiB][norm1.w norm1.b norm2.w norm2.b f32]`` for
+    ``ophip_encoder_layer_x3``."""
+    mats = {"q": sd[prefix + "q_proj.weight"], "k": sd[prefix + "k_proj.weight"], "v": sd[prefix + "v_proj.weight"],
+            "m": sd[prefix + "merge.weight"], "w0": sd[prefix + "mlp.0.weight"], "w2": sd[prefix + "mlp.2.weight"]}
+    mats = {k: v.detach().to(torch.float32).cpu().contiguous() for k, v in mats.items()}
+    if tuple(mats["q"].shape) != (256, 256) or tuple(mats["w0"].shape) != (512, 512) or tuple(mats["w2"].shape) != (256, 512):
+        raise ValueError("coarse encoder kernels are specialised for d_model = 256")
+    progs = [x3_program(fw) for fw in range(4)]
+    frags = [x3_frag(mats[m], r0, k0) for sel in (0, 1) for fw in range(4) for (m, r0, k0) in progs[fw][sel]]
+    flat = torch.stack(frags)                                     # [n][64][8] f32
+    hi = flat.to(torch.bfloat16)
+    lo = (flat - hi.float()).to(torch.bfloat16)
+    out = _bytes(torch.stack([hi, lo], 1), torch.cat(_ln(sd, prefix)))
+    assert out.numel() == 4 * (X3_MAIN_FRAGS + X3_KV_FRAGS) * 1024 + 16 * 256
+    return out
+
+
 def pack_fine_layers_bf16(sd: dict, prefix: str, n_layers: int) -> torch.Tensor:
     """uint8 block for ``ophip_fine_refine_bf16``: per layer ``[hi: Wq | Wkv | Wm | W0 | W2][lo: same][ln f32]`` where
     ``Wkv`` stacks per wave w = 0..3 ``Wk[32w:32w+32]`` then ``Wv[32w:32w+32]`` (``prefix`` like ``"loftr_fine.layers."``)."""

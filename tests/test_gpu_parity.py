@@ -142,6 +142,69 @@ def test_encoder_layer_bf16(sd, dev, nsplit, rtol, atol, cross, B, L3, L2):
     close(y2, r2, rtol=rtol, atol=atol, msg="2D stream")
 
 
+@pytest.mark.parametrize("cross", [0, 1])
+@pytest.mark.parametrize("B,L3,L2", [(1, 64, 32), (2, 70, 45), (1, 1000, 1200), (3, 49, 97)])
+def test_encoder_layer_x3(sd, dev, cross, B, L3, L2):
+    """split-bf16 layer on 16-token tiles / per-wave weight streams (csrc/encoder_x3.hip): tracks the f32 oracle to ~1e-4
+    at ragged sizes (tokens not a multiple of 48, several frames)."""
+    g = torch.Generator().manual_seed(2)
+    x3, x2 = torch.randn(B, L3, 256, generator=g), torch.randn(B, L2, 256, generator=g)
+    p = "loftr_coarse.layers.2."
+    if cross:
+        r2, r3 = orc.encoder_layer(sd, p, x2, x3, 8), orc.encoder_layer(sd, p, x3, x2, 8)
+    else:
+        r2, r3 = orc.encoder_layer(sd, p, x2, x2, 8), orc.encoder_layer(sd, p, x3, x3, 8)
+    w = packing.pack_coarse_layer_x3(sd, p).to(dev)
+    assert w.numel() == hip.load().ophip_encoder_x3_wpack_bytes()
+    ws = torch.empty(hip.load().ophip_encoder_x3_workspace_bytes(B, L3, L2), dtype=torch.uint8, device=dev)
+    d3, d2 = x3.to(dev), x2.to(dev)
+    y3, y2 = torch.full_like(d3, float("nan")), torch.full_like(d2, float("nan"))
+    hip.call("ophip_encoder_layer_x3", hip.ptr(d3), hip.ptr(d2), hip.ptr(y3), hip.ptr(y2), B, L3, L2, hip.ptr(w, None), None, cross, 0, 0,
+             hip.ptr(ws, None), hip.stream_handle())
+    e3 = (y3.cpu() - r3).abs().max().item()
+    e2 = (y2.cpu() - r2).abs().max().item()
+    print(f"x3 cross={cross} B={B} L=({L3},{L2}): max abs err 3D {e3:.3e} 2D {e2:.3e}")
+    close(y3, r3, rtol=3e-4, atol=1e-4, msg="3D stream")
+    close(y2, r2, rtol=3e-4, atol=1e-4, msg="2D stream")
+    with pytest.raises(ValueError):
+        hip.call("ophip_encoder_layer_x3", hip.ptr(d3), hip.ptr(d2), hip.ptr(d3), hip.ptr(y2), B, L3, L2, hip.ptr(w, None), None, cross, 0, 0,
+                 hip.ptr(ws, None), hip.stream_handle())
+
+
+@pytest.mark.parametrize("B,L3,L2", [(1, 100, 75), (2, 333, 260)])
+def test_encoder_x3_chain_with_fused_kv_tail(sd, dev, B, L3, L2):
+    """three chained layers (self, cross, self): layers 1.. take their K|V slabs from the previous launch's fused tail
+    (kv_from_prev = 1, slab sets ping-pong); result vs the oracle's layers and vs the same chain run stand-alone."""
+    g = torch.Generator().manual_seed(5)
+    x3, x2 = torch.randn(B, L3, 256, generator=g), torch.randn(B, L2, 256, generator=g)
+    names = ["self", "cross", "self"]
+    r3, r2 = x3, x2
+    for li, nm in enumerate(names):
+        p = f"loftr_coarse.layers.{li}."
+        if nm == "cross":
+            r2, r3 = orc.encoder_layer(sd, p, r2, r3, 8), orc.encoder_layer(sd, p, r3, r2, 8)
+        else:
+            r2, r3 = orc.encoder_layer(sd, p, r2, r2, 8), orc.encoder_layer(sd, p, r3, r3, 8)
+    ws_ = [packing.pack_coarse_layer_x3(sd, f"loftr_coarse.layers.{li}.").to(dev) for li in range(3)]
+    ws = torch.empty(hip.load().ophip_encoder_x3_workspace_bytes(B, L3, L2), dtype=torch.uint8, device=dev)
+
+    def chain(fused):
+        a3, a2 = x3.to(dev), x2.to(dev)
+        b3, b2 = torch.full_like(a3, float("nan")), torch.full_like(a2, float("nan"))
+        for li, nm in enumerate(names):
+            nxt = ws_[li + 1] if (fused and li + 1 < 3) else None
+            hip.call("ophip_encoder_layer_x3", hip.ptr(a3), hip.ptr(a2), hip.ptr(b3), hip.ptr(b2), B, L3, L2, hip.ptr(ws_[li], None),
+                     hip.ptr(nxt, None), 1 if nm == "cross" else 0, 1 if (fused and li > 0) else 0, (li & 1) if fused else 0,
+                     hip.ptr(ws, None), hip.stream_handle())
+            a3, b3, a2, b2 = b3, a3, b2, a2
+        return a3.clone(), a2.clone()
+    f3, f2 = chain(True)
+    s3, s2 = chain(False)
+    assert torch.equal(f3, s3) and torch.equal(f2, s2)          # the fused tail computes exactly what the stand-alone K|V launch does
+    close(f3, r3, rtol=5e-4, atol=2e-4, msg="3D stream after 3 layers")
+    close(f2, r2, rtol=5e-4, atol=2e-4, msg="2D stream after 3 layers")
+
+
 def _coarse_match(dev, f3, f2, kp, wc, thr=0.1, border=2, temp=0.08, scale=8.0, nsplit=0):
     B, N, _ = f3.shape
     M = f2.shape[1]

@@ -1,0 +1,37 @@
+"""Diagnostic: per-phase cycle stamps and launch time of the x3 encoder layer kernel at c2 (or --tokens N).  Not part of the product."""
+import ctypes, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from onepose_st_amd import hip, packing
+from onepose_st_amd.config import default_config
+from onepose_st_amd.synthetic import make_synthetic_state_dict
+sd = make_synthetic_state_dict(0, default_config()); dev = torch.device("cuda:0"); hip.load()
+B = int(os.environ.get("B", "1"))
+L3, L2 = 7000, 4800
+g = torch.Generator().manual_seed(0)
+x3, x2 = torch.randn(B, L3, 256, generator=g).to(dev), torch.randn(B, L2, 256, generator=g).to(dev)
+y3, y2 = torch.empty_like(x3), torch.empty_like(x2)
+w = packing.pack_coarse_layer_x3(sd, "loftr_coarse.layers.0.").to(dev)
+ws = torch.empty(hip.load().ophip_encoder_x3_workspace_bytes(B, L3, L2), dtype=torch.uint8, device=dev)
+fuse = not os.environ.get("NOFUSE")
+def run():
+    hip.call("ophip_encoder_layer_x3", hip.ptr(x3), hip.ptr(x2), hip.ptr(y3), hip.ptr(y2), B, L3, L2, hip.ptr(w, None),
+             hip.ptr(w, None) if fuse else None, 0, 0, 0, hip.ptr(ws, None), hip.stream_handle())
+for _ in range(3): run()
+torch.cuda.synchronize()
+for name in ("attn_apply", "kv_reduce", "kv_sum"):
+    hip.timing_select(name)
+    for _ in range(30): run()
+    torch.cuda.synchronize(); n, ms = hip.timing_read(); hip.timing_select("")
+    print(f"{name:12s} {ms / n * 1e3:7.1f} us per launch (B={B}, fused tail {fuse})")
+nwg = B * ((L3 + 47) // 48 + (L2 + 47) // 48)
+buf = torch.zeros(nwg * 32, dtype=torch.int64, device=dev)
+hip.call("ophip_debug_stamps", ctypes.c_void_p(buf.data_ptr())); run(); torch.cuda.synchronize(); hip.call("ophip_debug_stamps", None)
+s = buf.view(-1, 32)[:nwg].cpu().numpy().astype(np.int64)
+names = ["start", "ring fill + KV/Ksum loads + X stage + sync", "Q gemm", "attention + msg store + sync", "merge gemm", "LN1 moments + sync",
+         "W0c0 x-half (+LN1 normalise) + sync", "W0c0 msg-half", "W0c1 (+store c0) + sync", "W2c0 + W0c2 (+store c1) + sync",
+         "W2c1 + W0c3 (+store c2) + sync", "W2c2 (+store c3) + sync", "W2c3", "LN2 + residual + store", "K|V tail"]
+d = s[:, 14] - s[:, 0]
+print("workgroups", nwg, "WG cycles p10/p50/p90", np.percentile(d, 10), np.median(d), np.percentile(d, 90))
+for k in range(1, 15):
+    print(f"{names[k]:48s} {np.median(s[:, k] - s[:, k - 1]):9.0f}")
