@@ -330,7 +330,7 @@ def main():
             "parallelism": f"frames sharded over {world} rank(s), one RCCL broadcast of weights + 3D block ({bcast_bytes} B)",
         },
         "roofline": {
-            "kernel": {"bf16x3": "attn_apply_bf16_kernel<3, 1>", "bf16": "attn_apply_bf16_kernel<1, 1>", "f32": "attn_apply_kernel"}[args.precision]
+            "kernel": {"bf16x3": "enc_x3_kernel<false> (attn_apply)", "bf16": "attn_apply_bf16_kernel<1, 1>", "f32": "attn_apply_kernel"}[args.precision]
                       + " (fused Q-proj + linear attention + merge + MLP + 2 LayerNorms" + (" + next layer's K/V reduce)" if args.precision != "f32" else ")"),
             "bound": "mfma",
             "achieved": achieved,

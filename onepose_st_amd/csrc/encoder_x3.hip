@@ -32,7 +32,10 @@ constexpr int ROWB = C * 2;                     // plane row pitch (bytes), 32 c
 constexpr int HROWB = 128 * 2;                  // hidden-chunk plane pitch, 16 chunks
 constexpr int PLANE = TOK * ROWB;               // 24 576 B
 constexpr int HPLANE = TOK * HROWB;             // 12 288 B
-constexpr int R = 32;                           // ring depth in 1 KiB fragments (128 registers, 32 KiB in flight per wave)
+#ifndef X3_R
+#define X3_R 16
+#endif
+constexpr int R = X3_R;                        // ring depth in 1 KiB fragments (4 registers each)
 constexpr int MAIN_FRAGS = 512, KV_FRAGS = 128; // per wave: Q 64 | merge 64 | MLP 384 ;  next layer's K|V 128
 constexpr int KV_PART_FLOATS = NH * 1024 + NH * 32;             // per-tile slab: KV [head][dt][vt][lane][4] f32 + Ksum [head][32]
 constexpr int KV_FRAG_BYTES = NH * 2 * 2 * 64 * 16;             // [head][vt][plane][lane][16 B]
@@ -79,7 +82,35 @@ __device__ __forceinline__ void store_quad(const f32x4& v, char* ph, char* pl, i
     *reinterpret_cast<bf16x4*>(pl + off) = vl;
 }
 
+// sum over the four 16-lane rows (q) of a wave, result in every lane: v_permlane16_swap + v_permlane32_swap (vector ALU
+// only; __shfl_xor is an LDS round trip per step)
+__device__ __forceinline__ float sum_over_q(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);      // -> rows [r0 r0 r2 r2], [r1 r1 r3 r3]
+    const unsigned a0 = a[0], a1 = a[1];       // (a bit_cast applied to a vector ELEMENT reads element 0 on hipcc 7.2: copy first)
+    const float s = __builtin_bit_cast(float, a0) + __builtin_bit_cast(float, a1);
+    const unsigned w = __builtin_bit_cast(unsigned, s);
+    auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);      // -> [A A A A], [B B B B]
+    const unsigned b0 = b[0], b1 = b[1];
+    return __builtin_bit_cast(float, b0) + __builtin_bit_cast(float, b1);
+}
+
 struct Ring { bf16x8 s[R]; };
+
+// One wave's weight stream: 1 KiB fragments behind a buffer descriptor; every load is voffset = 16 lane (one VGPR for the
+// whole kernel) + a scalar / immediate fragment offset, so the stream costs no vector address arithmetic.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct WStream {
+    __amdgpu_buffer_rsrc_t rs;
+    int voff;
+    __device__ __forceinline__ void open(const bf16x8* base_uniform, int nfrags, int lane) {
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8*>(base_uniform), 0, nfrags * 1024, 0x00020000);
+        voff = lane * 16;
+    }
+    __device__ __forceinline__ bf16x8 load(int frag) const {
+        return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, frag * 1024, 0));
+    }
+};
 
 struct XFrag { bf16x8 h[NTT], l[NTT]; };
 
@@ -93,16 +124,19 @@ __device__ __forceinline__ void read_x(XFrag& x, const char* ph, const char* pl,
 }
 
 // One GEMM stage of a wave: acc[ft][tt] += W(ft) . Act(tt) over NKS k-steps of 32.
-//   weights: ring slots (S0 + ks * 2 NF + 2 ft + plane) % R, consumed in stream order; after a k-step its slots are refilled
-//            from `refill` (the stream position R fragments ahead of this stage's first fragment), the first NREFILL
-//            fragments of the stage only (the tail of the last stream has nothing to fetch);
+//   weights: ring slots (ks * 2 NF + 2 ft + plane) % R, consumed in stream order; after a k-step its slots are refilled with
+//            the fragments R positions ahead: the first NA of them from stream `wa` at posa.., the rest (up to NREFILL in
+//            all) from stream `wb` at posb.. (the main stream runs into the next layer's K|V stream; the tail of the last
+//            stream has nothing to fetch);
 //   activations: swizzled (hi, lo) planes, chunk0 = first 16-byte chunk of k-step 0; read one k-step ahead;
 //   W_IS_A: D[feature][token] (weights are the A operand) / false: D[token][feature];
 //   side(ks): a slice of independent epilogue work issued beside k-step ks's MFMAs.
-template <int NF, int NKS, bool W_IS_A, int S0, int NREFILL, class Side>
-__device__ __forceinline__ void gemm_stage(f32x4 (&acc)[NF][NTT], Ring& ring, const bf16x8* __restrict__ refill, const char* ph,
-                                           const char* pl, int rowb, int chunk0, int c16, int q, Side&& side) {
+template <int NF, int NKS, bool W_IS_A, int NREFILL, int NA, class Side>
+__device__ __forceinline__ void gemm_stage(f32x4 (&acc)[NF][NTT], Ring& ring, const WStream& wa, int posa, const WStream& wb, int posb,
+                                           const char* ph, const char* pl, int rowb, int chunk0, int c16, int q, Side&& side) {
+    constexpr int S0 = 0;
     constexpr int F = 2 * NF;
+    constexpr int NMFMA = 3 * NF * NTT;              // per k-step
     XFrag x[2];
     read_x(x[0], ph, pl, rowb, chunk0 + q, c16);
 #pragma unroll
@@ -120,9 +154,65 @@ __device__ __forceinline__ void gemm_stage(f32x4 (&acc)[NF][NTT], Ring& ring, co
         }
 #pragma unroll
         for (int f = 0; f < F; ++f)
-            if (ks * F + f < NREFILL) ring.s[(S0 + ks * F + f) % R] = refill[(size_t)(ks * F + f) * 64];
+            if (ks * F + f < NREFILL)
+                ring.s[(S0 + ks * F + f) % R] = (ks * F + f < NA) ? wa.load(posa + ks * F + f) : wb.load(posb + ks * F + f - NA);
         side(ks);
-        __builtin_amdgcn_sched_barrier(0);          // keep refills and the side slice inside their k-step
+        // issue order inside the k-step, one MFMA at a time: behind each of the first MFMAs one of the next k-step's activation
+        // reads (their LDS round trip must be over when this k-step's MFMAs are), then one ring refill per MFMA, and behind
+        // every MFMA up to two vector instructions and an LDS write of the side work (what a 16-cycle 16x16x32 slot leaves
+        // of the SIMD's issue bandwidth)
+        constexpr int NRD = 2 * NTT, NLD = F;
+#pragma unroll
+        for (int i = 0; i < NMFMA; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            else if (i - NRD < NLD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            if (i & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);          // nothing crosses a k-step
+    }
+}
+
+// The same stage as a rolled loop (no side work; refills unconditional from ONE stream: a fragment beyond the stream's end is
+// dropped by the descriptor's range check).  The body covers U k-steps = whole passes over the ring, so slot indices and the
+// activation double-buffer stay static; keeps the kernel's code inside the instruction cache.
+template <int NF, int NKS, bool W_IS_A>
+__device__ __forceinline__ void gemm_stage_rolled(f32x4 (&acc)[NF][NTT], Ring& ring, const WStream& wa, int posa, const char* ph,
+                                                  const char* pl, int rowb, int chunk0, int c16, int q) {
+    constexpr int F = 2 * NF;
+    constexpr int U = (R / F) >= 2 ? (R / F) : 2;
+    constexpr int NMFMA = 3 * NF * NTT;
+    static_assert(NKS % U == 0 && (U * F) % R == 0, "a loop body must cover whole passes over the ring");
+    XFrag x[2];
+    read_x(x[0], ph, pl, rowb, chunk0 + q, c16);
+#pragma unroll 1
+    for (int it = 0; it < NKS / U; ++it) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int cur = u & 1;
+            const int ks = it * U + u;
+            read_x(x[cur ^ 1], ph, pl, rowb, chunk0 + 4 * (ks + 1) + q, c16);          // one k-step past the end: stays inside the plane's row
+#pragma unroll
+            for (int ft = 0; ft < NF; ++ft) {
+                const bf16x8& whi = ring.s[(u * F + 2 * ft) % R];
+                const bf16x8& wlo = ring.s[(u * F + 2 * ft + 1) % R];
+#pragma unroll
+                for (int tt = 0; tt < NTT; ++tt)
+                    acc[ft][tt] = W_IS_A ? mma16x3(whi, wlo, x[cur].h[tt], x[cur].l[tt], acc[ft][tt])
+                                         : mma16x3(x[cur].h[tt], x[cur].l[tt], whi, wlo, acc[ft][tt]);
+            }
+#pragma unroll
+            for (int f = 0; f < F; ++f) ring.s[(u * F + f) % R] = wa.load(posa + ks * F + f);
+            constexpr int NRD = 2 * NTT, NLD = F;
+#pragma unroll
+            for (int i = 0; i < NMFMA; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                else if (i - NRD < NLD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
@@ -136,8 +226,7 @@ __device__ __forceinline__ void wave_moments(const f32x4 (&m)[4][NTT], float (&s
         float a = 0.f;
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft) a += (m[ft][tt][0] + m[ft][tt][1]) + (m[ft][tt][2] + m[ft][tt][3]);
-        a += __shfl_xor(a, 16, 64);
-        a += __shfl_xor(a, 32, 64);
+        a = sum_over_q(a);
         const float mean = a * (1.0f / 64);
         float b = 0.f;
 #pragma unroll
@@ -147,8 +236,7 @@ __device__ __forceinline__ void wave_moments(const f32x4 (&m)[4][NTT], float (&s
                 const float d = m[ft][tt][r] - mean;
                 b += d * d;
             }
-        b += __shfl_xor(b, 16, 64);
-        b += __shfl_xor(b, 32, 64);
+        b = sum_over_q(b);
         s[tt] = a;
         d2[tt] = b;
     }
@@ -199,8 +287,8 @@ struct EncX3Args {
 };
 
 // K|V projection of the 48 tokens in the X planes (heads 2 fw, 2 fw + 1) and their phi(K)^T V / Ksum slab.
-// The ring must hold the first R fragments of this wave's K|V stream; `wkv` points at fragment 0 (+ lane).
-__device__ __forceinline__ void kv_tail(Ring& ring, const bf16x8* __restrict__ wkv, const char* XH, const char* XL, int tok0, int L,
+// The ring must hold the first R fragments of this wave's K|V stream `wsk`.
+__device__ __forceinline__ void kv_tail(Ring& ring, const WStream& wsk, const char* XH, const char* XL, int tok0, int L,
                                         float* __restrict__ out, int fw, int lane) {
     const int c16 = lane & 15, q = lane >> 4;
     f32x4 kk[8][NTT];            // D[token 4q + r][feature c16]: ft 0..3 = K of heads 2fw (0,1), 2fw+1 (2,3); ft 4..7 = V likewise
@@ -208,7 +296,7 @@ __device__ __forceinline__ void kv_tail(Ring& ring, const bf16x8* __restrict__ w
     for (int ft = 0; ft < 8; ++ft)
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) kk[ft][tt] = zero4();
-    gemm_stage<8, 8, false, 0, KV_FRAGS - R>(kk, ring, wkv + (size_t)R * 64, XH, XL, ROWB, 0, c16, q, NoSide());
+    gemm_stage_rolled<8, 8, false>(kk, ring, wsk, R, XH, XL, ROWB, 0, c16, q);
     const float inv_len = 1.0f / (float)L;
 #pragma unroll
     for (int ft = 0; ft < 4; ++ft)
@@ -244,37 +332,46 @@ __device__ __forceinline__ void kv_tail(Ring& ring, const bf16x8* __restrict__ w
             float s = 0.f;                            // Ksum[d = 16 dt + c16]: exact f32 sum over the 48 tokens
 #pragma unroll
             for (int tt = 0; tt < NTT; ++tt) s += (kk[2 * hh + dt][tt][0] + kk[2 * hh + dt][tt][1]) + (kk[2 * hh + dt][tt][2] + kk[2 * hh + dt][tt][3]);
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
+            s = sum_over_q(s);
             if (q == 0) out[NH * 1024 + head * 32 + 16 * dt + c16] = s;
         }
     }
 }
 
-// global f32 rows -> swizzled (hi, lo) planes of the 48-token tile; zero fill beyond L
-__device__ __forceinline__ void stage_rows(char* ph, char* pl, const float* __restrict__ x, int tok0, int L, int tid) {
-    constexpr int ITEMS = TOK * (C / 8) / 256;       // 6 (row, 8-feature chunk) items per thread
+// global f32 rows -> swizzled (hi, lo) planes of the 48-token tile; zero fill beyond L.  load() and store() are separate so
+// that other loads can be queued behind the rows before the conversion waits for them.
+struct StagedRows {
+    static constexpr int ITEMS = TOK * (C / 8) / 256;       // 6 (row, 8-feature chunk) items per thread
     f32x4 v0[ITEMS], v1[ITEMS];
+    __device__ __forceinline__ void load(const float* __restrict__ x, int tok0, int L, int tid) {
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        const int it = tid + 256 * i, row = it >> 5, ch = it & 31;
-        v0[i] = v1[i] = zero4();
-        if (tok0 + row < L) {
-            const float* src = x + (size_t)(tok0 + row) * C + 8 * ch;
-            v0[i] = *reinterpret_cast<const f32x4*>(src);
-            v1[i] = *reinterpret_cast<const f32x4*>(src + 4);
+        for (int i = 0; i < ITEMS; ++i) {
+            const int it = tid + 256 * i, row = it >> 5, ch = it & 31;
+            v0[i] = v1[i] = zero4();
+            if (tok0 + row < L) {
+                const float* src = x + (size_t)(tok0 + row) * C + 8 * ch;
+                v0[i] = *reinterpret_cast<const f32x4*>(src);
+                v1[i] = *reinterpret_cast<const f32x4*>(src + 4);
+            }
         }
     }
+    // stash: exact f32 copy of the tile, [row][64 chunks of 16 B] with chunk ^ (row & 15) (NULL: none)
+    __device__ __forceinline__ void store(char* ph, char* pl, char* stash, int tid) const {
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        const int it = tid + 256 * i, row = it >> 5, ch = it & 31;
-        bf16x8 vh, vl;
-        split8(v0[i], v1[i], vh, vl);
-        const int off = row * ROWB + ((ch ^ (row & 15)) << 4);
-        *reinterpret_cast<bf16x8*>(ph + off) = vh;
-        *reinterpret_cast<bf16x8*>(pl + off) = vl;
+        for (int i = 0; i < ITEMS; ++i) {
+            const int it = tid + 256 * i, row = it >> 5, ch = it & 31;
+            bf16x8 vh, vl;
+            split8(v0[i], v1[i], vh, vl);
+            const int off = row * ROWB + ((ch ^ (row & 15)) << 4);
+            *reinterpret_cast<bf16x8*>(ph + off) = vh;
+            *reinterpret_cast<bf16x8*>(pl + off) = vl;
+            if (stash) {
+                *reinterpret_cast<f32x4*>(stash + row * (C * 4) + (((2 * ch) ^ (row & 15)) << 4)) = v0[i];
+                *reinterpret_cast<f32x4*>(stash + row * (C * 4) + (((2 * ch + 1) ^ (row & 15)) << 4)) = v1[i];
+            }
+        }
     }
-}
+};
 
 template <bool ONLY_KV>
 __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 1) void enc_x3_kernel(EncX3Args a) {
@@ -296,20 +393,31 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 1) void enc_x3_kernel(
     float* slab = a.partial + ((size_t)b * (a.tiles[0] + a.tiles[1]) + tile) * KV_PART_FLOATS;
 
     Ring ring;
-    const bf16x8* wkv = a.wkv ? a.wkv + (size_t)fw * KV_FRAGS * 64 + lane : nullptr;
+    const int fwu = __builtin_amdgcn_readfirstlane(fw);         // the wave index, provably uniform (scalar stream bases)
+    const bool tail = a.wkv != nullptr;
+    WStream wsk;                                                 // no tail: zero records, every load of it is dropped by the range check
+    wsk.open(tail ? a.wkv + (size_t)fwu * KV_FRAGS * 64 : a.wmain, tail ? KV_FRAGS : 0, lane);
     OPHIP_STAMP(a.stamps, wg, 0);
     if (ONLY_KV) {
+        StagedRows rows;
+        rows.load(xg, tok0, L, tid);
 #pragma unroll
-        for (int i = 0; i < R; ++i) ring.s[i] = wkv[(size_t)i * 64];
-        stage_rows(XH, XL, xg, tok0, L, tid);
+        for (int i = 0; i < R; ++i) ring.s[i] = wsk.load(i);
+        __builtin_amdgcn_sched_barrier(0);
+        rows.store(XH, XL, nullptr, tid);
         __syncthreads();
-        kv_tail(ring, wkv, XH, XL, tok0, L, slab, fw, lane);
+        kv_tail(ring, wsk, XH, XL, tok0, L, slab, fw, lane);
         return;
     }
-    const bf16x8* wm = a.wmain + (size_t)fw * MAIN_FRAGS * 64 + lane;
+    WStream wsm;
+    wsm.open(a.wmain + (size_t)fwu * MAIN_FRAGS * 64, MAIN_FRAGS, lane);
+    // loads return in issue order: the activation rows go first (the staging barrier waits for them only), the weight stream
+    // and this wave's slices of the attention state stay in flight behind them
+    StagedRows rows;
+    rows.load(xg, tok0, L, tid);
 #pragma unroll
-    for (int i = 0; i < R; ++i) ring.s[i] = wm[(size_t)i * 64];           // the stream starts while the activation tile is staged
-    // this wave's slices of the attention state: KV^T fragments (A operand, k = d in accumulator order) and Ksum
+    for (int i = 0; i < R; ++i) ring.s[i] = wsm.load(i);
+    // KV^T fragments (A operand, k = d in accumulator order) and Ksum of heads 2fw, 2fw+1
     const char* kvb = a.kv[s] + (size_t)b * a.kvbs;
     bf16x8 kvh[2][2], kvl[2][2];
     f32x4 ksm[2][2];
@@ -325,8 +433,26 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 1) void enc_x3_kernel(
         ksm[hh][0] = *reinterpret_cast<const f32x4*>(kp);
         ksm[hh][1] = *reinterpret_cast<const f32x4*>(kp + 16);
     }
-    stage_rows(XH, XL, xg, tok0, L, tid);
+    // LayerNorm parameters of this lane's features (parked in the accumulator-file half of the registers until needed)
+    f32x4 xr[4][NTT], g1[4], b1[4], g2[4], b2[4];
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+        const int f0 = 64 * fw + 16 * ft + 4 * q;
+        g1[ft] = *reinterpret_cast<const f32x4*>(a.ln + f0);
+        b1[ft] = *reinterpret_cast<const f32x4*>(a.ln + C + f0);
+        g2[ft] = *reinterpret_cast<const f32x4*>(a.ln + 2 * C + f0);
+        b2[ft] = *reinterpret_cast<const f32x4*>(a.ln + 3 * C + f0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    rows.store(XH, XL, HB, tid);                     // + an exact f32 copy in the (still idle) hidden buffers
     __syncthreads();
+    // residual rows in the accumulator layout, exact f32: four features of one token per lane and (ft, tt), read back from the
+    // stash (a global re-read in this layout touches 16 rows per instruction and stalls the ring queued behind it)
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt)
+            xr[ft][tt] = *reinterpret_cast<const f32x4*>(HB + (16 * tt + c16) * (C * 4) + (((16 * fw + 4 * ft + q) ^ c16) << 4));
     OPHIP_STAMP(a.stamps, wg, 1);
 
     // ---- Q projection (heads 2fw, 2fw+1), phi, linear attention from registers -> msg planes (Y) ----------------------
@@ -336,7 +462,7 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 1) void enc_x3_kernel(
         for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
             for (int tt = 0; tt < NTT; ++tt) qa[ft][tt] = zero4();
-        gemm_stage<4, 8, true, 0, 64>(qa, ring, wm + (size_t)(0 + R) * 64, XH, XL, ROWB, 0, c16, q, NoSide());
+        gemm_stage_rolled<4, 8, true>(qa, ring, wsm, 0 + R, XH, XL, ROWB, 0, c16, q);
         OPHIP_STAMP(a.stamps, wg, 2);
         const float S = a.srclen[s];
 #pragma unroll
@@ -351,8 +477,7 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 1) void enc_x3_kernel(
                     p1[r] = elu_plus_one_fast(qa[2 * hh + 1][tt][r]);
                     den += p0[r] * ksm[hh][0][r] + p1[r] * ksm[hh][1][r];
                 }
-                den += __shfl_xor(den, 16, 64);
-                den += __shfl_xor(den, 32, 64);
+                den = sum_over_q(den);
                 bf16x8 qh, ql;
                 split8(p0, p1, qh, ql);                          // B[k = d][token]: d = 4q + j (j < 4), 16 + 4q + j - 4
                 const float z = rcp_fast(den + 1e-6f) * S;
@@ -374,13 +499,7 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 1) void enc_x3_kernel(
     for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) m[ft][tt] = zero4();
-    f32x4 g1[4], b1[4];
-#pragma unroll
-    for (int ft = 0; ft < 4; ++ft) {
-        g1[ft] = *reinterpret_cast<const f32x4*>(a.ln + 64 * fw + 16 * ft + 4 * q);
-        b1[ft] = *reinterpret_cast<const f32x4*>(a.ln + C + 64 * fw + 16 * ft + 4 * q);
-    }
-    gemm_stage<4, 8, true, 0, 64>(m, ring, wm + (size_t)(64 + R) * 64, YH, YL, ROWB, 0, c16, q, NoSide());
+    gemm_stage_rolled<4, 8, true>(m, ring, wsm, 64 + R, YH, YL, ROWB, 0, c16, q);
     OPHIP_STAMP(a.stamps, wg, 4);
     {
         float sm[NTT], dm[NTT];
@@ -417,10 +536,14 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 1) void enc_x3_kernel(
 #pragma unroll
                 for (int tt = 0; tt < NTT; ++tt) merged_stats(scratch, tt, c16, mean[tt], rstd[tt]);
             }
-            if (ks >= 1 && ks <= 4) {
-                const int ft = ks - 1;
+            // 12 (ft, tt) quads over k-steps 1..7: two per step, the last two steps one each
+            const int first = ks == 0 ? 12 : (ks <= 5 ? 2 * (ks - 1) : 10 + (ks - 6));
+            const int count = ks == 0 ? 0 : (ks <= 5 ? 2 : 1);
 #pragma unroll
-                for (int tt = 0; tt < NTT; ++tt) {
+            for (int k = 0; k < 2; ++k) {
+                const int part = first + k;
+                if (k < count && part < 12) {
+                    const int ft = part / NTT, tt = part % NTT;
                     f32x4 v;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = (m[ft][tt][r] - mean[tt]) * rstd[tt] * g1[ft][r] + b1[ft][r];
@@ -428,27 +551,27 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 1) void enc_x3_kernel(
                 }
             }
         };
-        gemm_stage<2, 8, true, 0, 32>(hA, ring, wm + (size_t)(128 + R) * 64, XH, XL, ROWB, 0, c16, q, ln1_side);
+        gemm_stage<2, 8, true, 32, 32>(hA, ring, wsm, 128 + R, wsm, 0, XH, XL, ROWB, 0, c16, q, ln1_side);
     }
     __syncthreads();                                 // LayerNorm-1 output (the msg half of the MLP input) is in the Y planes
     OPHIP_STAMP(a.stamps, wg, 6);
-    gemm_stage<2, 8, true, 0, 32>(hA, ring, wm + (size_t)(160 + R) * 64, YH, YL, ROWB, 0, c16, q, NoSide());
+    gemm_stage_rolled<2, 8, true>(hA, ring, wsm, 160 + R, YH, YL, ROWB, 0, c16, q);
     OPHIP_STAMP(a.stamps, wg, 7);
     // stream positions: W0c0 128 | W0c1 192 | W2c0 256 | W0c2 288 | W2c1 352 | W0c3 384 | W2c2 448 | W2c3 480
     auto w0_x = [&](f32x4 (&hn)[2][NTT], const f32x4 (&hp)[2][NTT], int pos, int pbuf) {       // x half (k-steps 0..7) + previous chunk's store
-        gemm_stage<2, 8, true, 0, 32>(hn, ring, wm + (size_t)(pos + R) * 64, XH, XL, ROWB, 0, c16, q,
+        gemm_stage<2, 8, true, 32, 32>(hn, ring, wsm, pos + R, wsm, 0, XH, XL, ROWB, 0, c16, q,
                                       [&](int ks) { if (ks < 6) hidden_store(hp, pbuf, ks); });
     };
     auto w0_y = [&](f32x4 (&hn)[2][NTT], int pos) {
-        gemm_stage<2, 8, true, 0, 32>(hn, ring, wm + (size_t)(pos + 32 + R) * 64, YH, YL, ROWB, 0, c16, q, NoSide());
+        gemm_stage_rolled<2, 8, true>(hn, ring, wsm, pos + 32 + R, YH, YL, ROWB, 0, c16, q);
     };
-    auto w2 = [&](int buf, const bf16x8* refill, auto&& side) {
-        gemm_stage<4, 4, true, 0, 32>(o, ring, refill, HB + 2 * buf * HPLANE, HB + (2 * buf + 1) * HPLANE, HROWB, 0, c16, q, side);
+    auto w2 = [&](int buf, int pos, auto&& side) {
+        gemm_stage<4, 4, true, 32, 32>(o, ring, wsm, pos + R, wsm, 0, HB + 2 * buf * HPLANE, HB + (2 * buf + 1) * HPLANE, HROWB, 0, c16, q, side);
     };
     w0_x(hB, hA, 192, 0); w0_y(hB, 192);             // chunk 1 (+ chunk 0 -> hidden buffer 0)
     __syncthreads();
     OPHIP_STAMP(a.stamps, wg, 8);
-    w2(0, wm + (size_t)(256 + R) * 64, NoSide());
+    w2(0, 256, NoSide());
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
@@ -456,7 +579,7 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 1) void enc_x3_kernel(
     w0_x(hA, hB, 288, 1); w0_y(hA, 288);             // chunk 2 (+ chunk 1 -> buffer 1)
     __syncthreads();
     OPHIP_STAMP(a.stamps, wg, 9);
-    w2(1, wm + (size_t)(352 + R) * 64, NoSide());
+    w2(1, 352, NoSide());
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
@@ -464,27 +587,15 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 1) void enc_x3_kernel(
     w0_x(hB, hA, 384, 0); w0_y(hB, 384);             // chunk 3 (+ chunk 2 -> buffer 0; W2 chunk 0 finished two barriers ago)
     __syncthreads();
     OPHIP_STAMP(a.stamps, wg, 10);
-    // residual rows in the accumulator layout and LayerNorm-2 parameters: in flight under the last two W2 GEMMs
-    f32x4 xr[4][NTT], g2[4], b2[4];
-#pragma unroll
-    for (int ft = 0; ft < 4; ++ft) {
-        g2[ft] = *reinterpret_cast<const f32x4*>(a.ln + 2 * C + 64 * fw + 16 * ft + 4 * q);
-        b2[ft] = *reinterpret_cast<const f32x4*>(a.ln + 3 * C + 64 * fw + 16 * ft + 4 * q);
-#pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) {
-            const int tok = tok0 + 16 * tt + c16;
-            xr[ft][tt] = tok < L ? *reinterpret_cast<const f32x4*>(xg + (size_t)tok * C + 64 * fw + 16 * ft + 4 * q) : zero4();
-        }
-    }
-    w2(0, wm + (size_t)(448 + R) * 64, [&](int ks) {                     // chunk 3 -> buffer 1 beside W2 chunk 2
+    w2(0, 448, [&](int ks) {                     // chunk 3 -> buffer 1 beside W2 chunk 2
         if (2 * ks < 6) hidden_store(hB, 1, 2 * ks);
         if (2 * ks + 1 < 6) hidden_store(hB, 1, 2 * ks + 1);
     });
     __syncthreads();
     OPHIP_STAMP(a.stamps, wg, 11);
-    // the last 32 fragments of the main stream: their refills pull the head of the next layer's K|V stream (tail fused) or,
-    // without a tail, re-read this stream's last fragments (never consumed)
-    w2(1, wkv ? wkv : wm + (size_t)480 * 64, NoSide());
+    // the last 32 fragments of the main stream: the refills beyond its end pull the head of the next layer's K|V stream (or,
+    // without a tail, nothing: that stream has zero records)
+    gemm_stage<4, 4, true, 32, 32 - R>(o, ring, wsm, 480 + R, wsk, 0, HB + 2 * HPLANE, HB + 3 * HPLANE, HROWB, 0, c16, q, NoSide());
     OPHIP_STAMP(a.stamps, wg, 12);
 
     // ---- LayerNorm 2, residual, output rows (and their planes for the fused K|V tail) -----------------------------------
@@ -507,13 +618,13 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 1) void enc_x3_kernel(
             for (int r = 0; r < 4; ++r) v[r] = xr[ft][tt][r] + ((o[ft][tt][r] - mean) * rstd * g2[ft][r] + b2[ft][r]);
             if (tok < L) *reinterpret_cast<f32x4*>(yg + (size_t)tok * C + 64 * fw + 16 * ft + 4 * q) = v;
             else v = zero4();                                        // rows beyond L stay zero: they drop out of phi(K) and V
-            if (wkv) store_quad(v, XH, XL, ROWB, tt, c16, 64 * fw + 16 * ft + 4 * q);
+            if (tail) store_quad(v, XH, XL, ROWB, tt, c16, 64 * fw + 16 * ft + 4 * q);
         }
     }
     OPHIP_STAMP(a.stamps, wg, 13);
-    if (wkv) {
+    if (tail) {
         __syncthreads();
-        kv_tail(ring, wkv, XH, XL, tok0, L, slab, fw, lane);
+        kv_tail(ring, wsk, XH, XL, tok0, L, slab, fw, lane);
     }
     OPHIP_STAMP(a.stamps, wg, 14);
 }
@@ -526,33 +637,47 @@ struct KvSumX3Args {
 
 constexpr int KVS_G = 16;
 
-// fixed-order sum of the per-tile slabs; emits KV^T as (hi, lo) bf16 A fragments [head][vt][plane][lane][j = 4 dt + r] and Ksum f32
+// fixed-order sum of the per-tile slabs (four consecutive floats per thread, 16 tile groups per workgroup, groups merged in a
+// fixed order); emits KV^T as (hi, lo) bf16 A fragments [head][vt][plane][lane][j = 4 dt + r] and Ksum f32
 __global__ __launch_bounds__(1024) void kv_sum_x3_kernel(KvSumX3Args a) {
-    __shared__ float red[KVS_G][64];
+    __shared__ f32x4 red[KVS_G][64];
     const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int s = blockIdx.y & 1, b = blockIdx.y >> 1;
     const int ttot = a.tiles[0] + a.tiles[1];
     const int t0 = s ? a.tiles[0] : 0, nt = a.tiles[s];
-    const int e = blockIdx.x * 64 + o;
+    const int e = (blockIdx.x * 64 + o) * 4;
     const float* p = a.partial + ((size_t)b * ttot + t0) * KV_PART_FLOATS + e;
-    float acc = 0.f;
-    for (int t = g; t < nt; t += KVS_G) acc += p[(size_t)t * KV_PART_FLOATS];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int t = g;
+    for (; t + 3 * KVS_G < nt; t += 4 * KVS_G) {           // four independent loads in flight
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (size_t)t * KV_PART_FLOATS);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (size_t)(t + KVS_G) * KV_PART_FLOATS);
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (size_t)(t + 2 * KVS_G) * KV_PART_FLOATS);
+        const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (size_t)(t + 3 * KVS_G) * KV_PART_FLOATS);
+        acc = (((acc + v0) + v1) + v2) + v3;
+    }
+    for (; t < nt; t += KVS_G) acc += *reinterpret_cast<const f32x4*>(p + (size_t)t * KV_PART_FLOATS);
     red[g][o] = acc;
     __syncthreads();
     if (g == 0) {
-        float tot = 0.f;
+        f32x4 tot = red[0][o];
 #pragma unroll
-        for (int k = 0; k < KVS_G; ++k) tot += red[k][o];
+        for (int k = 1; k < KVS_G; ++k) tot += red[k][o];
         char* blk = a.kv + ((size_t)b * 2 + s) * KV_BLOCK_BYTES;
         if (e < NH * 1024) {
-            const int r = e & 3, ln = (e >> 2) & 63, vt = (e >> 8) & 1, dt = (e >> 9) & 1, head = e >> 10;
-            __bf16 hh, ll;
-            split_bf16(tot, hh, ll);
+            const int ln = (e >> 2) & 63, vt = (e >> 8) & 1, dt = (e >> 9) & 1, head = e >> 10;
+            bf16x4 vh, vl;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                __bf16 hh, ll;
+                split_bf16(tot[r], hh, ll);
+                vh[r] = hh; vl[r] = ll;
+            }
             const size_t fr = (size_t)(head * 2 + vt) * 2;
-            *reinterpret_cast<__bf16*>(blk + ((fr + 0) * 64 + ln) * 16 + (4 * dt + r) * 2) = hh;
-            *reinterpret_cast<__bf16*>(blk + ((fr + 1) * 64 + ln) * 16 + (4 * dt + r) * 2) = ll;
+            *reinterpret_cast<bf16x4*>(blk + ((fr + 0) * 64 + ln) * 16 + 8 * dt) = vh;
+            *reinterpret_cast<bf16x4*>(blk + ((fr + 1) * 64 + ln) * 16 + 8 * dt) = vl;
         } else {
-            reinterpret_cast<float*>(blk + KV_FRAG_BYTES)[e - NH * 1024] = tot;
+            *reinterpret_cast<f32x4*>(blk + KV_FRAG_BYTES + (size_t)(e - NH * 1024) * 4) = tot;
         }
     }
 }
@@ -613,7 +738,7 @@ extern "C" int ophip_encoder_layer_x3(const float* x3d, const float* x2d, float*
     }
     KvSumX3Args sa;
     sa.partial = partial; sa.kv = kv; sa.tiles[0] = t3; sa.tiles[1] = t2;
-    OPHIP_LAUNCH("kv_sum", stream, kv_sum_x3_kernel, dim3(KV_PART_FLOATS / 64, 2 * B), dim3(1024), 0, stream, sa);
+    OPHIP_LAUNCH("kv_sum", stream, kv_sum_x3_kernel, dim3(KV_PART_FLOATS / 256, 2 * B), dim3(1024), 0, stream, sa);
     OPHIP_CHECK_LAUNCH();
 
     aa.kv[0] = kv + (is_cross ? KV_BLOCK_BYTES : 0);

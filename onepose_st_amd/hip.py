@@ -12,7 +12,7 @@ import os
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libonepose_hip.so")
+_LIB_PATH = os.environ.get("OPHIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libonepose_hip.so")   # OPHIP_LIB: A/B builds
 _lib = None
 
 c_f = ctypes.c_void_p      # device float*
