@@ -93,11 +93,15 @@ def main():
                     help="also run the ResNet-FPN backbone (SURVEY 8f-1, HIP convolution kernels) on a synthetic image in every step; "
                          "its maps are then replaced by the planted feature maps (a random image has no matches)")
     ap.add_argument("--no-pnp", action="store_true", help="time the matcher only (no host PnP)")
-    ap.add_argument("--pnp-threads", type=int, default=3)
+    ap.add_argument("--pnp-policy", default="reference", choices=["reference", "adaptive"],
+                    help="RANSAC trial policy of the timed region: 'reference' = what the reference's inference loop runs (pycolmap branch of "
+                         "ransac_PnP: at least 10 000 trials per frame, metric_utils.py:155-165); 'adaptive' = its OpenCV branch (stops at the "
+                         "confidence).  The other policy and the matcher alone are timed too and reported beside `value`")
+    ap.add_argument("--pnp-threads", type=int, default=0, help="host threads of the PnP pool (0: this rank's share of the host cores minus 2)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses cuda:0 (one-GPU box, with --dist-backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-seconds", type=float, default=40.0, help="budget of the CPU baseline leg (all-core, full-forward and single-thread samples)")
     args = ap.parse_args()
 
     # ---- N > 1 without a launcher: this process becomes the driver and starts one child per GPU (it never touches the GPU
@@ -170,7 +174,10 @@ def main():
 
     # host PnP (metric: "2D-3D match + PnP"): frame t's pose is solved on host threads (C++, GIL released) while the GPU
     # matches frame t + 1; every pose is joined before the clock stops
-    pool = None if args.no_pnp else PnPPool(first["K"].numpy(), threads=max(1, args.pnp_threads), pnp_reprojection_error=7)
+    pnp_threads = args.pnp_threads if args.pnp_threads > 0 else max(1, host_cores() // world - 2)
+    pools = {} if args.no_pnp else {pol: PnPPool(first["K"].numpy(), threads=pnp_threads, pnp_reprojection_error=7, policy=pol)
+                                    for pol in ("reference", "adaptive")}
+    pool = pools.get(args.pnp_policy)
     pending = []
 
     inflight = []
@@ -241,6 +248,7 @@ def main():
     # allocator growth for the frames in flight, pinned buffers, side streams, PnP worker start-up, GPU clock ramp) never land
     # in a short timed region; the W warm-up steps and the K timed steps follow as the contract says
     blk_prev = None
+    setup_steps = 0
     t_setup = time.perf_counter()
     for rep in range(24):                                 # at most 24 x 16 steps (~0.4 s at c2), usually 2-3 blocks
         torch.cuda.synchronize()
@@ -250,6 +258,7 @@ def main():
         drain()
         join_poses()
         torch.cuda.synchronize()
+        setup_steps += 16
         blk = time.perf_counter() - tb
         if blk_prev is not None and abs(blk - blk_prev) <= 0.05 * blk_prev:
             break                                         # two consecutive blocks within 5 %: clocks and caches are settled
@@ -263,28 +272,46 @@ def main():
     poses = join_poses()
     n_inliers = int(poses[-1][1]) if poses else -1
 
-    for st in streams:
-        st.synchronize()
+    def timed_region(active_pool):
+        """W warm-up + exactly K timed steps with `active_pool` solving the poses (None: matcher only); returns seconds (max over ranks)"""
+        nonlocal pool
+        pool = active_pool
+        for i in range(args.warmup):
+            step(i)
+        drain()
+        join_poses()
+        for st in streams:
+            st.synchronize()
+        sync_all()
+        for k in host_t:
+            host_t[k] = 0.0
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        drain()
+        join_poses()
+        sync_all()
+        dt_ = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([dt_], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_ = float(tt.item())
+        return dt_
+
+    # side measurements first (the other PnP policy, the matcher alone), the contract's region last with the kernel timing on
+    other = {"reference": "adaptive", "adaptive": "reference"}[args.pnp_policy]
+    dt_other = timed_region(pools[other]) if pools else None
+    dt_matcher = timed_region(None)
+    model.cache_object = True                           # per-object cache of the keypoint encoding (config["hip_cache_object"]): a sequence's
+    dt_cached = timed_region(None)                      # frames share one resident object block; matcher only, to compare with dt_matcher
+    model.cache_object, model._obj_cache = False, None
     hip.timing_select("attn_apply")
-    sync_all()
-    for k in host_t:
-        host_t[k] = 0.0
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    drain()
-    join_poses()
-    sync_all()
-    dt = time.perf_counter() - t0
+    dt = timed_region(pools.get(args.pnp_policy))
     if os.environ.get("OPHIP_BENCH_TRACE") and rank == 0:
         print("host us/step: " + ", ".join(f"{k} {1e6 * v / args.steps:.0f}" for k, v in host_t.items()) + f"; wall {1e6 * dt / args.steps:.0f}", file=sys.stderr)
     launches, kern_ms = hip.timing_read()
     hip.timing_select("")
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
 
     # HBM bytes per launch of the roofline kernel: from the committed PMC pass (separate rocprofv3 --pmc runs), not live
     traffic = None
@@ -310,7 +337,11 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "setup_steps_untimed": setup_steps + 4 * args.warmup,      # settle blocks before the W warm-up steps + the warm-ups of the side regions
         "ms_per_step": dt / args.steps * 1e3,
+        "value_matcher_only": frames_total / dt_matcher,
+        "value_matcher_only_object_cached": frames_total / dt_cached,
+        ("value_pnp_" + other): (frames_total / dt_other) if dt_other else None,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -322,8 +353,10 @@ def main():
             "frames_per_step": B,
             "matches_per_frame": n_matches // max(B, 1),
             "timed_region": "rows a1-a11 (PE, keypoint encoding, 6-layer coarse encoder, dual-softmax + mutual-NN incl. the "
-                            "N x M conf_matrix write, fine refinement)" + ("" if args.no_pnp else " + host PnP/RANSAC of every frame "
-                            f"(C++, {args.pnp_threads} host threads, overlapped with the next frame, all joined before the clock stops)")
+                            "N x M conf_matrix write, fine refinement)" + ("" if args.no_pnp else " + host PnP/RANSAC of every frame (own C++ "
+                            f"estimator, trial policy '{args.pnp_policy}': " + ("at least 10 000 RANSAC trials per frame like the reference's pycolmap call"
+                            if args.pnp_policy == "reference" else "adaptive stop at confidence 0.99 like the reference's OpenCV branch")
+                            + f"; {pnp_threads} host threads, overlapped with the following frames, all joined before the clock stops)")
                             + ("; backbone (HIP convolutions) inside, on a synthetic image" if args.with_backbone else "; backbone outside"),
             "pnp_inliers_per_frame": n_inliers,
             "streams": len(streams),
@@ -347,20 +380,43 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import onepose_oracle as orc          # cpu_baseline leg only
+        import statistics
 
         cores = host_cores()
-        torch.set_num_threads(cores)
+        budget = args.cpu_seconds
+
+        def time_frames(fn, n_max, seconds):
+            """1 warm-up, then up to n_max frames or `seconds`; -> (median frames/s, n)"""
+            fn()
+            ts, t_all = [], time.perf_counter()
+            while len(ts) < n_max and (time.perf_counter() - t_all) < seconds:
+                t1 = time.perf_counter()
+                fn()
+                ts.append(time.perf_counter() - t1)
+            return 1.0 / statistics.median(ts), len(ts)
+
+        def feature_frame():
+            orc.forward_from_features(sd, cfg, first, first["feat_c"], first["feat_f"], image_hw)
+
+        img = torch.rand(1, 1, H, W, generator=torch.Generator().manual_seed(7))
+
+        def full_frame():          # backbone on the synthetic image + the path on the planted maps (a random image has no matches)
+            orc.backbone_8_2(sd, img)
+            feature_frame()
+
         with torch.no_grad():
-            orc.forward_from_features(sd, cfg, first, first["feat_c"], first["feat_f"], image_hw)     # warm-up
-            n, t0c = 0, time.perf_counter()
-            while n < 8 and (time.perf_counter() - t0c) < args.cpu_seconds:
-                orc.forward_from_features(sd, cfg, first, first["feat_c"], first["feat_f"], image_hw)
-                n += 1
-            dtc = time.perf_counter() - t0c
+            torch.set_num_threads(cores)
+            v_all, n_all = time_frames(feature_frame, 7, 0.45 * budget)
+            v_full, n_full = time_frames(full_frame, 3, 0.25 * budget)
+            torch.set_num_threads(1)
+            v_one, n_one = time_frames(feature_frame, 2, 0.3 * budget)
+            torch.set_num_threads(cores)
         result["cpu_baseline"] = {
-            "value": n / dtc, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n} frame(s) of the same {args.workload} workload (feature boundary, B=1) after 1 warm-up, torch fp32 "
-                      f"CPU oracle, {cores} threads",
+            "value": v_all, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"median of {n_all} frame(s) of the same {args.workload} workload (feature boundary, B=1) after 1 warm-up, torch fp32 "
+                      f"CPU oracle, {cores} threads; matcher only (no PnP)",
+            "single_thread": {"value": v_one, "frames": n_one},
+            "full_forward": {"value": v_full, "frames": n_full, "cores": cores, "note": "oracle backbone (ResNet-FPN) + matcher"},
         }
     if rank == 0:
         print(json.dumps(result))

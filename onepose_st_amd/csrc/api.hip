@@ -17,6 +17,25 @@ int ophip_bad_arg(const char* where, const char* what) {
     return -1;
 }
 
+// ---- dynamic-LDS limit of a kernel, once per (kernel, device): a process may drive several GPUs ------------------------
+#include <map>
+#include <mutex>
+#include <utility>
+int ophip_lds_attr(const void* fn, size_t bytes, const char* what) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, size_t> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return ophip_fail(e, what);
+    std::lock_guard<std::mutex> lk(mu);
+    size_t& have = done[{fn, dev}];
+    if (bytes <= have) return 0;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return ophip_fail(e, what);
+    have = bytes;
+    return 0;
+}
+
 // ---- per-kernel event timing ---------------------------------------------------------------------
 namespace {
 constexpr int kMaxEvents = 8192;
@@ -24,6 +43,7 @@ char g_sel[64] = "";
 hipEvent_t* g_start = nullptr;
 hipEvent_t* g_stop = nullptr;
 int g_used = 0;
+int g_dev = -1;              // device the events were created on
 }
 
 ophip_timed::ophip_timed(const char* name, hipStream_t s) : slot(-1), stream(s) {
@@ -37,7 +57,15 @@ ophip_timed::~ophip_timed() {
 
 extern "C" int ophip_timing_select(const char* kernel_name) {
     if (!kernel_name || strlen(kernel_name) >= sizeof(g_sel)) return ophip_bad_arg(__func__, "kernel name");
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (g_start && kernel_name[0] && dev != g_dev) {        // events belong to a device: re-create them when the caller switched
+        for (int i = 0; i < kMaxEvents; ++i) { (void)hipEventDestroy(g_start[i]); (void)hipEventDestroy(g_stop[i]); }
+        delete[] g_start; delete[] g_stop;
+        g_start = g_stop = nullptr;
+    }
     if (!g_start && kernel_name[0]) {
+        g_dev = dev;
         g_start = new hipEvent_t[kMaxEvents];
         g_stop = new hipEvent_t[kMaxEvents];
         for (int i = 0; i < kMaxEvents; ++i) {

@@ -626,15 +626,9 @@ extern "C" int ophip_coarse_match(const float* feat3d, const float* feat2d, cons
         // dynamic LDS = max(operand tiles, S staging image of the epilogue)
         const size_t tiles = nsplit == 0 ? (size_t)(TM + TN) * LDT * sizeof(float) : (size_t)(nsplit == 3 ? 4 : 2) * TM * SPITCH;
         const size_t lds = tiles > SIM_STAGE_BYTES ? tiles : SIM_STAGE_BYTES;
-        static bool attr[3] = {false, false, false};
         const void* fn = nsplit == 0 ? reinterpret_cast<const void*>(sim_stats_kernel)
                        : nsplit == 3 ? reinterpret_cast<const void*>(sim_stats_bf16_kernel<3>) : reinterpret_cast<const void*>(sim_stats_bf16_kernel<1>);
-        const int ai = nsplit == 0 ? 0 : (nsplit == 3 ? 2 : 1);
-        if (!attr[ai]) {
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return ophip_fail(e, "hipFuncSetAttribute(sim_stats)");
-            attr[ai] = true;
-        }
+        if (int rc = ophip_lds_attr(fn, lds, "hipFuncSetAttribute(sim_stats)")) return rc;
         if (nsplit == 0) OPHIP_LAUNCH("sim_stats", stream, sim_stats_kernel, dim3(ntc, ntr, B), dim3(256), lds, stream, sa);
         else if (nsplit == 3) OPHIP_LAUNCH("sim_stats", stream, sim_stats_bf16_kernel<3>, dim3(ntc, ntr, B), dim3(256), lds, stream, sa);
         else OPHIP_LAUNCH("sim_stats", stream, sim_stats_bf16_kernel<1>, dim3(ntc, ntr, B), dim3(256), lds, stream, sa);

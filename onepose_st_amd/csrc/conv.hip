@@ -316,12 +316,7 @@ int launch_conv_tile(const ConvArgs& a, int B, hipStream_t stream) {
     size_t lds = (size_t)(NS == 3 ? 2 : 1) * PW * PH * PIXB;
     const size_t stage = (size_t)32 * 64 * NT * 4;           // one output row of the workgroup tile in f32
     if (stage > lds) lds = stage;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<KS, STRIDE, NS, TH, NT, WR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return ophip_fail(e, "hipFuncSetAttribute(conv_mfma)");
-        attr = true;
-    }
+    if (int rc = ophip_lds_attr(reinterpret_cast<const void*>(conv_mfma_kernel<KS, STRIDE, NS, TH, NT, WR>), lds, "hipFuncSetAttribute(conv_mfma)")) return rc;
     const dim3 grid((a.Wout + TW - 1) / TW, (a.Hout + TH * WR - 1) / (TH * WR), B * ((a.ctiles + 2 * NT - 1) / (2 * NT)));
     OPHIP_LAUNCH("conv", stream, (conv_mfma_kernel<KS, STRIDE, NS, TH, NT, WR>), grid, dim3(128 * WR), lds, stream, a);
     OPHIP_CHECK_LAUNCH();

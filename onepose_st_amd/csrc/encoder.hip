@@ -282,12 +282,7 @@ extern "C" int ophip_encoder_layer(const float* x3d, const float* x2d, float* y3
     aa.w0 = reinterpret_cast<const f32x4*>(w0); aa.w2 = reinterpret_cast<const f32x4*>(w2);
     aa.g1 = ln; aa.b1 = ln + C; aa.g2 = ln + 2 * C; aa.b2 = ln + 3 * C;
     const size_t lds_attn = (size_t)OPHIP_TOK * (2 * LDX + LDH) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attn);
-        if (e != hipSuccess) return ophip_fail(e, "hipFuncSetAttribute(attn_apply)");
-        attr_set = true;
-    }
+    if (int rc = ophip_lds_attr(reinterpret_cast<const void*>(attn_apply_kernel), lds_attn, "hipFuncSetAttribute(attn_apply)")) return rc;
     OPHIP_LAUNCH("attn_apply", stream, attn_apply_kernel, dim3(t3 + t2, B), dim3(256), lds_attn, stream, aa);
     OPHIP_CHECK_LAUNCH();
     return 0;

@@ -687,8 +687,7 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(TT == 1 ? 2 : 1, TT == 1 
 
 template <typename K>
 int set_lds(K kernel, size_t bytes, const char* what) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    return e == hipSuccess ? 0 : ophip_fail(e, what);
+    return ophip_lds_attr(reinterpret_cast<const void*>(kernel), bytes, what);
 }
 
 }  // namespace
@@ -739,11 +738,9 @@ extern "C" int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, floa
         ka.w_hi = w_hi + C * C / 8; ka.w_lo = w_lo + C * C / 8;
         ka.partial = partial;
         const size_t lds_kv = (size_t)PL * 32 * ROWB;
-        static bool attr_kv[2] = {false, false};
-        const int vi = nsplit == 3 ? 1 : 0;
 #define OPHIP_KV_CASE(NS_)                                                                                                       \
         {                                                                                                                        \
-            if (!attr_kv[vi]) { if (int rc = set_lds(kv_reduce_bf16_kernel<NS_, 32>, lds_kv, "hipFuncSetAttribute(kv_reduce_bf16)")) return rc; attr_kv[vi] = true; } \
+            if (int rc = set_lds(kv_reduce_bf16_kernel<NS_, 32>, lds_kv, "hipFuncSetAttribute(kv_reduce_bf16)")) return rc; \
             OPHIP_LAUNCH("kv_reduce", stream, (kv_reduce_bf16_kernel<NS_, 32>), dim3(s3 + s2, B), dim3(256), lds_kv, stream, ka);  \
         }
         if (nsplit == 3) OPHIP_KV_CASE(3)
@@ -778,23 +775,19 @@ extern "C" int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, floa
     size_t lds_at = (size_t)PL * (2 * TOK * ROWB + TOK * HROWB);
     const size_t lds_fuse = (size_t)TOK * C * 4 + (size_t)PL * TOK * ROWB;
     if (lds_fuse > lds_at) lds_at = lds_fuse;
-    static bool attr_at[4] = {false, false, false, false};
-    const int wi = (nsplit == 3 ? 2 : 0) + (TT == 2 ? 1 : 0);
 #define OPHIP_AT_CASE(NS_, TT_)                                                                                                  \
     {                                                                                                                            \
-        if (!attr_at[wi]) { if (int rc = set_lds(attn_apply_bf16_kernel<NS_, TT_>, lds_at, "hipFuncSetAttribute(attn_apply_bf16)")) return rc; attr_at[wi] = true; } \
+        if (int rc = set_lds(attn_apply_bf16_kernel<NS_, TT_>, lds_at, "hipFuncSetAttribute(attn_apply_bf16)")) return rc; \
         OPHIP_LAUNCH("attn_apply", stream, (attn_apply_bf16_kernel<NS_, TT_>), dim3(t3 + t2, B), dim3(256), lds_at, stream, aa);    \
     }
     if (f8) {
         const size_t lds_f8 = (size_t)2 * PL * TOK * ROWB + 32768;       // X, Y planes + max(hidden planes, f32 partial sums)
         if (lds_f8 > lds_at) lds_at = lds_f8;
-        static bool attr_f8[2] = {false, false};
-        const int fi = nsplit == 3 ? 1 : 0;
         if (nsplit == 3) {
-            if (!attr_f8[fi]) { if (int rc = set_lds(attn_apply_f8_kernel<3>, lds_at, "hipFuncSetAttribute(attn_apply_f8)")) return rc; attr_f8[fi] = true; }
+            if (int rc = set_lds(attn_apply_f8_kernel<3>, lds_at, "hipFuncSetAttribute(attn_apply_f8)")) return rc;
             OPHIP_LAUNCH("attn_apply", stream, (attn_apply_f8_kernel<3>), dim3(t3 + t2, B), dim3(512), lds_at, stream, aa);
         } else {
-            if (!attr_f8[fi]) { if (int rc = set_lds(attn_apply_f8_kernel<1>, lds_at, "hipFuncSetAttribute(attn_apply_f8)")) return rc; attr_f8[fi] = true; }
+            if (int rc = set_lds(attn_apply_f8_kernel<1>, lds_at, "hipFuncSetAttribute(attn_apply_f8)")) return rc;
             OPHIP_LAUNCH("attn_apply", stream, (attn_apply_f8_kernel<1>), dim3(t3 + t2, B), dim3(512), lds_at, stream, aa);
         }
     }

@@ -682,10 +682,6 @@ __global__ __launch_bounds__(1024) void kv_sum_x3_kernel(KvSumX3Args a) {
     }
 }
 
-int lds_attr(const void* kernel, size_t bytes, const char* what) {
-    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    return e == hipSuccess ? 0 : ophip_fail(e, what);
-}
 
 }  // namespace
 
@@ -715,8 +711,8 @@ extern "C" int ophip_encoder_layer_x3(const float* x3d, const float* x2d, float*
     const bf16x8* wmain = reinterpret_cast<const bf16x8*>(wpack);
     const bf16x8* wkv_own = wmain + (size_t)4 * MAIN_FRAGS * 64;
     const float* ln = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wpack) + (size_t)4 * (MAIN_FRAGS + KV_FRAGS) * 1024);
-    if (int rc = lds_attr(reinterpret_cast<const void*>(enc_x3_kernel<false>), LDS_BYTES, "hipFuncSetAttribute(enc_x3)")) return rc;
-    if (int rc = lds_attr(reinterpret_cast<const void*>(enc_x3_kernel<true>), LDS_BYTES, "hipFuncSetAttribute(enc_x3 kv)")) return rc;
+    if (int rc = ophip_lds_attr(reinterpret_cast<const void*>(enc_x3_kernel<false>), LDS_BYTES, "hipFuncSetAttribute(enc_x3)")) return rc;
+    if (int rc = ophip_lds_attr(reinterpret_cast<const void*>(enc_x3_kernel<true>), LDS_BYTES, "hipFuncSetAttribute(enc_x3 kv)")) return rc;
 
     EncX3Args aa;
     aa.x[0] = x3d; aa.x[1] = x2d; aa.y[0] = y3d; aa.y[1] = y2d;

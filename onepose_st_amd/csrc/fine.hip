@@ -237,12 +237,7 @@ extern "C" int ophip_fine_refine(const float* feat_f, long long fs_b, long long 
     a.wc = wc; a.stride = stride; a.fine_scale = fine_scale;
     a.expec_f = expec_f; a.mkq_f = mkpts_f; a.dbg_win = dbg_win; a.dbg_f3 = dbg_f3;
     const size_t lds = (size_t)32 * (2 * LDF + LDF2) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fine_refine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return ophip_fail(e, "hipFuncSetAttribute(fine_refine)");
-        attr_set = true;
-    }
+    if (int rc = ophip_lds_attr(reinterpret_cast<const void*>(fine_refine_kernel), lds, "hipFuncSetAttribute(fine_refine)")) return rc;
     OPHIP_LAUNCH("fine_refine", (hipStream_t)stream_, fine_refine_kernel, dim3(max_matches), dim3(256), lds, (hipStream_t)stream_, a);
     OPHIP_CHECK_LAUNCH();
     return 0;

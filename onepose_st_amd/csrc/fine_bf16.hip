@@ -400,8 +400,7 @@ __global__ __launch_bounds__(NM * 256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_refi
 
 template <typename K>
 int set_lds(K kernel, size_t bytes, const char* what) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    return e == hipSuccess ? 0 : ophip_fail(e, what);
+    return ophip_lds_attr(reinterpret_cast<const void*>(kernel), bytes, what);
 }
 
 }  // namespace
@@ -436,11 +435,9 @@ extern "C" int ophip_fine_refine_bf16(const float* feat_f, long long fs_b, long 
     const int NM = nm_env == 2 ? 2 : 1;
     const int grid = (max_matches + NM - 1) / NM;
     const size_t lds = (size_t)NM * (nsplit == 3 ? (16 + 16 + 32) : (8 + 8 + 16)) * 1024;
-    static bool attr[4] = {false, false, false, false};
-    const int vi = (nsplit == 3 ? 2 : 0) + (NM - 1);
 #define OPHIP_FINE_CASE(NS_, NM_)                                                                                               \
     {                                                                                                                           \
-        if (!attr[vi]) { if (int rc = set_lds(fine_refine_bf16_kernel<NS_, NM_>, lds, "hipFuncSetAttribute(fine_refine_bf16)")) return rc; attr[vi] = true; } \
+        if (int rc = set_lds(fine_refine_bf16_kernel<NS_, NM_>, lds, "hipFuncSetAttribute(fine_refine_bf16)")) return rc; \
         OPHIP_LAUNCH("fine_refine", stream, (fine_refine_bf16_kernel<NS_, NM_>), dim3(grid), dim3(NM_ * 256), lds, stream, a);  \
     }
     if (nsplit == 3 && NM == 2) OPHIP_FINE_CASE(3, 2)

@@ -297,12 +297,7 @@ extern "C" int ophip_kpt_encode(const float* keypoints3d, long long kpts_bstride
     a.b1 = w; a.b2 = w + 32; a.b3 = w + 96; a.b4 = w + 224;
     a.out = out_bnc; a.B = B; a.N = N;
     const size_t lds = (size_t)(32 * (L0 + L1 + L2 + L3 + LO) + KD * LD_D) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kpt_encode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return ophip_fail(e, "hipFuncSetAttribute(kpt_encode)");
-        attr_set = true;
-    }
+    if (int rc = ophip_lds_attr(reinterpret_cast<const void*>(kpt_encode_kernel), lds, "hipFuncSetAttribute(kpt_encode)")) return rc;
     OPHIP_LAUNCH("kpt_encode", stream, kpt_encode_kernel, dim3((N + 31) / 32, B), dim3(256), lds, stream, a);
     OPHIP_CHECK_LAUNCH();
     return 0;

@@ -147,6 +147,8 @@ __device__ __forceinline__ void rows_layernorm(float* img, int ld, const float* 
 
 int ophip_fail(hipError_t e, const char* where);
 int ophip_bad_arg(const char* where, const char* what);
+// raise a kernel's dynamic-LDS limit (cached per kernel and device)
+int ophip_lds_attr(const void* fn, size_t bytes, const char* what);
 
 // Optional per-kernel HIP-event timing (bench.py's roofline leg): when `name` is the kernel selected with
 // ophip_timing_select(), the scope records an event pair around the launch on the launch stream.

@@ -6,9 +6,12 @@
 // outputs, so this is NOT a restatement of their internals ("parity unpinned"): it is the build's own estimator,
 // applied identically to the HIP path's matches and to the oracle's matches so that pose parity is checkable.
 //
-//   hypotheses : 6-point DLT on calibrated rays (smallest eigenvector of the 12x12 normal matrix by cyclic Jacobi),
-//                projected to SO(3) by Newton polar iteration, cheirality check
-//   scoring    : reprojection error < threshold (pixels), adaptive stopping at the requested confidence
+//   hypotheses : 6-point DLT on calibrated rays: the normal matrix's block structure reduces it to the smallest eigenvector
+//                of a 4x4 Schur complement (inverse iteration), projected to SO(3) by Newton polar iteration, cheirality check
+//   scoring    : reprojection error < threshold (pixels) on a float structure-of-arrays copy (AVX2 / AVX-512 clones of
+//                one loop, hypotheses that cannot win any more dropped block by block); a candidate best is re-scored in
+//                double, which decides; at least min_iters trials (the
+//                reference's pycolmap call runs >= 10 000), then adaptive stopping at the requested confidence
 //   refinement : Levenberg-Marquardt on the inliers (6 dof, analytic Jacobian), inlier set re-evaluated once
 //   randomness : xorshift64* seeded by the caller -> bit-reproducible
 #include <cmath>
@@ -16,8 +19,10 @@
 #include <cstring>
 #include <condition_variable>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -97,6 +102,124 @@ bool polar_rotation(double* R) {
     return true;
 }
 
+// eigenvector of the smallest eigenvalue of a symmetric positive semi-definite N x N matrix: inverse iteration on
+// A + eps I (Cholesky, three solves from a fixed start).  The DLT matrix of a near-exact minimal sample has one eigenvalue
+// ~ 0 far below the rest, so the iteration converges in one or two steps -- what makes the reference's 10 000-trial floor
+// affordable (a cyclic Jacobi decomposition of the 12 x 12 normal matrix took ~45 us per hypothesis).
+template <int N>
+bool smallest_eigvec(const double* A, double trace, double* v) {
+    double Lm[N * N];
+    const double eps = 1e-13 * (trace > 0 ? trace : 1.0);
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double sum = A[i * N + j] + (i == j ? eps : 0.0);
+            for (int k = 0; k < j; ++k) sum -= Lm[i * N + k] * Lm[j * N + k];
+            if (i == j) {
+                if (!(sum > 0.0)) return false;
+                Lm[i * N + i] = std::sqrt(sum);
+            } else {
+                Lm[i * N + j] = sum / Lm[j * N + j];
+            }
+        }
+    for (int i = 0; i < N; ++i) v[i] = 1.0 + 0.0625 * i;          // fixed, generic start
+    for (int it = 0; it < 3; ++it) {
+        double y[N];
+        for (int i = 0; i < N; ++i) {
+            double sum = v[i];
+            for (int k = 0; k < i; ++k) sum -= Lm[i * N + k] * y[k];
+            y[i] = sum / Lm[i * N + i];
+        }
+        for (int i = N - 1; i >= 0; --i) {
+            double sum = y[i];
+            for (int k = i + 1; k < N; ++k) sum -= Lm[k * N + i] * v[k];
+            v[i] = sum / Lm[i * N + i];
+        }
+        double nrm = 0.0;
+        for (int i = 0; i < N; ++i) nrm += v[i] * v[i];
+        if (!(nrm > 0.0) || !std::isfinite(nrm)) return false;
+        nrm = 1.0 / std::sqrt(nrm);
+        for (int i = 0; i < N; ++i) v[i] *= nrm;
+    }
+    return true;
+}
+
+// inverse of a symmetric positive definite 4 x 4 matrix (Cholesky); false when not positive definite
+bool inv4_spd(const double* A, double* Ai) {
+    double Lm[16] = {0};
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double sum = A[i * 4 + j];
+            for (int k = 0; k < j; ++k) sum -= Lm[i * 4 + k] * Lm[j * 4 + k];
+            if (i == j) {
+                if (!(sum > 1e-300)) return false;
+                Lm[i * 4 + i] = std::sqrt(sum);
+            } else {
+                Lm[i * 4 + j] = sum / Lm[j * 4 + j];
+            }
+        }
+    for (int c = 0; c < 4; ++c) {                      // solve L L^T x = e_c
+        double y[4], x[4];
+        for (int i = 0; i < 4; ++i) {
+            double sum = i == c ? 1.0 : 0.0;
+            for (int k = 0; k < i; ++k) sum -= Lm[i * 4 + k] * y[k];
+            y[i] = sum / Lm[i * 4 + i];
+        }
+        for (int i = 3; i >= 0; --i) {
+            double sum = y[i];
+            for (int k = i + 1; k < 4; ++k) sum -= Lm[k * 4 + i] * x[k];
+            x[i] = sum / Lm[i * 4 + i];
+        }
+        for (int i = 0; i < 4; ++i) Ai[i * 4 + c] = x[i];
+    }
+    return true;
+}
+
+// float copy of the correspondences in structure-of-arrays form: the RANSAC loop scores every hypothesis on it with SIMD
+// (the winner's inlier mask and count are then re-evaluated in double precision)
+struct FastPoints {
+    int n = 0;
+    std::vector<float> x, y, z, u, v;
+};
+
+// inliers and truncated cost of pose (premultiplied by K: 3 x 4 row-major floats) -- the vectorised hot loop of the RANSAC.
+// Scored in blocks of 256 points; after each block the hypothesis is dropped as soon as it can no longer beat the best one
+// (count first, then cost: with `rest` points to go it needs cnt + rest >= best_cnt, and on a possible tie a cost below
+// best_cost, while the cost only grows).  The decision is exactly the one a full pass would take; returns false when dropped.
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+__attribute__((target_clones("avx512f", "avx2", "default")))
+#endif
+bool score_fast(const FastPoints& F, const float* kp, float thr2, int best_cnt, float best_cost, int* cnt_out, float* cost_out) {
+    int cnt = 0;
+    float cost = 0.f;
+    const float *X = F.x.data(), *Y = F.y.data(), *Z = F.z.data(), *U = F.u.data(), *V = F.v.data();
+    constexpr int BLK = 256;
+    for (int i0 = 0; i0 < F.n; i0 += BLK) {
+        const int i1 = i0 + BLK < F.n ? i0 + BLK : F.n;
+        int c_b = 0;
+        float s_b = 0.f;
+#pragma omp simd reduction(+ : c_b, s_b)
+        for (int i = i0; i < i1; ++i) {
+            const float a = kp[0] * X[i] + kp[1] * Y[i] + kp[2] * Z[i] + kp[3];
+            const float b = kp[4] * X[i] + kp[5] * Y[i] + kp[6] * Z[i] + kp[7];
+            const float c = kp[8] * X[i] + kp[9] * Y[i] + kp[10] * Z[i] + kp[11];
+            const float ic = 1.0f / c;
+            const float du = a * ic - U[i], dv = b * ic - V[i];
+            const float e2 = du * du + dv * dv;
+            const bool in = (c > 1e-12f) & (e2 < thr2);
+            c_b += in ? 1 : 0;
+            s_b += in ? e2 : thr2;
+        }
+        cnt += c_b;
+        cost += s_b;
+        const int reach = cnt + (F.n - i1);              // the count if every remaining point were an inlier
+        if (reach < best_cnt || (reach == best_cnt && !(cost < best_cost))) return false;
+        if (cnt <= best_cnt && reach <= best_cnt && !(cost < best_cost)) return false;
+    }
+    *cnt_out = cnt;
+    *cost_out = cost;
+    return true;
+}
+
 struct Problem {
     int n;
     const double* K;          // 3x3
@@ -147,27 +270,47 @@ bool dlt_pose(const Problem& P, const int* idx, int m, double* pose) {
     }
     if (sc < 1e-300) return false;
     sc = std::sqrt(3.0) * m / sc;
-    double A[144];
-    std::memset(A, 0, sizeof(A));
+    // normal matrix of the DLT rows  [Xh 0 -x Xh ; 0 Xh -y Xh]:  A = [[S, 0, -Sx], [0, S, -Sy], [-Sx, -Sy, Sxx + Syy]]  (4x4 blocks)
+    double S[16] = {0}, Sx[16] = {0}, Sy[16] = {0}, Sq[16] = {0};
     for (int k = 0; k < m; ++k) {
         const int i = idx[k];
         const double Xh[4] = {(P.X[3 * i] - mu[0]) * sc, (P.X[3 * i + 1] - mu[1]) * sc, (P.X[3 * i + 2] - mu[2]) * sc, 1.0};
-        const double x = P.ray[2 * i], y = P.ray[2 * i + 1];
-        double r1[12], r2[12];
-        for (int j = 0; j < 4; ++j) {
-            r1[j] = Xh[j]; r1[4 + j] = 0.0; r1[8 + j] = -x * Xh[j];
-            r2[j] = 0.0; r2[4 + j] = Xh[j]; r2[8 + j] = -y * Xh[j];
-        }
-        for (int a = 0; a < 12; ++a)
-            for (int b = 0; b < 12; ++b) A[a * 12 + b] += r1[a] * r1[b] + r2[a] * r2[b];
+        const double x = P.ray[2 * i], y = P.ray[2 * i + 1], q2 = x * x + y * y;
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b) {
+                const double o = Xh[a] * Xh[b];
+                S[a * 4 + b] += o; Sx[a * 4 + b] += x * o; Sy[a * 4 + b] += y * o; Sq[a * 4 + b] += q2 * o;
+            }
     }
-    double V[144];
-    jacobi_eig<12>(A, V);
-    int best = 0;
-    for (int j = 1; j < 12; ++j)
-        if (A[j * 12 + j] < A[best * 12 + best]) best = j;
+    // minimise p^T A p over the last projection row p3 (|p3| = 1) with the first two rows eliminated: p1 = S^-1 Sx p3,
+    // p2 = S^-1 Sy p3, and p3 = the eigenvector of the smallest eigenvalue of the 4 x 4 Schur complement
+    // Sq - Sx S^-1 Sx - Sy S^-1 Sy (all blocks symmetric): a 4 x 4 problem instead of the 12 x 12 one
+    double Si[16];
+    if (!inv4_spd(S, Si)) return false;
+    double SiSx[16], SiSy[16], C4[16];
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) {
+            double u = 0.0, v = 0.0;
+            for (int k = 0; k < 4; ++k) { u += Si[a * 4 + k] * Sx[k * 4 + b]; v += Si[a * 4 + k] * Sy[k * 4 + b]; }
+            SiSx[a * 4 + b] = u; SiSy[a * 4 + b] = v;
+        }
+    double tr = 0.0;
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) {
+            double u = Sq[a * 4 + b];
+            for (int k = 0; k < 4; ++k) u -= Sx[a * 4 + k] * SiSx[k * 4 + b] + Sy[a * 4 + k] * SiSy[k * 4 + b];
+            C4[a * 4 + b] = u;
+        }
+    for (int a = 0; a < 4; ++a)
+        for (int b = a + 1; b < 4; ++b) C4[a * 4 + b] = C4[b * 4 + a] = 0.5 * (C4[a * 4 + b] + C4[b * 4 + a]);
+    for (int a = 0; a < 4; ++a) tr += C4[a * 4 + a];
     double p[12];
-    for (int j = 0; j < 12; ++j) p[j] = V[j * 12 + best];
+    if (!smallest_eigvec<4>(C4, tr, p + 8)) return false;
+    for (int a = 0; a < 4; ++a) {
+        double u = 0.0, v = 0.0;
+        for (int k = 0; k < 4; ++k) { u += SiSx[a * 4 + k] * p[8 + k]; v += SiSy[a * 4 + k] * p[8 + k]; }
+        p[a] = u; p[4 + a] = v;
+    }
     double M[9] = {p[0], p[1], p[2], p[4], p[5], p[6], p[8], p[9], p[10]};
     double t[3] = {p[3], p[7], p[11]};
     double d = det3(M);
@@ -305,96 +448,181 @@ void refine_lm(const Problem& P, const unsigned char* mask, double* pose, int it
 
 }  // namespace
 
+// ---- RANSAC in chunks of CH trials ------------------------------------------------------------------------------------
+// Trial t belongs to chunk t / CH and every chunk has its own generator, so the floor of min_iters trials (the reference's
+// pycolmap call: 10 000) splits into independent chunks that a pool solves in parallel; merging the chunks' best candidates
+// in chunk order makes the result independent of how many threads took part (and identical to the sequential call).
+namespace {
+
+constexpr int CH = 2048;
+
+struct Candidate {
+    double pose[12];
+    int cnt = 0;
+    double cost = 1e300;
+    std::vector<unsigned char> mask;
+    bool better_than(const Candidate& o) const { return cnt > o.cnt || (cnt == o.cnt && cost < o.cost); }
+};
+
+struct Ransac {
+    Problem P;
+    FastPoints F;
+    double K[9];
+    double thr2 = 0, confidence = 0.99;
+    int n = 0, min_iters = 0, max_iters = 0;
+    unsigned long long seed = 1;
+
+    void setup(const double* K_, const float* pts2d, const float* pts3d, int n_, double reproj, double conf, int min_it, int max_it,
+               unsigned long long seed_) {
+        n = n_; std::memcpy(K, K_, sizeof(K));
+        P.n = n; P.K = K;
+        P.ray.resize(2 * (size_t)n); P.px.resize(2 * (size_t)n); P.X.resize(3 * (size_t)n);
+        double Ki[9];
+        inv3(K, Ki);
+        F.n = n; F.x.resize(n); F.y.resize(n); F.z.resize(n); F.u.resize(n); F.v.resize(n);
+        for (int i = 0; i < n; ++i) {
+            const double u = pts2d[2 * i], v = pts2d[2 * i + 1];
+            P.px[2 * i] = u; P.px[2 * i + 1] = v;
+            const double w = Ki[6] * u + Ki[7] * v + Ki[8];
+            P.ray[2 * i] = (Ki[0] * u + Ki[1] * v + Ki[2]) / w;
+            P.ray[2 * i + 1] = (Ki[3] * u + Ki[4] * v + Ki[5]) / w;
+            for (int d = 0; d < 3; ++d) P.X[3 * i + d] = pts3d[3 * i + d];
+            F.x[i] = pts3d[3 * i]; F.y[i] = pts3d[3 * i + 1]; F.z[i] = pts3d[3 * i + 2];
+            F.u[i] = pts2d[2 * i]; F.v[i] = pts2d[2 * i + 1];
+        }
+        thr2 = reproj * reproj; confidence = conf; min_iters = min_it; max_iters = max_it; seed = seed_;
+    }
+    int full_chunks() const { return (min_iters < max_iters ? min_iters : max_iters) / CH; }
+
+    int needed_for(int cnt) const {
+        const double w = (double)cnt / n, pw = std::pow(w, 6.0);
+        if (pw > 1.0 - 1e-12) return 1;
+        if (pw > 1e-12) return (int)std::ceil(std::log(1.0 - confidence) / std::log(1.0 - pw));
+        return max_iters;
+    }
+
+    // trials [0, limit) of `chunk`; `floor_in_chunk` of them unconditionally, after that while the global trial index is
+    // below what the best candidate so far (`best`: carried in, updated) asks for.  Returns the number of trials run.
+    int run_chunk(int chunk, int limit, int floor_in_chunk, Candidate& best) const {
+        Rng rng(seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(chunk + 1));
+        std::vector<unsigned char> mask((size_t)n);
+        int best_cnt_f = 0;
+        float best_cost_f = 3.0e38f;
+        int needed = best.cnt > 0 ? needed_for(best.cnt) : max_iters;
+        int it = 0;
+        for (; it < limit && (it < floor_in_chunk || (long long)chunk * CH + it < needed); ++it) {
+            int idx[6];
+            for (int k = 0; k < 6;) {
+                const int c = rng.below(n);
+                bool dup = false;
+                for (int j = 0; j < k; ++j) dup |= idx[j] == c;
+                if (!dup) idx[k++] = c;
+            }
+            double pose[12];
+            if (!dlt_pose(P, idx, 6, pose)) continue;
+            float kp[12];
+            for (int c = 0; c < 4; ++c) {
+                kp[c] = (float)(K[0] * pose[c] + K[1] * pose[4 + c] + K[2] * pose[8 + c]);
+                kp[4 + c] = (float)(K[4] * pose[4 + c] + K[5] * pose[8 + c]);
+                kp[8 + c] = (float)pose[8 + c];
+            }
+            float cost_f;
+            int cnt_f;
+            if (!score_fast(F, kp, (float)thr2, best_cnt_f, best_cost_f, &cnt_f, &cost_f)) continue;
+            if (cnt_f < best_cnt_f || (cnt_f == best_cnt_f && !(cost_f < best_cost_f))) continue;
+            best_cnt_f = cnt_f; best_cost_f = cost_f;
+            // a new best of this chunk by the float score: its exact (double) count, cost and mask decide what is kept
+            Candidate c;
+            c.cnt = count_inliers(P, pose, thr2, mask.data(), &c.cost);
+            if (c.better_than(best)) {
+                std::memcpy(c.pose, pose, sizeof(pose));
+                c.mask = mask;
+                best = std::move(c);
+                needed = needed_for(best.cnt);
+            }
+        }
+        return it;
+    }
+
+    // chunks after the unconditional ones, one at a time, until the confidence criterion or max_iters stops them
+    void run_tail(Candidate& best, int* iters_run) const {
+        int c = full_chunks();
+        long long total = (long long)c * CH;
+        const int rem = (min_iters < max_iters ? min_iters : max_iters) - c * CH;
+        while (total < max_iters) {
+            const int limit = (int)((max_iters - total) < CH ? (max_iters - total) : CH);
+            const int ran = run_chunk(c, limit, c == full_chunks() ? rem : 0, best);
+            total += ran;
+            if (ran < limit) break;
+            ++c;
+        }
+        if (iters_run) *iters_run = (int)total;
+    }
+
+    // local optimisation of the winner: LM on the inliers, re-evaluate the inlier set, LM again
+    int finish(Candidate& best, double* pose_out, unsigned char* inlier_mask, int* n_inliers) {
+        if (best.cnt < 6) return 1;
+        std::vector<unsigned char> mask;
+        for (int round = 0; round < 2; ++round) {
+            refine_lm(P, best.mask.data(), best.pose, 20);
+            mask = best.mask;
+            best.cnt = count_inliers(P, best.pose, thr2, best.mask.data(), nullptr);
+            if (best.cnt < 6 || mask == best.mask) break;     // same inlier set: the pose is already its optimum
+        }
+        std::memcpy(pose_out, best.pose, sizeof(best.pose));
+        if (inlier_mask) std::memcpy(inlier_mask, best.mask.data(), (size_t)n);
+        if (n_inliers) *n_inliers = best.cnt;
+        return best.cnt >= 6 ? 0 : 1;
+    }
+};
+
+const double kIdentPose[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+
+}  // namespace
+
 extern "C" int oppnp_abi_version(void) { return 1; }
 
 extern "C" int oppnp_ransac(const double* K, const float* pts2d, const float* pts3d, int n, double reproj_err_px, double confidence,
                             int min_iters, int max_iters, unsigned long long seed, double* pose_out, unsigned char* inlier_mask,
                             int* n_inliers, int* iters_run) {
-    if (!K || !pose_out || (n > 0 && (!pts2d || !pts3d))) return -1;
-    static const double ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-    std::memcpy(pose_out, ident, sizeof(ident));
+    if (!K || !pose_out || (n > 0 && (!pts2d || !pts3d)) || max_iters < 1 || min_iters < 0) return -1;
+    std::memcpy(pose_out, kIdentPose, sizeof(kIdentPose));
     if (inlier_mask && n > 0) std::memset(inlier_mask, 0, (size_t)n);
     if (n_inliers) *n_inliers = 0;
     if (iters_run) *iters_run = 0;
     if (n < 6) return 1;                                  // too few correspondences: identity pose, no inliers
-    Problem P;
-    P.n = n; P.K = K;
-    P.ray.resize(2 * (size_t)n); P.px.resize(2 * (size_t)n); P.X.resize(3 * (size_t)n);
-    double Ki[9];
-    inv3(K, Ki);
-    for (int i = 0; i < n; ++i) {
-        const double u = pts2d[2 * i], v = pts2d[2 * i + 1];
-        P.px[2 * i] = u; P.px[2 * i + 1] = v;
-        const double w = Ki[6] * u + Ki[7] * v + Ki[8];
-        P.ray[2 * i] = (Ki[0] * u + Ki[1] * v + Ki[2]) / w;
-        P.ray[2 * i + 1] = (Ki[3] * u + Ki[4] * v + Ki[5]) / w;
-        for (int d = 0; d < 3; ++d) P.X[3 * i + d] = pts3d[3 * i + d];
+    Ransac R;
+    R.setup(K, pts2d, pts3d, n, reproj_err_px, confidence, min_iters, max_iters, seed);
+    Candidate best;
+    for (int c = 0; c < R.full_chunks(); ++c) {
+        Candidate local;
+        R.run_chunk(c, CH, CH, local);
+        if (local.better_than(best)) best = std::move(local);
     }
-    const double thr2 = reproj_err_px * reproj_err_px;
-    Rng rng(seed);
-    std::vector<unsigned char> mask((size_t)n), best_mask((size_t)n, 0);
-    double best_pose[12];
-    std::memcpy(best_pose, ident, sizeof(ident));
-    int best_cnt = 0;
-    double best_cost = 1e300;
-    int needed = max_iters, it = 0;
-    for (; it < max_iters && (it < min_iters || it < needed); ++it) {
-        int idx[6];
-        for (int k = 0; k < 6;) {
-            const int c = rng.below(n);
-            bool dup = false;
-            for (int j = 0; j < k; ++j) dup |= idx[j] == c;
-            if (!dup) idx[k++] = c;
-        }
-        double pose[12];
-        if (!dlt_pose(P, idx, 6, pose)) continue;
-        double cost;
-        const int cnt = count_inliers(P, pose, thr2, mask.data(), &cost);
-        if (cnt > best_cnt || (cnt == best_cnt && cost < best_cost)) {
-            best_cnt = cnt; best_cost = cost;
-            std::memcpy(best_pose, pose, sizeof(pose));
-            best_mask = mask;
-            const double w = (double)cnt / n;
-            const double pw = std::pow(w, 6.0);
-            if (pw > 1.0 - 1e-12) needed = 1;
-            else if (pw > 1e-12) needed = (int)std::ceil(std::log(1.0 - confidence) / std::log(1.0 - pw));
-        }
-    }
-    if (iters_run) *iters_run = it;
-    if (best_cnt < 6) return 1;
-    // local optimisation: LM on the inliers, re-evaluate the inlier set, LM again
-    for (int round = 0; round < 2; ++round) {
-        refine_lm(P, best_mask.data(), best_pose, 20);
-        mask = best_mask;
-        best_cnt = count_inliers(P, best_pose, thr2, best_mask.data(), nullptr);
-        if (best_cnt < 6 || mask == best_mask) break;     // same inlier set: the pose is already its optimum
-    }
-    std::memcpy(pose_out, best_pose, sizeof(best_pose));
-    if (inlier_mask) std::memcpy(inlier_mask, best_mask.data(), (size_t)n);
-    if (n_inliers) *n_inliers = best_cnt;
-    return best_cnt >= 6 ? 0 : 1;
+    R.run_tail(best, iters_run);
+    return R.finish(best, pose_out, inlier_mask, n_inliers);
 }
 
-// ---- asynchronous pool: poses are solved on library-owned host threads (no Python / GIL on the per-frame path) --------
+// ---- asynchronous pool: poses are solved on library-owned host threads (no Python / GIL on the per-frame path); the
+//      unconditional chunks of a frame are separate tasks, so one frame's 10 000-trial floor spreads over every thread ------
 namespace {
 
-struct Job {
-    double K[9];
-    std::vector<float> p2, p3;
-    double thr, conf;
-    int min_it, max_it;
-    unsigned long long seed;
-    long long ticket;
-};
 struct Result {
     double pose[12];
     int n_inliers, rc;
 };
 
+struct Job {
+    Ransac R;
+    long long ticket = 0;
+    std::vector<Candidate> chunk_best;      // one per unconditional chunk
+    int remaining = 0;                       // unconditional chunks not finished yet (guarded by Pool::mu)
+};
+
 struct Pool {
     std::vector<std::thread> workers;
-    std::deque<Job> queue;
-    std::vector<Result> results;          // indexed by ticket
+    std::deque<std::pair<std::shared_ptr<Job>, int>> queue;      // (job, chunk); chunk -1: the whole tail (no full chunks)
+    std::unordered_map<long long, Result> results;     // by ticket; erased when read
     std::mutex mu;
     std::condition_variable cv_work, cv_done;
     long long submitted = 0, finished = 0;
@@ -408,26 +636,41 @@ struct Pool {
         cv_work.notify_all();
         for (auto& t : workers) t.join();
     }
+    void finish_job(Job& job) {              // merge in chunk order, sequential tail, refinement
+        Candidate best;
+        for (auto& c : job.chunk_best)
+            if (c.better_than(best)) best = std::move(c);
+        job.R.run_tail(best, nullptr);
+        Result r;
+        std::memcpy(r.pose, kIdentPose, sizeof(kIdentPose));
+        r.n_inliers = 0;
+        r.rc = job.R.finish(best, r.pose, nullptr, &r.n_inliers);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            results[job.ticket] = r;
+            ++finished;
+        }
+        cv_done.notify_all();
+    }
     void run() {
         for (;;) {
-            Job job;
+            std::pair<std::shared_ptr<Job>, int> task;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv_work.wait(lk, [this] { return stop || !queue.empty(); });
                 if (stop && queue.empty()) return;
-                job = std::move(queue.front());
+                task = std::move(queue.front());
                 queue.pop_front();
             }
-            Result r;
-            const int n = (int)(job.p2.size() / 2);
-            r.rc = oppnp_ransac(job.K, job.p2.data(), job.p3.data(), n, job.thr, job.conf, job.min_it, job.max_it, job.seed, r.pose,
-                                nullptr, &r.n_inliers, nullptr);
+            Job& job = *task.first;
+            if (task.second < 0) { finish_job(job); continue; }
+            job.R.run_chunk(task.second, CH, CH, job.chunk_best[(size_t)task.second]);
+            bool last;
             {
                 std::lock_guard<std::mutex> lk(mu);
-                results[(size_t)job.ticket] = r;
-                ++finished;
+                last = --job.remaining == 0;
             }
-            cv_done.notify_all();
+            if (last) finish_job(job);
         }
     }
 };
@@ -442,20 +685,31 @@ extern "C" void oppnp_pool_destroy(void* pool) { delete reinterpret_cast<Pool*>(
 extern "C" long long oppnp_pool_submit(void* pool_, const double* K, const float* pts2d, const float* pts3d, int n, double reproj_err_px,
                                        double confidence, int min_iters, int max_iters, unsigned long long seed) {
     Pool* pool = reinterpret_cast<Pool*>(pool_);
-    if (!pool || !K || n < 0 || (n > 0 && (!pts2d || !pts3d))) return -1;
-    Job job;
-    std::memcpy(job.K, K, sizeof(job.K));
-    job.p2.assign(pts2d, pts2d + 2 * (size_t)n);
-    job.p3.assign(pts3d, pts3d + 3 * (size_t)n);
-    job.thr = reproj_err_px; job.conf = confidence; job.min_it = min_iters; job.max_it = max_iters; job.seed = seed;
+    if (!pool || !K || n < 0 || (n > 0 && (!pts2d || !pts3d)) || max_iters < 1 || min_iters < 0) return -1;
+    long long ticket;
+    if (n < 6) {                                          // no pose: identity, recorded at once
+        Result r;
+        std::memcpy(r.pose, kIdentPose, sizeof(kIdentPose));
+        r.n_inliers = 0; r.rc = 1;
+        std::lock_guard<std::mutex> lk(pool->mu);
+        ticket = pool->submitted++;
+        pool->results[ticket] = r;
+        ++pool->finished;
+        return ticket;
+    }
+    auto job = std::make_shared<Job>();
+    job->R.setup(K, pts2d, pts3d, n, reproj_err_px, confidence, min_iters, max_iters, seed);
+    const int nfull = job->R.full_chunks();
+    job->chunk_best.resize((size_t)nfull);
+    job->remaining = nfull;
     {
         std::lock_guard<std::mutex> lk(pool->mu);
-        job.ticket = pool->submitted++;
-        pool->results.resize((size_t)pool->submitted);
-        pool->queue.push_back(std::move(job));
+        ticket = job->ticket = pool->submitted++;
+        if (nfull == 0) pool->queue.emplace_back(job, -1);
+        for (int c = 0; c < nfull; ++c) pool->queue.emplace_back(job, c);
     }
-    pool->cv_work.notify_one();
-    return pool->submitted - 1;
+    pool->cv_work.notify_all();
+    return ticket;
 }
 
 // blocks until every submitted job is finished; returns their number
@@ -469,8 +723,10 @@ extern "C" long long oppnp_pool_wait_all(void* pool_) {
 extern "C" int oppnp_pool_result(void* pool_, long long ticket, double* pose_out, int* n_inliers) {
     Pool* pool = reinterpret_cast<Pool*>(pool_);
     std::lock_guard<std::mutex> lk(pool->mu);
-    if (ticket < 0 || ticket >= (long long)pool->results.size()) return -1;
-    const Result& r = pool->results[(size_t)ticket];
+    auto itr = pool->results.find(ticket);
+    if (itr == pool->results.end()) return -1;          // unknown, unfinished or already read
+    const Result r = itr->second;
+    pool->results.erase(itr);                            // a long frame loop does not accumulate results
     if (pose_out) std::memcpy(pose_out, r.pose, sizeof(r.pose));
     if (n_inliers) *n_inliers = r.n_inliers;
     return r.rc;

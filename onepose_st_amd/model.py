@@ -124,6 +124,10 @@ class OnePosePlus_model(nn.Module):
         self.overlap_fine = bool(config.get("hip_overlap_fine", True))
         self._fine_streams = {}      # (device, compute stream) -> (fine stream, last fine-done event)
         self._pe_cache = {}          # (h, w, device) -> [M, C] device table
+        # per-object cache of the frame-invariant keypoint encoding (rows a2 + a3); off by default so that a forward always does
+        # all of its work unless the caller opts in (bench.py reports both)
+        self.cache_object = bool(config.get("hip_cache_object", False))
+        self._obj_cache = None
 
         pretrained = config["loftr_backbone"]["pretrained"]
         if pretrained is not None:
@@ -282,19 +286,34 @@ class OnePosePlus_model(nn.Module):
                 ff_cl = torch.empty(B, hf * wf, ff.shape[1], **f32)
                 lib_call("ophip_transpose_cl", P(ff), P(ff_cl), B, ff.shape[1], hf * wf, S)
                 ff, ff_strides = ff_cl, (hf * wf * ff_cl.shape[2], 1, wf * ff_cl.shape[2], ff_cl.shape[2])
-        # ---- a2 + a3: keypoint encoding ---------------------------------------------------------
-        x3d = torch.empty(B, N, C, **f32)
-        if self.kpt_3d_pos_encoding is not None:
-            stats = torch.empty(4 * B + 4, **f32)
-            lib_call("ophip_kpt_encode", P(kpts_d), bstride(kpts_d), P(desc_in_d), bstride(desc_in_d), P(W["kpt"]),
-                     P(stats), P(x3d), B, N, S)
-        else:
-            src = desc_in_d if desc_in_d.shape[0] == B else desc_in_d.expand(B, -1, -1).contiguous()
-            lib_call("ophip_transpose_cl", P(src), P(x3d), B, C, N, S)
+        # ---- a2 + a3: keypoint encoding (frame-invariant: depends on the object block only) -------------------
+        x3d = None
+        ckey = None
+        if self.cache_object:
+            # the reference keeps the object block resident across frames (OnePosePlus_inference_dataset.py:157-169); its encoding
+            # is recomputed only when the tensors (or the weights) change
+            ckey = (str(dev), B, N, kpts_d.data_ptr(), kpts_d._version, desc_in_d.data_ptr(), desc_in_d._version, id(W))
+            if self._obj_cache is not None and self._obj_cache[0] == ckey:
+                x3d = self._obj_cache[1]
+                torch.cuda.current_stream(dev).wait_event(self._obj_cache[2])
+        if x3d is None:
+            x3d = torch.empty(B, N, C, **f32)
+            if self.kpt_3d_pos_encoding is not None:
+                stats = torch.empty(4 * B + 4, **f32)
+                lib_call("ophip_kpt_encode", P(kpts_d), bstride(kpts_d), P(desc_in_d), bstride(desc_in_d), P(W["kpt"]),
+                         P(stats), P(x3d), B, N, S)
+            else:
+                src = desc_in_d if desc_in_d.shape[0] == B else desc_in_d.expand(B, -1, -1).contiguous()
+                lib_call("ophip_transpose_cl", P(src), P(x3d), B, C, N, S)
+            if self.cache_object:
+                ev = torch.cuda.Event()
+                ev.record()
+                self._obj_cache = (ckey, x3d, ev, kpts_d, desc_in_d)          # the key's tensors stay alive with the entry
         # ---- a4-a6: coarse encoder ----------------------------------------------------------------
         main = torch.cuda.current_stream(dev)
         fkey = (str(dev), main.cuda_stream)
         y3d, y2d = torch.empty_like(x3d), torch.empty_like(x2d)
+        z3d = torch.empty_like(x3d) if self.cache_object else x3d          # a cached encoding is read-only: ping-pong between y and z
 
         def wait_previous_fine():                                 # the previous frame's fine stage is done
             if self.overlap_fine and fkey in self._fine_streams and self._fine_streams[fkey][1] is not None:
@@ -305,7 +324,7 @@ class OnePosePlus_model(nn.Module):
             for li, name in enumerate(self.loftr_coarse.layer_names):
                 lib_call("ophip_encoder_layer", P(x3d), P(x2d), P(y3d), P(y2d), B, N, M, P(W["coarse"][li]),
                          1 if name == "cross" else 0, P(ws), S)
-                x3d, y3d, x2d, y2d = y3d, x3d, y2d, x2d
+                x3d, y3d, x2d, y2d = y3d, (z3d if li == 0 else x3d), y2d, x2d
         elif self.precision == "bf16x3" and not os.environ.get("OPHIP_ENC_V1"):
             # 16-token tiles, one workgroup per CU, per-wave weight streams (csrc/encoder_x3.hip)
             ws = torch.empty(hip.load().ophip_encoder_x3_workspace_bytes(B, N, M), device=dev, dtype=torch.uint8)
@@ -316,7 +335,7 @@ class OnePosePlus_model(nn.Module):
                     wait_previous_fine()
                 lib_call("ophip_encoder_layer_x3", P(x3d), P(x2d), P(y3d), P(y2d), B, N, M, P(W["coarse_x3"][li], None), P(nxt, None),
                          1 if name == "cross" else 0, 1 if li > 0 else 0, li & 1, P(ws, None), S)
-                x3d, y3d, x2d, y2d = y3d, x3d, y2d, x2d
+                x3d, y3d, x2d, y2d = y3d, (z3d if li == 0 else x3d), y2d, x2d
         else:
             nsplit = 3 if self.precision == "bf16x3" else 1
             ws = torch.empty(hip.load().ophip_encoder_bf16_workspace_bytes(B, N, M), device=dev, dtype=torch.uint8)
@@ -328,7 +347,7 @@ class OnePosePlus_model(nn.Module):
                     wait_previous_fine()                          # attn_apply, the roofline kernel, never shares the chip with fine
                 lib_call("ophip_encoder_layer_bf16", P(x3d), P(x2d), P(y3d), P(y2d), B, N, M, P(W["coarse_bf16"][li], None), P(nxt, None),
                          nsplit, 1 if name == "cross" else 0, 1 if li > 0 else 0, li & 1, P(ws, None), S)
-                x3d, y3d, x2d, y2d = y3d, x3d, y2d, x2d
+                x3d, y3d, x2d, y2d = y3d, (z3d if li == 0 else x3d), y2d, x2d
         if self.debug:
             data["_feat3d_c"], data["_feat2d_c"] = x3d, x2d
         # ---- a7 + a8: coarse matching -----------------------------------------------------------
@@ -356,6 +375,8 @@ class OnePosePlus_model(nn.Module):
         fine_ctx = contextlib.nullcontext()
         if fine_on and self.overlap_fine:
             if fkey not in self._fine_streams:
+                if len(self._fine_streams) >= 16:
+                    self._fine_streams.pop(next(iter(self._fine_streams)))
                 self._fine_streams[fkey] = [torch.cuda.Stream(device=dev), None]
             sfine = self._fine_streams[fkey][0]
             coarse_done = torch.cuda.Event()
@@ -377,7 +398,7 @@ class OnePosePlus_model(nn.Module):
                 keep.append(ff)
                 stride = hf // hc
                 fine_scale = (cf["window_size"] // 2) * (data["q_hw_i"][0] / hf)
-                max_matches = min(cap, B * min(N, M) + 64)      # mutual matches are one per row and (barring exact ties) per column
+                max_matches = cap                                # one match per 3D point at most: the grid covers every possible K (surplus workgroups exit)
                 if self.precision == "f32":
                     lib_call("ophip_fine_refine", P(ff), *ff_strides, hf, wf,
                              P(desc_fine_d), bstride(desc_fine_d), desc_fine_d.stride(1),
@@ -436,6 +457,8 @@ class PendingFrame:
         main = torch.cuda.current_stream(dev)
         side = PendingFrame._copy_streams.get((dev, main.cuda_stream))
         if side is None:
+            if len(PendingFrame._copy_streams) >= 16:          # keyed on raw stream handles: drop the oldest instead of growing for ever
+                PendingFrame._copy_streams.pop(next(iter(PendingFrame._copy_streams)))
             side = PendingFrame._copy_streams[(dev, main.cuda_stream)] = torch.cuda.Stream(device=dev)
         ready = torch.cuda.Event()
         ready.record(main)
@@ -446,6 +469,31 @@ class PendingFrame:
             self.event.record(side)
         self.done = False
 
+    def _release_pin(self):
+        if self._pin is not None:
+            pool = PendingFrame._pinned_pool.setdefault(self._key, [])
+            if len(pool) < 8:                       # a few frames in flight at most: do not hoard pinned memory
+                pool.append(self._pin)
+            self._pin = None
+
+    def close(self):
+        """Abandon the frame: wait until the side streams (fine stage, read-back) are done with its buffers, then release them.
+        Called by ``__del__``, so a frame dropped without ``finish()`` (an exception in the pipeline) cannot hand device blocks
+        that are still being read or written back to the caching allocator."""
+        if self.done or self._pin is None:
+            return
+        try:
+            self.event.synchronize()
+        finally:
+            self._release_pin()
+            self.done = True
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def finish(self):
         """Wait for this frame (event), read K, fill ``data`` exactly like the reference's ``forward``."""
         if self.done:
@@ -453,13 +501,10 @@ class PendingFrame:
         self.event.synchronize()                    # the one host wait of the frame
         K = int(self._pin[:4].view(torch.int32)[0])
         B, N, M, cap = self.B, self.N, self.M, self.cap
-        if self.fine_on and K > min(cap, B * min(N, M) + 64):
-            raise RuntimeError("more coarse matches than the fine grid covers (exact confidence ties); "
-                               "re-run with a larger grid is not implemented")
         if self._host_copy:
             _, _, hb, h3, h2 = _result_views(self._pin, cap)
             self.host = {"K": K, "mkpts_3d_db": h3[:K].numpy().copy(), "mkpts_2d": h2[:K].numpy().copy(), "b_ids": hb[:K].numpy().copy()}
-        PendingFrame._pinned_pool[self._key].append(self._pin)
+        self._release_pin()
         bf = self.bufs
         data, dev = self.data, self.dev
         b_ids, i_ids, j_ids = bf["b_ids"][:K], bf["i_ids"][:K], bf["j_ids"][:K]

@@ -38,12 +38,29 @@ def load():
     return _lib
 
 
+# trial policy of the two branches of the reference's ``ransac_PnP`` (``metric_utils.py:155-165`` / ``:188-196``)
+POLICY = {
+    "reference": dict(min_iters=10000, max_iters=1000000),     # pycolmap: min_num_trials 10 000, max_num_trials 1 000 000, confidence 0.99
+    "adaptive": dict(min_iters=4, max_iters=10000),            # cv2.solvePnPRansac: iterationsCount 10 000, stops at the confidence
+}
+
+
+def trial_policy(use_pycolmap_ransac: bool, min_iters=None, max_iters=None) -> tuple:
+    pol = POLICY["reference" if use_pycolmap_ransac else "adaptive"]
+    return (pol["min_iters"] if min_iters is None else int(min_iters), pol["max_iters"] if max_iters is None else int(max_iters))
+
+
 def ransac_PnP(K, pts_2d, pts_3d, scale=1, pnp_reprojection_error=5, img_hw=None, use_pycolmap_ransac=False,
-               confidence=0.99, min_iters=4, max_iters=10000, seed=1):
+               confidence=0.99, min_iters=None, max_iters=None, seed=1):
     """-> ``(pose [3,4], pose_homo [4,4], inliers [k] int64)`` like the reference.  ``scale`` multiplies the 3D points
-    for the solve and divides the translation afterwards (the reference's OpenCV branch, ``metric_utils.py:186,200``);
-    ``img_hw`` / ``use_pycolmap_ransac`` are accepted for signature compatibility and ignored."""
+    for the solve and divides the translation afterwards (the reference's OpenCV branch, ``metric_utils.py:186,200``).
+    ``use_pycolmap_ransac`` selects the trial policy of the reference's branch: ``True`` (what ``inference.py:181-189``
+    passes) runs at least 10 000 trials like ``pycolmap.absolute_pose_estimation(min_num_trials=10000, max_num_trials=1e6)``,
+    ``False`` stops adaptively at the confidence within 10 000 trials like ``cv2.solvePnPRansac``; ``min_iters`` /
+    ``max_iters`` override either.  The estimator itself is the build's own (pose parity vs pycolmap / OpenCV is unpinned);
+    ``img_hw`` is accepted for signature compatibility."""
     lib = load()
+    min_iters, max_iters = trial_policy(bool(use_pycolmap_ransac), min_iters, max_iters)
     K = np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(3, 3))
     p2 = np.ascontiguousarray(np.asarray(pts_2d, dtype=np.float32).reshape(-1, 2))
     p3 = np.ascontiguousarray(np.asarray(pts_3d, dtype=np.float32).reshape(-1, 3) * np.float32(scale))
@@ -67,8 +84,11 @@ def ransac_PnP(K, pts_2d, pts_3d, scale=1, pnp_reprojection_error=5, img_hw=None
 class PnPPool:
     """Library-owned worker threads: ``submit`` copies the matches and returns a ticket immediately."""
 
-    def __init__(self, K, threads=3, pnp_reprojection_error=7, confidence=0.99, min_iters=4, max_iters=10000, seed=1):
+    def __init__(self, K, threads=3, pnp_reprojection_error=7, confidence=0.99, min_iters=None, max_iters=None, seed=1, policy="reference"):
+        """``policy``: "reference" = the pycolmap branch's trial floor (what the reference's inference loop runs), "adaptive" = the
+        OpenCV branch; a frame's unconditional trials are split over all pool threads (same pose for any thread count)."""
         self._lib = load()
+        min_iters, max_iters = trial_policy(policy == "reference", min_iters, max_iters)
         self._K = np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(3, 3))
         self._args = (float(pnp_reprojection_error), float(confidence), int(min_iters), int(max_iters), int(seed))
         self._pool = ctypes.c_void_p(self._lib.oppnp_pool_create(int(threads)))

@@ -589,3 +589,63 @@ def test_pipelined_frames_match_sequential_runs(model, sd, cfg, dev):
             assert torch.equal(d[k], alone[1][k]), k
     finally:
         model.overlap_fine = saved
+
+
+def test_dropped_pending_frame_does_not_disturb_the_next(model, sd, cfg, dev):
+    """A frame enqueued and then dropped without finish() (an exception in a pipeline): its side-stream work is waited for
+    before its buffers and pinned block are released, and the following frames are still bit-identical to stand-alone runs."""
+    frames = [make_synthetic_inputs(sd, n_points=900, image_hw=(128, 160), n_plant=300, seed=31, config=cfg, frame=f) for f in range(2)]
+    obj = {k: frames[0][k].to(dev) for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db")}
+    feats = [(f["feat_c"].to(dev), f["feat_f"].to(dev)) for f in frames]
+    keys = ("i_ids", "j_ids", "mconf", "mkpts_query_f", "expec_f")
+    ref = dict(obj)
+    model.enqueue_features(ref, *feats[1], frames[0]["image_hw"]).finish()
+    ref = {k: ref[k].clone() for k in keys}
+    for rep in range(3):
+        dropped = model.enqueue_features(dict(obj), *feats[0], frames[0]["image_hw"], host_copy=True)
+        d = dict(obj)
+        nxt = model.enqueue_features(d, *feats[1], frames[0]["image_hw"], host_copy=True)
+        del dropped                                           # never finished
+        nxt.finish()
+        for k in keys:
+            assert torch.equal(d[k], ref[k]), (rep, k)
+    p = model.enqueue_features(dict(obj), *feats[0], frames[0]["image_hw"])
+    p.close()
+    p.close()                                                 # idempotent
+    assert p.done
+
+
+def test_object_cache_is_bit_identical(sd, cfg, dev):
+    """config["hip_cache_object"]: the keypoint encoding (rows a2 + a3) of a resident object block is computed once and re-used
+    by the following frames -- same results bit for bit as the uncached model; a changed block (or an in-place edit) re-encodes."""
+    import copy
+    frames = [make_synthetic_inputs(sd, n_points=1100, image_hw=(128, 192), n_plant=400, seed=41, config=cfg, frame=f) for f in range(3)]
+    obj = {k: frames[0][k].to(dev) for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db")}
+    keys = ("i_ids", "j_ids", "mconf", "mkpts_query_f", "expec_f", "conf_matrix")
+    plain = OnePosePlus_model(copy.deepcopy(cfg)).eval()
+    plain.load_state_dict(sd, strict=True)
+    plain.to(dev)
+    ccfg = copy.deepcopy(cfg)
+    ccfg["hip_cache_object"] = True
+    cached = OnePosePlus_model(ccfg).eval()
+    cached.load_state_dict(sd, strict=True)
+    cached.to(dev)
+    for f in frames:
+        a, b = dict(obj), dict(obj)
+        plain.forward_features(a, f["feat_c"].to(dev), f["feat_f"].to(dev), f["image_hw"])
+        cached.forward_features(b, f["feat_c"].to(dev), f["feat_f"].to(dev), f["image_hw"])
+        assert len(a["i_ids"]) > 200
+        for k in keys:
+            assert torch.equal(a[k], b[k]), k
+    entry = cached._obj_cache
+    assert entry is not None
+    d = dict(obj)
+    cached.forward_features(d, frames[0]["feat_c"].to(dev), frames[0]["feat_f"].to(dev), frames[0]["image_hw"])
+    assert cached._obj_cache is entry                           # same block: the cached encoding was used
+    obj["keypoints3d"].mul_(1.5)                               # in-place edit bumps the version: re-encode
+    a, b = dict(obj), dict(obj)
+    plain.forward_features(a, frames[1]["feat_c"].to(dev), frames[1]["feat_f"].to(dev), frames[1]["image_hw"])
+    cached.forward_features(b, frames[1]["feat_c"].to(dev), frames[1]["feat_f"].to(dev), frames[1]["image_hw"])
+    assert cached._obj_cache is not entry
+    for k in keys:
+        assert torch.equal(a[k], b[k]), k

@@ -65,13 +65,29 @@ def test_pose_is_insensitive_at_matcher_noise_level():
 
 
 def test_async_pool_matches_sync_calls():
+    """both trial policies of the reference's ransac_PnP; the pool splits a frame's unconditional trials over its threads and
+    must return the sequential call's pose bit for bit, for any thread count; a ticket is read once"""
     scenes = [_scene(400 + 50 * i, 10 + i, noise_px=0.3, outlier_frac=0.1) for i in range(6)]
     K = scenes[0][0]
-    pool = PnPPool(K, threads=3, pnp_reprojection_error=7)
-    tickets = [pool.submit(s[1], s[2]) for s in scenes]
-    assert tickets == list(range(6)) and pool.wait_all() == 6
-    for tk, s in zip(tickets, scenes):
-        pose, n_in, rc = pool.result(tk)
-        ref, _, inl = ransac_PnP(K, s[1], s[2], pnp_reprojection_error=7)
-        assert rc == 0 and np.array_equal(pose, ref) and n_in == len(inl)
-    pool.close()
+    for policy, pycolmap_branch, min_iters in (("adaptive", False, None), ("reference", True, 5000)):    # 5000 trials: two full 2048-trial chunks + a partial one
+        for threads in (1, 3):
+            pool = PnPPool(K, threads=threads, pnp_reprojection_error=7, policy=policy, min_iters=min_iters)
+            tickets = [pool.submit(s[1], s[2]) for s in scenes]
+            assert tickets == list(range(6)) and pool.wait_all() == 6
+            for tk, s in zip(tickets, scenes):
+                pose, n_in, rc = pool.result(tk)
+                ref, _, inl = ransac_PnP(K, s[1], s[2], pnp_reprojection_error=7, use_pycolmap_ransac=pycolmap_branch, min_iters=min_iters)
+                assert rc == 0 and np.array_equal(pose, ref) and n_in == len(inl)
+            assert pool.result(tickets[0])[2] == -1          # results are handed out once (a long frame loop does not accumulate them)
+            pool.close()
+
+
+def test_trial_policy_follows_the_reference_branches():
+    from onepose_st_amd.pnp import trial_policy
+    assert trial_policy(True) == (10000, 1000000)            # pycolmap branch: min_num_trials / max_num_trials (metric_utils.py:155-165)
+    assert trial_policy(False) == (4, 10000)                 # cv2 branch: iterationsCount 10 000, adaptive (metric_utils.py:188-196)
+    assert trial_policy(True, min_iters=64) == (64, 1000000)
+    K, uv, X, R, t, _ = _scene(600, 4, noise_px=0.5, outlier_frac=0.2)
+    pa, _, ia = ransac_PnP(K, uv, X, pnp_reprojection_error=7)
+    pr, _, ir = ransac_PnP(K, uv, X, pnp_reprojection_error=7, use_pycolmap_ransac=True, min_iters=2000)
+    assert np.abs(pa[:, :3] - pr[:, :3]).max() < 1e-4 and abs(len(ia) - len(ir)) <= 2      # more trials, the same pose to refinement accuracy
