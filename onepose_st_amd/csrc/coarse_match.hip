@@ -14,6 +14,7 @@
 //                 empty), mutual test, first-true-j semantics on exact ties, compaction in ascending (b, i)
 #include "tile_bf16.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -303,6 +304,334 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_stats_bf16
     }
     sim_epilogue<true>(acc, p, reinterpret_cast<float*>(smem), tid, i0, j0, b);
     OPHIP_STAMP(p.stamps, wg, 31);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Two-pass form of the bf16 modes: S is never stored.  split_planes turns the two encoder outputs into (hi, lo) bf16 planes
+// once (scaled by 1/sqrt(C) = 1/16, exact); pass 1 computes the S tiles and keeps only their row / column (max, sum exp)
+// partials; after stat_combine, pass 2 recomputes each tile on the matrix pipe, turns it into confidences in registers,
+// stores conf_matrix ONCE (whole rows through the LDS image) and leaves per-tile row-best / column-max partials that
+// best_combine merges in a fixed order (no atomics).  HBM traffic of the stage: the N x M f32 write plus the 2 x 12 MB of
+// planes, against write S + read S + write conf before.  Workgroups are dealt to the XCDs in row bands: the blocks that share
+// an XCD (blockIdx % 8) sweep all column tiles of a contiguous range of row tiles, so an XCD's L2 holds its A rows and
+// streams B once.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct SplitArgs {
+    const float* x;      // [rows][C]
+    char* hi;            // [rows][C] bf16
+    char* lo;
+    long long rows;
+};
+
+__global__ __launch_bounds__(256) void split_planes_kernel(SplitArgs p) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;        // one 8-feature chunk per thread
+    if (i >= p.rows * (C / 8)) return;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(p.x + i * 8);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(p.x + i * 8 + 4);
+    bf16x8 vh, vl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        __bf16 hh, ll;
+        split_bf16(v0[j] * 0.0625f, hh, ll); vh[j] = hh; vl[j] = ll;          // feat / sqrt(C): exact power of two
+        split_bf16(v1[j] * 0.0625f, hh, ll); vh[4 + j] = hh; vl[4 + j] = ll;
+    }
+    *reinterpret_cast<bf16x8*>(p.hi + i * 16) = vh;
+    *reinterpret_cast<bf16x8*>(p.lo + i * 16) = vl;
+}
+
+struct Sim2Args {
+    const char *a_hi, *a_lo;     // [B][N][C] bf16 planes
+    const char *b_hi, *b_lo;     // [B][M][C]
+    float* conf;                 // [B][N][M]                         (pass 2)
+    float* rowpart;              // [B][ntc][N][2] (max, sum exp)      (pass 1)
+    float* colpart;              // [B][ntr][M][2]
+    const float* rowstat;        // [B][N][2] merged                   (pass 2)
+    const float* colstat;        // [B][M][2]
+    float* rowbest;              // [B][ntc][N][3] (value, j bits, tie count bits)   (pass 2)
+    float* colmaxp;              // [B][ntr][M]                                      (pass 2)
+    int N, M, ntr, ntc, per_xcd; // per_xcd: blocks per XCD label (grid.x = 8 * per_xcd)
+    float temp;
+};
+
+// XCD-aware tile of this block: label x = blockIdx.x % 8 owns row tiles [r0, r1) (sizes differ by at most one) and walks
+// them column-major (consecutive blocks of an XCD share the B tile, the whole range shares the A rows); false: no tile
+__device__ __forceinline__ bool xcd_tile(const Sim2Args& p, int& ti, int& tj) {
+    const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int q = p.ntr / 8, rem = p.ntr % 8;
+    const int r0 = x * q + (x < rem ? x : rem), nr = q + (x < rem ? 1 : 0);
+    if (nr == 0 || k >= nr * p.ntc) return false;
+    tj = k / nr;
+    ti = r0 + k % nr;
+    return true;
+}
+
+// S tile (128 x 128, f32 accumulators) from the planes: K chunks of 64 staged through padded LDS rows (144 B: conflict-free
+// ds_read_b128), next chunk prefetched into registers under the MFMAs.  The accumulators hold a.b / 256 (planes are pre-scaled).
+template <int NS>
+__device__ __forceinline__ void sim_tile_from_planes(f32x16 (&acc)[2][2], const Sim2Args& p, char* smem, int i0, int j0, int b, int tid) {
+    constexpr int PL = NS == 3 ? 2 : 1;
+    constexpr int PB = TM * SPITCH;
+    char* AH = smem;
+    char* AL = smem + (PL - 1) * PB;
+    char* BH = smem + PL * PB;
+    char* BL = BH + (PL - 1) * PB;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
+    const size_t arow = (size_t)b * p.N, brow = (size_t)b * p.M;
+    bf16x8 ra[4][PL], rb[4][PL];
+    auto prefetch = [&](int kc) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + 256 * u, row = idx >> 3, c8 = idx & 7;
+            const bool va = i0 + row < p.N, vb = j0 + row < p.M;
+            const size_t oa = ((arow + i0 + row) * C + kc * SKC + 8 * c8) * 2, ob = ((brow + j0 + row) * C + kc * SKC + 8 * c8) * 2;
+            ra[u][0] = va ? *reinterpret_cast<const bf16x8*>(p.a_hi + oa) : zero_bf8();
+            rb[u][0] = vb ? *reinterpret_cast<const bf16x8*>(p.b_hi + ob) : zero_bf8();
+            if (NS == 3) {
+                ra[u][PL - 1] = va ? *reinterpret_cast<const bf16x8*>(p.a_lo + oa) : zero_bf8();
+                rb[u][PL - 1] = vb ? *reinterpret_cast<const bf16x8*>(p.b_lo + ob) : zero_bf8();
+            }
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + 256 * u, row = idx >> 3, c8 = idx & 7;
+            const int off = row * SPITCH + 16 * c8;
+            *reinterpret_cast<bf16x8*>(AH + off) = ra[u][0];
+            *reinterpret_cast<bf16x8*>(BH + off) = rb[u][0];
+            if (NS == 3) {
+                *reinterpret_cast<bf16x8*>(AL + off) = ra[u][PL - 1];
+                *reinterpret_cast<bf16x8*>(BL + off) = rb[u][PL - 1];
+            }
+        }
+    };
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = zero16();
+    prefetch(0);
+    stage();
+    __syncthreads();
+    constexpr int NKC = C / SKC;
+    for (int kc = 0; kc < NKC; ++kc) {
+        if (kc + 1 < NKC) prefetch(kc + 1);
+#pragma unroll
+        for (int kb = 0; kb < SKC / 16; ++kb) {
+            bf16x8 fah[2], fal[2], fbh[2], fbl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int oa = (64 * wr + 32 * t + r) * SPITCH + 16 * (2 * kb + h);
+                const int ob = (64 * wc + 32 * t + r) * SPITCH + 16 * (2 * kb + h);
+                fah[t] = *reinterpret_cast<const bf16x8*>(AH + oa);
+                fbh[t] = *reinterpret_cast<const bf16x8*>(BH + ob);
+                fal[t] = (NS == 3) ? *reinterpret_cast<const bf16x8*>(AL + oa) : zero_bf8();
+                fbl[t] = (NS == 3) ? *reinterpret_cast<const bf16x8*>(BL + ob) : zero_bf8();
+            }
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) acc[x][y] = mma_bf16<NS>(fah[x], fal[x], fbh[y], fbl[y], acc[x][y]);
+        }
+        __syncthreads();
+        if (kc + 1 < NKC) {
+            stage();
+            __syncthreads();
+        }
+    }
+}
+
+// pass 1: row / column (max, sum exp) partials of the tile; S is not stored
+template <int NS>
+__global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_pass1_kernel(Sim2Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int ti, tj;
+    if (!xcd_tile(p, ti, tj)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
+    const int i0 = ti * TM, j0 = tj * TN, b = blockIdx.y;
+    f32x16 acc[2][2];
+    sim_tile_from_planes<NS>(acc, p, smem, i0, j0, b, tid);
+    float* St = reinterpret_cast<float*>(smem);
+    const float inv_temp = 1.0f / p.temp;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                St[(64 * wr + 32 * x + acc_row(reg, h)) * SLD + 64 * wc + 32 * y + r] = acc[x][y][reg] * inv_temp;
+    __syncthreads();
+    const int idx = tid >> 1, par = tid & 1;
+    {
+        const int ncol = min(TN, p.M - j0);
+        float v[TN / 2];
+#pragma unroll
+        for (int q = 0; q < TN / 2; ++q) v[q] = (2 * q + par < ncol) ? St[idx * SLD + 2 * q + par] : -INFINITY;
+        float m = -INFINITY, e = 0.f;
+#pragma unroll
+        for (int q = 0; q < TN / 2; ++q) m = fmaxf(m, v[q]);
+        if (m != -INFINITY) {
+#pragma unroll
+            for (int q = 0; q < TN / 2; ++q) e += __expf(v[q] - m);
+        }
+        const float m2 = __shfl_xor(m, 1, 64), e2 = __shfl_xor(e, 1, 64);
+        float ma = par ? m2 : m, ea = par ? e2 : e, mb = par ? m : m2, eb = par ? e : e2;      // even lane's part first
+        merge_ms(ma, ea, mb, eb);
+        if (par == 0 && i0 + idx < p.N) {
+            float* o = p.rowpart + (((size_t)b * p.ntc + tj) * p.N + i0 + idx) * 2;
+            o[0] = ma; o[1] = ea;
+        }
+    }
+    {
+        const int nrow = min(TM, p.N - i0);
+        float v[TM / 2];
+#pragma unroll
+        for (int q = 0; q < TM / 2; ++q) v[q] = (2 * q + par < nrow) ? St[(2 * q + par) * SLD + idx] : -INFINITY;
+        float m = -INFINITY, e = 0.f;
+#pragma unroll
+        for (int q = 0; q < TM / 2; ++q) m = fmaxf(m, v[q]);
+        if (m != -INFINITY) {
+#pragma unroll
+            for (int q = 0; q < TM / 2; ++q) e += __expf(v[q] - m);
+        }
+        const float m2 = __shfl_xor(m, 1, 64), e2 = __shfl_xor(e, 1, 64);
+        float ma = par ? m2 : m, ea = par ? e2 : e, mb = par ? m : m2, eb = par ? e : e2;
+        merge_ms(ma, ea, mb, eb);
+        if (par == 0 && j0 + idx < p.M) {
+            float* o = p.colpart + (((size_t)b * p.ntr + ti) * p.M + j0 + idx) * 2;
+            o[0] = ma; o[1] = ea;
+        }
+    }
+}
+
+// pass 2: the tile again -> conf = softmax over i x softmax over j from the merged statistics (one exponential per element:
+// exp((S - cm_j) + (S - rm_i)) / (csum_j rsum_i)), stored once; row best (value, lowest j, ties) and column maximum of the tile
+template <int NS>
+__global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_pass2_kernel(Sim2Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float rstat[TM][2];       // (max, 1 / sum) of the tile's rows
+    int ti, tj;
+    if (!xcd_tile(p, ti, tj)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
+    const int i0 = ti * TM, j0 = tj * TN, b = blockIdx.y;
+    if (tid < TM) {
+        const int i = i0 + tid;
+        const float* q = p.rowstat + ((size_t)b * p.N + min(i, p.N - 1)) * 2;
+        rstat[tid][0] = q[0];
+        rstat[tid][1] = 1.0f / q[1];
+    }
+    // this lane's two columns: (max, 1 / sum)
+    float cm[2], cinv[2];
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+        const int j = min(j0 + 64 * wc + 32 * y + r, p.M - 1);
+        const float* q = p.colstat + ((size_t)b * p.M + j) * 2;
+        cm[y] = q[0];
+        cinv[y] = 1.0f / q[1];
+    }
+    f32x16 acc[2][2];
+    sim_tile_from_planes<NS>(acc, p, smem, i0, j0, b, tid);           // (its barriers also publish rstat)
+    float* St = reinterpret_cast<float*>(smem);
+    const float inv_temp = 1.0f / p.temp;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = 64 * wr + 32 * x + acc_row(reg, h);
+            const float rm = rstat[row][0], rinv = rstat[row][1];
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const float sv = acc[x][y][reg] * inv_temp;
+                St[row * SLD + 64 * wc + 32 * y + r] = __expf((sv - cm[y]) + (sv - rm)) * (cinv[y] * rinv);
+            }
+        }
+    __syncthreads();
+    // ---- conf_matrix rows, coalesced ---------------------------------------------------------------------------
+    float* conf = p.conf + (size_t)b * p.N * p.M;
+    const bool vec = (p.M & 3) == 0;
+#pragma unroll 4
+    for (int i = tid; i < TM * (TN / 4); i += 256) {
+        const int row = i / (TN / 4), c4 = i % (TN / 4);
+        const int gi = i0 + row, gj = j0 + 4 * c4;
+        if (gi >= p.N || gj >= p.M) continue;
+        const float* src = St + row * SLD + 4 * c4;
+        if (vec) {
+            f32x4 v = {src[0], src[1], src[2], src[3]};
+            *reinterpret_cast<f32x4*>(conf + (size_t)gi * p.M + gj) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (gj + e < p.M) conf[(size_t)gi * p.M + gj + e] = src[e];
+        }
+    }
+    // ---- row best / column maximum of the tile: lanes (2k, 2k + 1) share row (column) k, even / odd elements ----------
+    const int idx = tid >> 1, par = tid & 1;
+    {
+        const int ncol = min(TN, p.M - j0);
+        float bv = -1.f;
+        int bj = 0x7fffffff, bc = 0;
+#pragma unroll 16
+        for (int q = 0; q < TN / 2; ++q) {
+            const int jj = 2 * q + par;
+            if (jj < ncol) {
+                const float c = St[idx * SLD + jj];
+                if (c > bv) { bv = c; bj = j0 + jj; bc = 1; }
+                else if (c == bv) { bc += 1; }                 // ascending sweep: bj already holds the lowest j
+            }
+        }
+        const float v2 = __shfl_xor(bv, 1, 64);
+        const int j2 = __shfl_xor(bj, 1, 64), c2 = __shfl_xor(bc, 1, 64);
+        if (v2 > bv) { bv = v2; bj = j2; bc = c2; }
+        else if (v2 == bv) { bj = min(bj, j2); bc += c2; }
+        if (par == 0 && i0 + idx < p.N) {
+            float* o = p.rowbest + (((size_t)b * p.ntc + tj) * p.N + i0 + idx) * 3;
+            o[0] = bv; o[1] = __int_as_float(bj); o[2] = __int_as_float(bc);
+        }
+    }
+    {
+        const int nrow = min(TM, p.N - i0);
+        float m = 0.f;                                       // conf >= 0
+#pragma unroll 16
+        for (int q = 0; q < TM / 2; ++q) {
+            const int ii = 2 * q + par;
+            if (ii < nrow) m = fmaxf(m, St[ii * SLD + idx]);
+        }
+        m = fmaxf(m, __shfl_xor(m, 1, 64));
+        if (par == 0 && j0 + idx < p.M) p.colmaxp[((size_t)b * p.ntr + ti) * p.M + j0 + idx] = m;
+    }
+}
+
+struct BestArgs {
+    const float* rowbest_part;   // [B][ntc][N][3]
+    const float* colmaxp;        // [B][ntr][M]
+    float* rowbest;              // [B][N][3]
+    float* colmax;               // [B][M]
+    int N, M, ntr, ntc;
+};
+
+// fixed-order merge of the per-tile partials: one thread per row (over the ntc column tiles) or column (over the ntr row tiles)
+__global__ __launch_bounds__(256) void best_combine_kernel(BestArgs p) {
+    const int g = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (g < p.N) {
+        float v = -1.f;
+        int j = 0x7fffffff, c = 0;
+        for (int t = 0; t < p.ntc; ++t) {
+            const float* q = p.rowbest_part + (((size_t)b * p.ntc + t) * p.N + g) * 3;
+            const float v2 = q[0];
+            const int j2 = __float_as_int(q[1]), c2 = __float_as_int(q[2]);
+            if (v2 > v) { v = v2; j = j2; c = c2; }
+            else if (v2 == v) { j = min(j, j2); c += c2; }
+        }
+        float* o = p.rowbest + ((size_t)b * p.N + g) * 3;
+        o[0] = v; o[1] = __int_as_float(j); o[2] = __int_as_float(c);
+    } else if (g - p.N < p.M) {
+        const int jj = g - p.N;
+        float m = 0.f;
+        for (int t = 0; t < p.ntr; ++t) m = fmaxf(m, p.colmaxp[((size_t)b * p.ntr + t) * p.M + jj]);
+        p.colmax[(size_t)b * p.M + jj] = m;
+    }
 }
 
 struct CombineArgs {
@@ -597,8 +926,11 @@ extern "C" size_t ophip_coarse_workspace_floats(int B, int N, int M) {
     f += (size_t)B * ntc * N * 2;          // rowpart
     f += (size_t)B * ntr * M * 2;          // colpart
     f += (size_t)B * N * 2 + (size_t)B * M * 2;     // rowstat, colstat
-    f += (size_t)B * conf_nspan(M) * N * 3;         // rowbest
+    f += (size_t)B * conf_nspan(M) * N * 3;         // rowbest (one-pass form: per span)
     f += (size_t)B * M;                    // colmax (float bits)
+    // two-pass form of the bf16 modes: (hi, lo) bf16 planes of both inputs, per-tile row-best / column-max partials
+    f += (size_t)B * ((size_t)N + M) * C + 64;
+    f += (size_t)B * ntc * N * 3 + (size_t)B * ntr * M + (size_t)B * N * 3;
     return f + 64;
 }
 
@@ -621,30 +953,78 @@ extern "C" int ophip_coarse_match(const float* feat3d, const float* feat2d, cons
     float* rowbest = colstat + (size_t)B * M * 2;
     float* colmax = rowbest + (size_t)B * nspan * N * 3;
 
-    SimArgs sa{feat3d, feat2d, conf, rowpart, colpart, N, M, ntr, ntc, (float)(temperature + 1e-4), ophip_stamp_buffer()};
-    {
-        // dynamic LDS = max(operand tiles, S staging image of the epilogue)
-        const size_t tiles = nsplit == 0 ? (size_t)(TM + TN) * LDT * sizeof(float) : (size_t)(nsplit == 3 ? 4 : 2) * TM * SPITCH;
+    // Measured at c2 (tools/time_coarse.py, round 2): the two-pass form as built moves 1/3 of the bytes but runs its tile GEMM
+    // + epilogue twice -- split 16 + pass1 119 + combine 8 + pass2 181 + best 27 + select 19 = 345 us against 205 us for the
+    // one-pass chain (sim_stats 105, conf 85): the 128 x 128 tile kernel spends 3/4 of its time outside the MFMAs (staging,
+    // barriers, the LDS sweeps of the epilogue), so recomputing S only pays once that kernel is ~2x leaner.  It stays
+    // selectable (OPHIP_COARSE_TWOPASS=1) and parity-tested; the default is the one-pass chain.
+    static const bool two_pass_env = getenv("OPHIP_COARSE_TWOPASS") != nullptr;
+    const bool two_pass = nsplit != 0 && two_pass_env;
+    int sel_nspan = nspan;
+    if (two_pass) {
+        // ---- bf16 modes: S recomputed instead of stored (see the kernels above) ------------------------------------------
+        float* w2 = colmax + (size_t)B * M;
+        w2 += (16 - ((reinterpret_cast<uintptr_t>(w2) >> 2) & 15)) & 15;                 // 64-byte aligned planes
+        char* a_hi = reinterpret_cast<char*>(w2);
+        char* a_lo = a_hi + (size_t)B * N * C * 2;
+        char* b_hi = a_lo + (size_t)B * N * C * 2;
+        char* b_lo = b_hi + (size_t)B * M * C * 2;
+        float* rowbest_part = reinterpret_cast<float*>(b_lo + (size_t)B * M * C * 2);
+        float* colmaxp = rowbest_part + (size_t)B * ntc * N * 3;
+        float* rowbest1 = colmaxp + (size_t)B * ntr * M;
+        SplitArgs s3{feat3d, a_hi, a_lo, (long long)B * N}, s2{feat2d, b_hi, b_lo, (long long)B * M};
+        OPHIP_LAUNCH("split_planes", stream, split_planes_kernel, dim3((unsigned)(((long long)B * N * (C / 8) + 255) / 256)), dim3(256), 0, stream, s3);
+        OPHIP_LAUNCH("split_planes", stream, split_planes_kernel, dim3((unsigned)(((long long)B * M * (C / 8) + 255) / 256)), dim3(256), 0, stream, s2);
+        OPHIP_CHECK_LAUNCH();
+        const int per_xcd = ((ntr + 7) / 8) * ntc;
+        Sim2Args pa{a_hi, a_lo, b_hi, b_lo, conf, rowpart, colpart, rowstat, colstat, rowbest_part, colmaxp, N, M, ntr, ntc, per_xcd,
+                    (float)(temperature + 1e-4)};
+        const size_t tiles = (size_t)(nsplit == 3 ? 4 : 2) * TM * SPITCH;
         const size_t lds = tiles > SIM_STAGE_BYTES ? tiles : SIM_STAGE_BYTES;
-        const void* fn = nsplit == 0 ? reinterpret_cast<const void*>(sim_stats_kernel)
-                       : nsplit == 3 ? reinterpret_cast<const void*>(sim_stats_bf16_kernel<3>) : reinterpret_cast<const void*>(sim_stats_bf16_kernel<1>);
-        if (int rc = ophip_lds_attr(fn, lds, "hipFuncSetAttribute(sim_stats)")) return rc;
-        if (nsplit == 0) OPHIP_LAUNCH("sim_stats", stream, sim_stats_kernel, dim3(ntc, ntr, B), dim3(256), lds, stream, sa);
-        else if (nsplit == 3) OPHIP_LAUNCH("sim_stats", stream, sim_stats_bf16_kernel<3>, dim3(ntc, ntr, B), dim3(256), lds, stream, sa);
-        else OPHIP_LAUNCH("sim_stats", stream, sim_stats_bf16_kernel<1>, dim3(ntc, ntr, B), dim3(256), lds, stream, sa);
+        const void* f1 = nsplit == 3 ? reinterpret_cast<const void*>(sim_pass1_kernel<3>) : reinterpret_cast<const void*>(sim_pass1_kernel<1>);
+        const void* f2 = nsplit == 3 ? reinterpret_cast<const void*>(sim_pass2_kernel<3>) : reinterpret_cast<const void*>(sim_pass2_kernel<1>);
+        if (int rc = ophip_lds_attr(f1, lds, "hipFuncSetAttribute(sim_pass1)")) return rc;
+        if (int rc = ophip_lds_attr(f2, lds, "hipFuncSetAttribute(sim_pass2)")) return rc;
+        if (nsplit == 3) OPHIP_LAUNCH("sim_pass1", stream, sim_pass1_kernel<3>, dim3(8 * per_xcd, B), dim3(256), lds, stream, pa);
+        else OPHIP_LAUNCH("sim_pass1", stream, sim_pass1_kernel<1>, dim3(8 * per_xcd, B), dim3(256), lds, stream, pa);
+        OPHIP_CHECK_LAUNCH();
+        CombineArgs ca{rowpart, colpart, rowstat, colstat, reinterpret_cast<unsigned*>(colmax), N, M, ntr, ntc};
+        OPHIP_LAUNCH("stat_combine", stream, stat_combine_kernel, dim3((N + M + 31) / 32, B), dim3(256), 0, stream, ca);
+        OPHIP_CHECK_LAUNCH();
+        if (nsplit == 3) OPHIP_LAUNCH("sim_pass2", stream, sim_pass2_kernel<3>, dim3(8 * per_xcd, B), dim3(256), lds, stream, pa);
+        else OPHIP_LAUNCH("sim_pass2", stream, sim_pass2_kernel<1>, dim3(8 * per_xcd, B), dim3(256), lds, stream, pa);
+        OPHIP_CHECK_LAUNCH();
+        BestArgs ba{rowbest_part, colmaxp, rowbest1, colmax, N, M, ntr, ntc};
+        OPHIP_LAUNCH("best_combine", stream, best_combine_kernel, dim3((N + M + 255) / 256, B), dim3(256), 0, stream, ba);
+        OPHIP_CHECK_LAUNCH();
+        rowbest = rowbest1;
+        sel_nspan = 1;
+    } else {
+        SimArgs sa{feat3d, feat2d, conf, rowpart, colpart, N, M, ntr, ntc, (float)(temperature + 1e-4), ophip_stamp_buffer()};
+        {
+            // dynamic LDS = max(operand tiles, S staging image of the epilogue)
+            const size_t tiles = nsplit == 0 ? (size_t)(TM + TN) * LDT * sizeof(float) : (size_t)(nsplit == 3 ? 4 : 2) * TM * SPITCH;
+            const size_t lds = tiles > SIM_STAGE_BYTES ? tiles : SIM_STAGE_BYTES;
+            const void* fn = nsplit == 0 ? reinterpret_cast<const void*>(sim_stats_kernel)
+                           : nsplit == 3 ? reinterpret_cast<const void*>(sim_stats_bf16_kernel<3>) : reinterpret_cast<const void*>(sim_stats_bf16_kernel<1>);
+            if (int rc = ophip_lds_attr(fn, lds, "hipFuncSetAttribute(sim_stats)")) return rc;
+            if (nsplit == 0) OPHIP_LAUNCH("sim_stats", stream, sim_stats_kernel, dim3(ntc, ntr, B), dim3(256), lds, stream, sa);
+            else if (nsplit == 3) OPHIP_LAUNCH("sim_stats", stream, sim_stats_bf16_kernel<3>, dim3(ntc, ntr, B), dim3(256), lds, stream, sa);
+            else OPHIP_LAUNCH("sim_stats", stream, sim_stats_bf16_kernel<1>, dim3(ntc, ntr, B), dim3(256), lds, stream, sa);
+        }
+        OPHIP_CHECK_LAUNCH();
+        CombineArgs ca{rowpart, colpart, rowstat, colstat, reinterpret_cast<unsigned*>(colmax), N, M, ntr, ntc};
+        OPHIP_LAUNCH("stat_combine", stream, stat_combine_kernel, dim3((N + M + 31) / 32, B), dim3(256), 0, stream, ca);
+        OPHIP_CHECK_LAUNCH();
+        ConfArgs fa{conf, rowstat, colstat, rowbest, reinterpret_cast<unsigned*>(colmax), N, M, nspan, spanw, nrb};
+        const bool vec = M % 4 == 0, fast = nsplit != 0;
+        if (vec && fast) OPHIP_LAUNCH("conf", stream, (conf_kernel<true, true>), dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
+        else if (vec) OPHIP_LAUNCH("conf", stream, (conf_kernel<true, false>), dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
+        else if (fast) OPHIP_LAUNCH("conf", stream, (conf_kernel<false, true>), dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
+        else OPHIP_LAUNCH("conf", stream, (conf_kernel<false, false>), dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
+        OPHIP_CHECK_LAUNCH();
     }
-    OPHIP_CHECK_LAUNCH();
-    CombineArgs ca{rowpart, colpart, rowstat, colstat, reinterpret_cast<unsigned*>(colmax), N, M, ntr, ntc};
-    OPHIP_LAUNCH("stat_combine", stream, stat_combine_kernel, dim3((N + M + 31) / 32, B), dim3(256), 0, stream, ca);
-    OPHIP_CHECK_LAUNCH();
-    ConfArgs fa{conf, rowstat, colstat, rowbest, reinterpret_cast<unsigned*>(colmax), N, M, nspan, spanw, nrb};
-    const bool vec = M % 4 == 0, fast = nsplit != 0;
-    if (vec && fast) OPHIP_LAUNCH("conf", stream, (conf_kernel<true, true>), dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
-    else if (vec) OPHIP_LAUNCH("conf", stream, (conf_kernel<true, false>), dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
-    else if (fast) OPHIP_LAUNCH("conf", stream, (conf_kernel<false, true>), dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
-    else OPHIP_LAUNCH("conf", stream, (conf_kernel<false, false>), dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
-    OPHIP_CHECK_LAUNCH();
-    SelectArgs se{conf, rowbest, colmax, keypoints3d, kpts_bstride, B, N, M, nspan, wc, border_rm, thr, scale,
+    SelectArgs se{conf, rowbest, colmax, keypoints3d, kpts_bstride, B, N, M, sel_nspan, wc, border_rm, thr, scale,
                   b_ids, i_ids, j_ids, mconf, mkpts3d, mkpts_c, m_bids, gt_mask, count};
     OPHIP_LAUNCH("select", stream, select_kernel, dim3(1), dim3(1024), 0, stream, se);
     OPHIP_CHECK_LAUNCH();
