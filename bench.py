@@ -313,14 +313,16 @@ def main():
     launches, kern_ms = hip.timing_read()
     hip.timing_select("")
 
-    # HBM bytes per launch of the roofline kernel: from the committed PMC pass (separate rocprofv3 --pmc runs), not live
-    traffic = None
+    # HBM bytes and matrix-pipe busy cycles per launch of the roofline kernel: from the committed counter passes (separate
+    # rocprofv3 --pmc runs, tools/run_profile_r02.sh), not live
+    traffic, mfma_busy = None, None
     try:
-        pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))["kernels"]
-        stem = {"bf16x3": "attn_apply_bf16_kernel<3", "bf16": "attn_apply_bf16_kernel<1", "f32": "attn_apply_kernel"}[args.precision]
+        pmc = json.load(open(os.path.join(REPO, "profiles", "r02_pmc.json")))["kernels"]
+        stem = {"bf16x3": "enc_x3_kernel<false>", "bf16": "attn_apply_bf16_kernel<1", "f32": "attn_apply_kernel"}[args.precision]
         hits = [v for k, v in pmc.items() if k.startswith(stem)]
         if hits and B == 1 and args.workload == "c2":
             traffic = hits[0]["hbm_bytes_per_launch"]
+            mfma_busy = hits[0].get("SQ_VALU_MFMA_BUSY_CYCLES_median")
     except (OSError, KeyError, ValueError):
         pass
 
@@ -372,6 +374,10 @@ def main():
             "frac": achieved / MFMA_PEAK_TFLOPS[args.precision],
             "mfma_issue_frac": achieved * (3.0 if args.precision == "bf16x3" else 1.0) / MFMA_PEAK_TFLOPS[args.precision],
             "traffic": traffic,
+            # SQ_VALU_MFMA_BUSY_CYCLES of the committed counter pass over (1024 SIMDs x this run's launch time x the 2.4 GHz the
+            # 2.5 PFLOP/s peak is quoted at): the matrix pipe's busy share at PEAK clock; the chip holds ~1.75 GHz in this kernel
+            # (in-kernel s_memtime), where the pipe is busy 46 % of the cycles
+            "mfma_busy_frac_at_peak_clock": (mfma_busy / (1024.0 * avg_ms * 1e-3 * 2.4e9)) if (mfma_busy and launches) else None,
             "launches": launches,
             "avg_launch_ms": avg_ms,
             "flops_per_launch": flops,

@@ -116,7 +116,19 @@ int ophip_fine_refine(const float* feat_f, long long fs_b, long long fs_c, long 
                       int wc, int stride, float fine_scale, float* expec_f, float* mkpts_f,
                       float* dbg_win, float* dbg_f3, void* stream);
 
-/* ophip_fine_refine on the bf16 matrix pipe (nsplit = 1 plain bf16, 3 split-bf16); two matches per workgroup.
+/* The same stage, split-bf16 only, second-generation mapping (csrc/fine_x3.hip): three matches per workgroup on
+ * v_mfma_f32_16x16x32_bf16, the layers' weights streamed once per three matches (packing.pack_fine_layers_x3,
+ * ophip_fine_x3_wpack_bytes(nlayers) bytes, 16-byte aligned).  The fine map must be channels-last (fs_c == 1).
+ * Other arguments as ophip_fine_refine.  Replaces fine_preprocess.py:32-55, transformer.py (fine cfg), fine_matching.py:28-110. */
+size_t ophip_fine_x3_wpack_bytes(int nlayers);
+int ophip_fine_refine_x3(const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x, int hf, int wf,
+                         const float* desc3d_f, long long ds_b, long long ds_c,
+                         const long long* b_ids, const long long* i_ids, const long long* j_ids, const int* count, int max_matches,
+                         const float* mkpts_c, const void* wpack, int nlayers, unsigned cross_bits, int encoder_enable,
+                         int wc, int stride, float fine_scale, float* expec_f, float* mkpts_f,
+                         float* dbg_win, float* dbg_f3, void* stream);
+
+/* ophip_fine_refine on the bf16 matrix pipe (nsplit = 1 plain bf16, 3 split-bf16); one match per 4-wave workgroup.
  * wpack: packing.pack_fine_layers_bf16 (ophip_fine_bf16_wpack_bytes(nlayers) bytes).  Other arguments as above. */
 size_t ophip_fine_bf16_wpack_bytes(int nlayers);
 int ophip_fine_refine_bf16(const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x, int hf, int wf,

@@ -162,6 +162,8 @@ class OnePosePlus_model(nn.Module):
             if self.precision == "bf16x3":
                 blocks["coarse_x3"] = [packing.pack_coarse_layer_x3(sd, f"loftr_coarse.layers.{i}.").to(device)
                                        for i in range(len(self.loftr_coarse.layer_names))]
+            if self.precision == "bf16x3" and os.environ.get("OPHIP_FINE_X3"):
+                blocks["fine_x3"] = packing.pack_fine_layers_x3(sd, "loftr_fine.layers.", len(self.loftr_fine.layer_names)).to(device)
             blocks["fine_bf16"] = packing.pack_fine_layers_bf16(sd, "loftr_fine.layers.", len(self.loftr_fine.layer_names)).to(device)
         self._packed = (key, blocks)
         return blocks
@@ -404,6 +406,15 @@ class OnePosePlus_model(nn.Module):
                              P(desc_fine_d), bstride(desc_fine_d), desc_fine_d.stride(1),
                              P(b_ids, torch.int64), P(i_ids, torch.int64), P(j_ids, torch.int64), P(count, torch.int32), max_matches,
                              P(mkc), P(W["fine"]), len(names_f), ctypes.c_uint(cross_bits), 1 if cf["enable"] else 0,
+                             wc, stride, float(fine_scale), P(expec), P(mkf), P(dbg_w), P(dbg_3), S)
+                elif self.precision == "bf16x3" and ff_strides[1] == 1 and os.environ.get("OPHIP_FINE_X3"):
+                    # three matches per workgroup, weights streamed once per three (csrc/fine_x3.hip).  Opt-in: stand-alone it is 6 %
+                    # faster than the one-match kernel (267 vs 283 us at K = 2975), but a 150 KiB-LDS workgroup per CU leaves no room
+                    # for the next frame's input kernels that run beside the fine stage: 1067 vs 1119 frames/s end to end
+                    lib_call("ophip_fine_refine_x3", P(ff), *ff_strides, hf, wf,
+                             P(desc_fine_d), bstride(desc_fine_d), desc_fine_d.stride(1),
+                             P(b_ids, torch.int64), P(i_ids, torch.int64), P(j_ids, torch.int64), P(count, torch.int32), max_matches,
+                             P(mkc), P(W["fine_x3"], None), len(names_f), ctypes.c_uint(cross_bits), 1 if cf["enable"] else 0,
                              wc, stride, float(fine_scale), P(expec), P(mkf), P(dbg_w), P(dbg_3), S)
                 else:
                     lib_call("ophip_fine_refine_bf16", P(ff), *ff_strides, hf, wf,

@@ -176,6 +176,50 @@ def pack_fine_layers_bf16(sd: dict, prefix: str, n_layers: int) -> torch.Tensor:
     return out
 
 
+X3_FINE_LAYER_FRAGS = 160        # per wave and layer, hi and lo counted separately
+
+
+def x3_fine_program(fw: int):
+    """(matrix, row0, k0) entries of ONE fine layer (d_model 128) in the order wave ``fw`` of csrc/fine_x3.hip consumes them:
+    K|V of heads 2fw, 2fw+1 | Q | merge | W0 chunk 0 | W2 chunk 0 | W0 chunk 1 | W2 chunk 1 (hidden chunk c = features 128c..)."""
+    rows = [32 * fw + 16 * ft for ft in range(2)]
+    prog = [(("k" if ft < 2 else "v"), 32 * fw + 16 * (ft & 1), 32 * ks) for ks in range(4) for ft in range(4)]
+    prog += [("q", r0, 32 * ks) for ks in range(4) for r0 in rows]
+    prog += [("m", r0, 32 * ks) for ks in range(4) for r0 in rows]
+    for c in range(2):
+        prog += [("w0", 128 * c + r0, 32 * ks) for ks in range(8) for r0 in rows]
+        prog += [("w2", r0, 128 * c + 32 * ks) for ks in range(4) for r0 in rows]
+    assert 2 * len(prog) == X3_FINE_LAYER_FRAGS
+    return prog
+
+
+def pack_fine_layers_x3(sd: dict, prefix: str, n_layers: int) -> torch.Tensor:
+    """uint8 block ``[streams: 4 waves x (n_layers x 160 KiB)][ln: n_layers x (norm1.w norm1.b norm2.w norm2.b) f32]`` for
+    ``ophip_fine_refine_x3`` (``prefix`` like ``"loftr_fine.layers."``); a wave's stream runs through all layers."""
+    frags = []
+    lns = []
+    per_layer = []
+    for i in range(n_layers):
+        p = f"{prefix}{i}."
+        mats = {"q": sd[p + "q_proj.weight"], "k": sd[p + "k_proj.weight"], "v": sd[p + "v_proj.weight"],
+                "m": sd[p + "merge.weight"], "w0": sd[p + "mlp.0.weight"], "w2": sd[p + "mlp.2.weight"]}
+        mats = {k: v.detach().to(torch.float32).cpu().contiguous() for k, v in mats.items()}
+        if tuple(mats["q"].shape) != (128, 128) or tuple(mats["w0"].shape) != (256, 256) or tuple(mats["w2"].shape) != (128, 256):
+            raise ValueError("fine encoder kernel is specialised for d_model = 128")
+        per_layer.append(mats)
+        lns.append(torch.cat(_ln(sd, p)))
+    for fw in range(4):
+        prog = x3_fine_program(fw)
+        for mats in per_layer:
+            frags += [x3_frag(mats[m], r0, k0) for (m, r0, k0) in prog]
+    flat = torch.stack(frags)
+    hi = flat.to(torch.bfloat16)
+    lo = (flat - hi.float()).to(torch.bfloat16)
+    out = _bytes(torch.stack([hi, lo], 1), torch.cat(lns))
+    assert out.numel() == n_layers * (4 * X3_FINE_LAYER_FRAGS * 1024 + 16 * 128)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------
 # backbone convolutions (csrc/conv.hip): BatchNorm folded in, weights as A-operand fragments in the order the kernel
 # walks K: (32-channel chunk, tap, 16-channel k-block)

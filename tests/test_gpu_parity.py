@@ -286,9 +286,11 @@ def test_coarse_match_empty(dev):
     close(conf, orc.dual_softmax_confidence(f3, f2, 0.08), atol=1e-7)
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16", "x3"])
 @pytest.mark.parametrize("channels_last", [False, True])
 def test_fine_refine_vs_oracle(sd, cfg, dev, channels_last, mode):
+    if mode == "x3" and not channels_last:
+        pytest.skip("ophip_fine_refine_x3 takes the channels-last map (the model always hands it one)")
     B, N, hc, wc = 2, 90, 6, 7
     hf, wf = hc * 4, wc * 4
     g = torch.Generator().manual_seed(7)
@@ -322,6 +324,11 @@ def test_fine_refine_vs_oracle(sd, cfg, dev, channels_last, mode):
         w = torch.cat([packing.pack_fine_layer(sd, f"loftr_fine.layers.{i}.") for i in range(2)]).to(dev)
         hip.call("ophip_fine_refine", *head, hip.ptr(w), 2, ctypes.c_uint(2), 1, *tail)
         rt, at = RTOL, ATOL
+    elif mode == "x3":                           # three matches per workgroup: K = 37 leaves a single match in the last one
+        w = packing.pack_fine_layers_x3(sd, "loftr_fine.layers.", 2).to(dev)
+        assert w.numel() == hip.load().ophip_fine_x3_wpack_bytes(2)
+        hip.call("ophip_fine_refine_x3", *head, hip.ptr(w, None), 2, ctypes.c_uint(2), 1, *tail)
+        rt, at = 5e-4, 2e-4
     else:
         w = packing.pack_fine_layers_bf16(sd, "loftr_fine.layers.", 2).to(dev)
         assert w.numel() == hip.load().ophip_fine_bf16_wpack_bytes(2)

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Summarise separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes into profiles/*_pmc_traffic.json.
 
-usage: python tools/pmc_summary.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out.json> [command text]
+usage: python tools/pmc_summary.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out.json> [command text] [dir of the matrix-pipe pass]
+
+The optional matrix-pipe pass (`--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE`) adds, per kernel,
+the MFMA-busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 (the counter
+sums the 8 XCDs; MI355X_MICROARCH.md "DVFS give-back"), and the clock that implies with the kernel-trace duration.
 
 Each pass is `rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -d <dir> -- python bench.py ...` (counters in
 their own runs, never with --stats/--sys-trace).  HBM bytes per launch follow /opt/skills/guides/MI355X_MICROARCH.md:
@@ -33,10 +37,23 @@ def collect(d, counter):
     return per
 
 
+def durations(d):
+    """median kernel duration (ns) per kernel from the pass's kernel trace"""
+    per = {}
+    for path in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                per.setdefault(short(row["Kernel_Name"]), []).append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+    return {k: statistics.median(v) for k, v in per.items()}
+
+
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
     command = sys.argv[4] if len(sys.argv) > 4 else ""
+    mfma_dir = sys.argv[5] if len(sys.argv) > 5 else None
     fetch, write = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
+    mf = {c: collect(mfma_dir, c) for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE")} if mfma_dir else {}
+    dur = durations(mfma_dir) if mfma_dir else {}
     kernels = {}
     for k in fetch:
         if k.startswith("__amd_rocclr") or k not in write:
@@ -48,6 +65,19 @@ def main():
             "launches": len(fetch[k]),
             "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0,
         }
+        if mf and k in mf["SQ_VALU_MFMA_BUSY_CYCLES"] and k in mf["GRBM_GUI_ACTIVE"]:
+            busy = statistics.median(mf["SQ_VALU_MFMA_BUSY_CYCLES"][k])
+            gui = statistics.median(mf["GRBM_GUI_ACTIVE"][k])
+            cyc = gui / 8.0
+            kernels[k].update({
+                "SQ_VALU_MFMA_BUSY_CYCLES_median": busy,
+                "GRBM_GUI_ACTIVE_median": gui,
+                "SQ_BUSY_CYCLES_median": statistics.median(mf["SQ_BUSY_CYCLES"].get(k, [0])),
+                "SQ_WAVE_CYCLES_median": statistics.median(mf["SQ_WAVE_CYCLES"].get(k, [0])),
+                "mfma_busy_frac": busy / (1024.0 * cyc) if cyc else None,
+                "duration_us_under_pmc": dur.get(k, 0) / 1e3,
+                "clock_ghz": cyc / dur[k] if dur.get(k) else None,
+            })
     json.dump({
         "command": command,
         "correction": "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (MI355X_MICROARCH.md HBM: on gfx950 FETCH_SIZE "
@@ -55,7 +85,8 @@ def main():
         "kernels": kernels,
     }, open(out, "w"), indent=1)
     for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:14]:
-        print(f"{k:60s} {v['hbm_bytes_per_launch'] / 1e6:10.2f} MB/launch  x{v['launches']}")
+        extra = f"  mfma busy {v['mfma_busy_frac']:.3f}, {v['duration_us_under_pmc']:.1f} us, {v['clock_ghz']:.2f} GHz" if v.get("mfma_busy_frac") is not None else ""
+        print(f"{k:60s} {v['hbm_bytes_per_launch'] / 1e6:10.2f} MB/launch  x{v['launches']}{extra}")
 
 
 if __name__ == "__main__":
