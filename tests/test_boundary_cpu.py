@@ -78,3 +78,18 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(root, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", txt, re.M), os.path.join(root, f)
+
+
+def test_custom_ops_are_registered_without_a_cpu_implementation():
+    """north_star: the kernels as PyTorch custom ops -- torch.ops.onepose_hip.* exist with the documented schemas and, like the
+    rest of the product path, have no CPU implementation"""
+    import pytest
+    import torch
+    from onepose_st_amd import ops
+    for name in ops.OPS:
+        op = getattr(torch.ops.onepose_hip, name)
+        assert str(op.default._schema).startswith(f"onepose_hip::{name}(")
+    with pytest.raises(NotImplementedError):
+        torch.ops.onepose_hip.pe_add_transpose(torch.zeros(1, 256, 2, 2), None, torch.zeros(1, 4, 256))
+    with pytest.raises(NotImplementedError):
+        torch.ops.onepose_hip.coarse_match(torch.zeros(1, 8, 256), torch.zeros(1, 4, 256), torch.zeros(1, 8, 3), 2, 0.08, 0.1, 2, 8.0, 3)

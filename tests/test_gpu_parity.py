@@ -656,3 +656,28 @@ def test_object_cache_is_bit_identical(sd, cfg, dev):
     assert cached._obj_cache is not entry
     for k in keys:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_custom_ops_match_the_c_abi(sd, dev):
+    """torch.ops.onepose_hip.* (onepose_st_amd/ops.py) forward to the same C symbols: one encoder layer and the coarse-matching
+    stage through the ops equal the direct calls bit for bit"""
+    from onepose_st_amd import ops  # noqa: F401  (registers the library)
+    g = torch.Generator().manual_seed(3)
+    B, L3, L2 = 1, 130, 96
+    x3, x2 = torch.randn(B, L3, 256, generator=g).to(dev), torch.randn(B, L2, 256, generator=g).to(dev)
+    w = packing.pack_coarse_layer_x3(sd, "loftr_coarse.layers.0.").to(dev)
+    ws = torch.empty(hip.load().ophip_encoder_x3_workspace_bytes(B, L3, L2), dtype=torch.uint8, device=dev)
+    y3, y2 = torch.empty_like(x3), torch.empty_like(x2)
+    torch.ops.onepose_hip.encoder_layer_x3(x3, x2, y3, y2, w, None, False, False, 0, ws)
+    z3, z2 = torch.empty_like(x3), torch.empty_like(x2)
+    hip.call("ophip_encoder_layer_x3", hip.ptr(x3), hip.ptr(x2), hip.ptr(z3), hip.ptr(z2), B, L3, L2, hip.ptr(w, None), None, 0, 0, 0,
+             hip.ptr(ws, None), hip.stream_handle())
+    assert torch.equal(y3, z3) and torch.equal(y2, z2)
+    kp = torch.randn(B, L3, 3, generator=g).to(dev)
+    f2 = y2.clone()
+    f2[0, :40] = y3[0, :40]                                   # plant matches
+    conf, b_ids, i_ids, j_ids, mconf, mk3, mkc, count = torch.ops.onepose_hip.coarse_match(y3, f2, kp, 12, 0.08, 0.1, 0, 8.0, 3)
+    K = int(count.item())
+    assert K >= 30 and conf.shape == (B, L3, L2) and torch.all(i_ids[:K][1:] > i_ids[:K][:-1])
+    with pytest.raises(ValueError):
+        torch.ops.onepose_hip.encoder_layer_x3(x3, x2, y3, y2, w, None, False, False, 0, ws[:64])
