@@ -318,7 +318,7 @@ def main():
     traffic, mfma_busy = None, None
     try:
         pmc = json.load(open(os.path.join(REPO, "profiles", "r02_pmc.json")))["kernels"]
-        stem = {"bf16x3": "enc_x3_kernel<false>", "bf16": "attn_apply_bf16_kernel<1", "f32": "attn_apply_kernel"}[args.precision]
+        stem = {"bf16x3": "enc_x3w8_kernel<false>" if os.environ.get("OPHIP_ENC_W8", "1") != "0" else "enc_x3_kernel<false>", "bf16": "attn_apply_bf16_kernel<1", "f32": "attn_apply_kernel"}[args.precision]
         hits = [v for k, v in pmc.items() if k.startswith(stem)]
         if hits and B == 1 and args.workload == "c2":
             traffic = hits[0]["hbm_bytes_per_launch"]
@@ -365,7 +365,7 @@ def main():
             "parallelism": f"frames sharded over {world} rank(s), one RCCL broadcast of weights + 3D block ({bcast_bytes} B)",
         },
         "roofline": {
-            "kernel": {"bf16x3": "enc_x3_kernel<false> (attn_apply)", "bf16": "attn_apply_bf16_kernel<1, 1>", "f32": "attn_apply_kernel"}[args.precision]
+            "kernel": {"bf16x3": ("enc_x3w8_kernel<false>" if os.environ.get("OPHIP_ENC_W8", "1") != "0" else "enc_x3_kernel<false>") + " (attn_apply)", "bf16": "attn_apply_bf16_kernel<1, 1>", "f32": "attn_apply_kernel"}[args.precision]
                       + " (fused Q-proj + linear attention + merge + MLP + 2 LayerNorms" + (" + next layer's K/V reduce)" if args.precision != "f32" else ")"),
             "bound": "mfma",
             "achieved": achieved,

@@ -86,6 +86,14 @@ int ophip_encoder_layer_x3(const float* x3d, const float* x2d, float* y3d, float
                            const void* wpack, const void* wpack_next, int is_cross, int kv_from_prev, int slot,
                            void* workspace, void* stream);
 
+/* ophip_encoder_layer_x3 with eight waves per workgroup (two per SIMD; csrc/encoder_x3w8.hip): same arguments, same slab and
+ * K/V formats, its own weight block (packing.pack_coarse_layer_x3w8, ophip_encoder_x3w8_wpack_bytes() bytes). */
+size_t ophip_encoder_x3w8_workspace_bytes(int B, int L3d, int L2d);
+size_t ophip_encoder_x3w8_wpack_bytes(void);
+int ophip_encoder_layer_x3w8(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
+                             const void* wpack, const void* wpack_next, int is_cross, int kv_from_prev, int slot,
+                             void* workspace, void* stream);
+
 /* a7 + a8 -- CoarseMatching.forward + get_coarse_match, inference branch
  * (utils/coarse_matching.py:76-123, :125-242, mask_border :10-20).
  * feat3d [B][N][256], feat2d [B][M][256] (encoder outputs), M = hc * wc.

@@ -1,0 +1,462 @@
+// Coarse LoFTR encoder layer, split-bf16, 48-token workgroups of EIGHT waves (two per SIMD).  Same mathematics, data layout,
+// K/V slab format and kv_sum as csrc/encoder_x3.hip (reference: loftr_module/transformer.py:65-94,146-159,
+// linear_attention.py:29-61); what changes is the split of a workgroup's work over waves:
+//
+//   * wave fw = head fw owns 32 of the 256 output features (two 16-row feature tiles) of all three token tiles, so every weight
+//     fragment still enters the CU once -- but a SIMD now holds two waves, and while one of them is stuck issuing a 1 KiB buffer
+//     load (~12 issue cycles next to a 16-cycle 16x16x32 MFMA, tools/micro/gemm16_rate.hip) or runs an epilogue on the vector
+//     ALU, its partner keeps the matrix pipe fed (tools/micro/gemm16_2w.hip: 257 against 293 us for the bare k-step loop);
+//   * the MLP's hidden layer goes in two 256-wide chunks through ONE hidden buffer (each wave produces 32 hidden features per
+//     chunk: with 128-wide chunks a wave would own a single feature tile and read 1 KiB of activations per 3 MFMAs);
+//   * per-wave streams are 256 + 64 KiB (packing.pack_coarse_layer_x3w8): Q | merge | W0c0 | W2c0 | W0c1 | W2c1, then the next
+//     layer's K|V of head fw.
+#include "tile_x3.h"
+#include <stdlib.h>
+
+namespace {
+
+using namespace x3;
+
+constexpr int C = 256, NH = 8, NW = 8;
+constexpr int NTT = 3, TOK = 16 * NTT;
+constexpr int ROWB = C * 2;                     // X / Y / hidden plane pitch (512 B, 32 chunks)
+constexpr int PLANE = TOK * ROWB;               // 24 576 B
+constexpr int MAIN_FRAGS = 256, KV_FRAGS = 64;  // per wave: Q 32 | merge 32 | W0c0 64 | W2c0 32 | W0c1 64 | W2c1 32 ;  K|V 64
+constexpr int KV_PART_FLOATS = NH * 1024 + NH * 32;
+constexpr int KV_FRAG_BYTES = NH * 2 * 2 * 64 * 16;
+constexpr int KV_BLOCK_BYTES = KV_FRAG_BYTES + NH * 32 * 4;
+constexpr int LDS_BYTES = 6 * PLANE + NW * TOK * 2 * 4;       // X, Y, hidden planes (hi, lo) + LayerNorm scratch = 150 528 B
+
+struct EncW8Args {
+    const float* x[2];
+    float* y[2];
+    long long xbs[2], ybs[2];
+    int L[2];
+    int tiles[2];
+    const char* kv[2];
+    long long kvbs;
+    float srclen[2];
+    const bf16x8* wmain;       // [8 waves][MAIN_FRAGS][64]
+    const bf16x8* wkv;         // [8 waves][KV_FRAGS][64] consumed by the tail; NULL: no tail
+    const float* ln;
+    float* partial;
+    unsigned long long* stamps;
+};
+
+__device__ __forceinline__ int stash_off(int row, int chunk) { return row * (C * 4) + ((chunk ^ (row & 15)) << 4); }
+
+// merge the eight waves' moments of token 16 tt + c16 -> mean, 1 / sqrt(var + eps)   (biased variance over 256 features)
+__device__ __forceinline__ void merged_stats(const float* scratch, int tt, int c16, float& mean, float& rstd) {
+    float sw[NW], dw[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const float2 v = *reinterpret_cast<const float2*>(scratch + (w * TOK + 16 * tt + c16) * 2);
+        sw[w] = v.x; dw[w] = v.y;
+    }
+    mean = (((sw[0] + sw[1]) + (sw[2] + sw[3])) + ((sw[4] + sw[5]) + (sw[6] + sw[7]))) * (1.0f / C);
+    float m2 = ((dw[0] + dw[1]) + (dw[2] + dw[3])) + ((dw[4] + dw[5]) + (dw[6] + dw[7]));
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const float d = sw[w] * (1.0f / 32) - mean;
+        m2 += 32.f * d * d;
+    }
+    rstd = 1.0f / sqrtf(m2 * (1.0f / C) + 1e-5f);
+}
+
+__device__ __forceinline__ void publish_moments(float* scratch, const float (&s)[NTT], const float (&d2)[NTT], int fw, int c16, int q) {
+    if (q == 0) {
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+            float2 v = {s[tt], d2[tt]};
+            *reinterpret_cast<float2*>(scratch + (fw * TOK + 16 * tt + c16) * 2) = v;
+        }
+    }
+}
+
+// K|V projection of the 48 tokens in the X planes for head fw and its phi(K)^T V / Ksum slab slice
+__device__ __forceinline__ void kv_tail(Ring& ring, const WStream& wsk, const char* XH, const char* XL, int tok0, int L, float* __restrict__ out,
+                                        int fw, int lane) {
+    const int c16 = lane & 15, q = lane >> 4;
+    f32x4 kk[4][NTT];            // D[token 4q + r][feature c16]: ft 0, 1 = K of head fw, ft 2, 3 = V
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) kk[ft][tt] = zero4();
+    gemm_stage<NTT, 4, 8, false>(kk, ring, wsk, R, XH, XL, ROWB, 0, c16, q);
+    const float inv_len = 1.0f / (float)L;
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                kk[ft][tt][r] = (tok0 + 16 * tt + 4 * q + r < L) ? elu_plus_one_fast(kk[ft][tt][r]) : 0.f;
+                kk[2 + ft][tt][r] *= inv_len;
+            }
+    const f32x4 z4 = zero4();
+    const int head = fw;
+    bf16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        split8(kk[t][0], kk[t][1], ah[t][0], al[t][0]);
+        split8(kk[t][2], z4, ah[t][1], al[t][1]);
+        split8(kk[2 + t][0], kk[2 + t][1], bh[t][0], bl[t][0]);
+        split8(kk[2 + t][2], z4, bh[t][1], bl[t][1]);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+        for (int vt = 0; vt < 2; ++vt) {
+            f32x4 kvt = zero4();
+            kvt = mma16x3(ah[dt][0], al[dt][0], bh[vt][0], bl[vt][0], kvt);
+            kvt = mma16x3(ah[dt][1], al[dt][1], bh[vt][1], bl[vt][1], kvt);
+            *reinterpret_cast<f32x4*>(out + ((size_t)((head * 2 + dt) * 2 + vt) * 64 + lane) * 4) = kvt;
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) s += (kk[dt][tt][0] + kk[dt][tt][1]) + (kk[dt][tt][2] + kk[dt][tt][3]);
+        s = sum_over_q(s);
+        if (q == 0) out[NH * 1024 + head * 32 + 16 * dt + c16] = s;
+    }
+}
+
+template <bool ONLY_KV>
+__global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kernel(EncW8Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* XH = smem;
+    char* XL = smem + PLANE;
+    char* YH = smem + 2 * PLANE;
+    char* YL = smem + 3 * PLANE;
+    char* HH = smem + 4 * PLANE;
+    char* HL = smem + 5 * PLANE;
+    float* scratch = reinterpret_cast<float*>(smem + 6 * PLANE);
+    const int tid = threadIdx.x, lane = tid & 63, fw = tid >> 6;
+    const int c16 = lane & 15, q = lane >> 4;
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int s = tile >= a.tiles[0] ? 1 : 0;
+    const int lt = s ? tile - a.tiles[0] : tile;
+    const int L = a.L[s], tok0 = lt * TOK;
+    const float* xg = a.x[s] + (size_t)b * a.xbs[s];
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    float* slab = a.partial + ((size_t)b * (a.tiles[0] + a.tiles[1]) + tile) * KV_PART_FLOATS;
+    const int fwu = __builtin_amdgcn_readfirstlane(fw);
+    const bool tail = a.wkv != nullptr;
+    WStream wsk;
+    wsk.open(tail ? a.wkv + (size_t)fwu * KV_FRAGS * 64 : a.wmain, tail ? KV_FRAGS : 0, lane);
+    Ring ring;
+    OPHIP_STAMP(a.stamps, wg, 0);
+
+    // activation rows: 48 x 256 f32, (row, 8-feature chunk) items over 512 threads
+    constexpr int ITEMS = TOK * (C / 8) / 512;       // 3
+    f32x4 v0[ITEMS], v1[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int it = tid + 512 * i, row = it >> 5, ch = it & 31;
+        v0[i] = v1[i] = zero4();
+        if (tok0 + row < L) {
+            const float* src = xg + (size_t)(tok0 + row) * C + 8 * ch;
+            v0[i] = *reinterpret_cast<const f32x4*>(src);
+            v1[i] = *reinterpret_cast<const f32x4*>(src + 4);
+        }
+    }
+    WStream wsm;
+    wsm.open(a.wmain + (size_t)fwu * MAIN_FRAGS * 64, MAIN_FRAGS, lane);
+    if (ONLY_KV) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) ring.s[i] = wsk.load(i);
+    } else {
+#pragma unroll
+        for (int i = 0; i < R; ++i) ring.s[i] = wsm.load(i);
+    }
+    // attention state of head fw and the LayerNorm parameters of this lane's features
+    bf16x8 kvh[2], kvl[2];
+    f32x4 ksm[2], g1[2], b1[2], g2[2], b2[2];
+    if (!ONLY_KV) {
+        const char* kvb = a.kv[s] + (size_t)b * a.kvbs;
+#pragma unroll
+        for (int vt = 0; vt < 2; ++vt) {
+            kvh[vt] = *reinterpret_cast<const bf16x8*>(kvb + ((size_t)((fw * 2 + vt) * 2 + 0) * 64 + lane) * 16);
+            kvl[vt] = *reinterpret_cast<const bf16x8*>(kvb + ((size_t)((fw * 2 + vt) * 2 + 1) * 64 + lane) * 16);
+        }
+        const float* kp = reinterpret_cast<const float*>(kvb + KV_FRAG_BYTES) + fw * 32 + 4 * q;
+        ksm[0] = *reinterpret_cast<const f32x4*>(kp);
+        ksm[1] = *reinterpret_cast<const f32x4*>(kp + 16);
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) {
+            const int f0 = 32 * fw + 16 * ft + 4 * q;
+            g1[ft] = *reinterpret_cast<const f32x4*>(a.ln + f0);
+            b1[ft] = *reinterpret_cast<const f32x4*>(a.ln + C + f0);
+            g2[ft] = *reinterpret_cast<const f32x4*>(a.ln + 2 * C + f0);
+            b2[ft] = *reinterpret_cast<const f32x4*>(a.ln + 3 * C + f0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int it = tid + 512 * i, row = it >> 5, ch = it & 31;
+        bf16x8 vh, vl;
+        split8(v0[i], v1[i], vh, vl);
+        const int off = row * ROWB + ((ch ^ (row & 15)) << 4);
+        *reinterpret_cast<bf16x8*>(XH + off) = vh;
+        *reinterpret_cast<bf16x8*>(XL + off) = vl;
+        if (!ONLY_KV) {                               // exact f32 copy for the residual, parked in the idle hidden planes
+            *reinterpret_cast<f32x4*>(HH + stash_off(row, 2 * ch)) = v0[i];
+            *reinterpret_cast<f32x4*>(HH + stash_off(row, 2 * ch + 1)) = v1[i];
+        }
+    }
+    __syncthreads();
+    if (ONLY_KV) {
+        kv_tail(ring, wsk, XH, XL, tok0, L, slab, fw, lane);
+        return;
+    }
+    f32x4 xr[2][NTT];
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) xr[ft][tt] = *reinterpret_cast<const f32x4*>(HH + stash_off(16 * tt + c16, 8 * fw + 4 * ft + q));
+    OPHIP_STAMP(a.stamps, wg, 1);
+
+    // ---- Q projection of head fw, phi, linear attention from registers -> msg planes (Y) --------------------------------
+    {
+        f32x4 qa[2][NTT];
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt) qa[ft][tt] = zero4();
+        gemm_stage<NTT, 2, 8, true>(qa, ring, wsm, 0 + R, XH, XL, ROWB, 0, c16, q);
+        OPHIP_STAMP(a.stamps, wg, 2);
+        const float S = a.srclen[s];
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+            f32x4 p0, p1;
+            float den = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p0[r] = elu_plus_one_fast(qa[0][tt][r]);
+                p1[r] = elu_plus_one_fast(qa[1][tt][r]);
+                den += p0[r] * ksm[0][r] + p1[r] * ksm[1][r];
+            }
+            den = sum_over_q(den);
+            bf16x8 qh, ql;
+            split8(p0, p1, qh, ql);
+            const float z = rcp_fast(den + 1e-6f) * S;
+#pragma unroll
+            for (int vt = 0; vt < 2; ++vt) {
+                f32x4 num = mma16x3(kvh[vt], kvl[vt], qh, ql, zero4());
+#pragma unroll
+                for (int r = 0; r < 4; ++r) num[r] *= z;
+                store_quad(num, YH, YL, ROWB, tt, c16, 32 * fw + 16 * vt + 4 * q);
+            }
+        }
+    }
+    __syncthreads();
+    OPHIP_STAMP(a.stamps, wg, 3);
+
+    // ---- merge + LayerNorm 1 -> Y --------------------------------------------------------------------------------------
+    {
+        f32x4 m[2][NTT];
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt) m[ft][tt] = zero4();
+        gemm_stage<NTT, 2, 8, true>(m, ring, wsm, 32 + R, YH, YL, ROWB, 0, c16, q);
+        OPHIP_STAMP(a.stamps, wg, 4);
+        float sm[NTT], dm[NTT];
+        wave_moments<NTT, 2>(m, sm, dm);
+        publish_moments(scratch, sm, dm, fw, c16, q);
+        __syncthreads();                             // moments visible; every wave is done reading the msg planes
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+            float mean, rstd;
+            merged_stats(scratch, tt, c16, mean, rstd);
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (m[ft][tt][r] - mean) * rstd * g1[ft][r] + b1[ft][r];
+                store_quad(v, YH, YL, ROWB, tt, c16, 32 * fw + 16 * ft + 4 * q);
+            }
+        }
+    }
+    __syncthreads();
+    OPHIP_STAMP(a.stamps, wg, 5);
+
+    // ---- MLP: hidden = relu([x, msg] W0^T) in two 256-feature chunks, o += hidden_chunk W2[:, chunk]^T ------------------------
+    f32x4 o[2][NTT];
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) o[ft][tt] = zero4();
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        f32x4 hd[2][NTT];
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt) hd[ft][tt] = zero4();
+        const int pos = 64 + 96 * c;                 // W0 chunk c: 64 fragments (x half 32, msg half 32), then W2 chunk c: 32
+        gemm_stage<NTT, 2, 8, true>(hd, ring, wsm, pos + R, XH, XL, ROWB, 0, c16, q);
+        gemm_stage<NTT, 2, 8, true>(hd, ring, wsm, pos + 32 + R, YH, YL, ROWB, 0, c16, q);
+        if (c == 1) __syncthreads();                 // every wave is done reading chunk 0 of the hidden planes
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(hd[ft][tt][r], 0.f);
+                store_quad(v, HH, HL, ROWB, tt, c16, 32 * fw + 16 * ft + 4 * q);
+            }
+        __syncthreads();
+        OPHIP_STAMP(a.stamps, wg, 6 + 2 * c);
+        // W2 chunk c; the main stream ends inside chunk 1: its last 16 refills pull the head of the next layer's K|V stream
+        if (c == 0) gemm_stage<NTT, 2, 8, true>(o, ring, wsm, pos + 64 + R, HH, HL, ROWB, 0, c16, q);
+        else gemm_stage<NTT, 2, 8, true>(o, ring, wsm, pos + 64 + R, HH, HL, ROWB, 0, c16, q, 32 - R, &wsk, 0);
+        OPHIP_STAMP(a.stamps, wg, 7 + 2 * c);
+    }
+
+    // ---- LayerNorm 2, residual, output rows (and their planes for the fused K|V tail) -----------------------------------
+    {
+        float so[NTT], dq[NTT];
+        wave_moments<NTT, 2>(o, so, dq);
+        publish_moments(scratch, so, dq, fw, c16, q);
+    }
+    __syncthreads();                                 // also: every wave is done with the X planes
+    float* yg = a.y[s] + (size_t)b * a.ybs[s];
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+        float mean, rstd;
+        merged_stats(scratch, tt, c16, mean, rstd);
+        const int tok = tok0 + 16 * tt + c16;
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = xr[ft][tt][r] + ((o[ft][tt][r] - mean) * rstd * g2[ft][r] + b2[ft][r]);
+            if (tok < L) *reinterpret_cast<f32x4*>(yg + (size_t)tok * C + 32 * fw + 16 * ft + 4 * q) = v;
+            else v = zero4();
+            if (tail) store_quad(v, XH, XL, ROWB, tt, c16, 32 * fw + 16 * ft + 4 * q);
+        }
+    }
+    OPHIP_STAMP(a.stamps, wg, 10);
+    if (tail) {
+        __syncthreads();
+        kv_tail(ring, wsk, XH, XL, tok0, L, slab, fw, lane);
+    }
+    OPHIP_STAMP(a.stamps, wg, 11);
+}
+
+struct KvSumArgs {
+    const float* partial;
+    char* kv;
+    int tiles[2];
+};
+
+constexpr int KVS_G = 16;
+
+// identical in function to kv_sum_x3_kernel of encoder_x3.hip (same slab and fragment formats)
+__global__ __launch_bounds__(1024) void kv_sum_w8_kernel(KvSumArgs a) {
+    __shared__ f32x4 red[KVS_G][64];
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int s = blockIdx.y & 1, b = blockIdx.y >> 1;
+    const int ttot = a.tiles[0] + a.tiles[1];
+    const int t0 = s ? a.tiles[0] : 0, nt = a.tiles[s];
+    const int e = (blockIdx.x * 64 + o) * 4;
+    const float* p = a.partial + ((size_t)b * ttot + t0) * KV_PART_FLOATS + e;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int t = g;
+    for (; t + 3 * KVS_G < nt; t += 4 * KVS_G) {
+        const f32x4 u0 = *reinterpret_cast<const f32x4*>(p + (size_t)t * KV_PART_FLOATS);
+        const f32x4 u1 = *reinterpret_cast<const f32x4*>(p + (size_t)(t + KVS_G) * KV_PART_FLOATS);
+        const f32x4 u2 = *reinterpret_cast<const f32x4*>(p + (size_t)(t + 2 * KVS_G) * KV_PART_FLOATS);
+        const f32x4 u3 = *reinterpret_cast<const f32x4*>(p + (size_t)(t + 3 * KVS_G) * KV_PART_FLOATS);
+        acc = (((acc + u0) + u1) + u2) + u3;
+    }
+    for (; t < nt; t += KVS_G) acc += *reinterpret_cast<const f32x4*>(p + (size_t)t * KV_PART_FLOATS);
+    red[g][o] = acc;
+    __syncthreads();
+    if (g == 0) {
+        f32x4 tot = red[0][o];
+#pragma unroll
+        for (int k = 1; k < KVS_G; ++k) tot += red[k][o];
+        char* blk = a.kv + ((size_t)b * 2 + s) * KV_BLOCK_BYTES;
+        if (e < NH * 1024) {
+            const int ln = (e >> 2) & 63, vt = (e >> 8) & 1, dt = (e >> 9) & 1, head = e >> 10;
+            bf16x4 vh, vl;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                __bf16 hh, ll;
+                split_bf16(tot[r], hh, ll);
+                vh[r] = hh; vl[r] = ll;
+            }
+            const size_t fr = (size_t)(head * 2 + vt) * 2;
+            *reinterpret_cast<bf16x4*>(blk + ((fr + 0) * 64 + ln) * 16 + 8 * dt) = vh;
+            *reinterpret_cast<bf16x4*>(blk + ((fr + 1) * 64 + ln) * 16 + 8 * dt) = vl;
+        } else {
+            *reinterpret_cast<f32x4*>(blk + KV_FRAG_BYTES + (size_t)(e - NH * 1024) * 4) = tot;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t ophip_encoder_x3w8_workspace_bytes(int B, int L3d, int L2d) {
+    const size_t tiles = (size_t)((L3d + TOK - 1) / TOK + (L2d + TOK - 1) / TOK);
+    return 2 * (size_t)B * tiles * KV_PART_FLOATS * 4 + (size_t)B * 2 * KV_BLOCK_BYTES + 256;
+}
+
+extern "C" size_t ophip_encoder_x3w8_wpack_bytes(void) { return (size_t)NW * (MAIN_FRAGS + KV_FRAGS) * 1024 + 4 * C * 4; }
+
+extern "C" int ophip_encoder_layer_x3w8(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
+                                        const void* wpack, const void* wpack_next, int is_cross, int kv_from_prev, int slot,
+                                        void* workspace, void* stream_) {
+    if (!x3d || !x2d || !y3d || !y2d || !wpack || !workspace) return ophip_bad_arg(__func__, "null pointer");
+    if (B < 1 || L3d < 1 || L2d < 1) return ophip_bad_arg(__func__, "B, L3d, L2d must be >= 1");
+    if (slot != 0 && slot != 1) return ophip_bad_arg(__func__, "slot must be 0 or 1");
+    if (x3d == y3d || x2d == y2d) return ophip_bad_arg(__func__, "in-place layer is not supported (cross layers read the pre-update streams)");
+    if (reinterpret_cast<uintptr_t>(wpack) & 15) return ophip_bad_arg(__func__, "wpack must be 16-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int t3 = (L3d + TOK - 1) / TOK, t2 = (L2d + TOK - 1) / TOK;
+    const size_t part_floats = (size_t)B * (t3 + t2) * KV_PART_FLOATS;
+    float* partial = reinterpret_cast<float*>(workspace) + (size_t)slot * part_floats;
+    float* partial_next = reinterpret_cast<float*>(workspace) + (size_t)(slot ^ 1) * part_floats;
+    char* kv = reinterpret_cast<char*>(workspace) + 2 * part_floats * 4;
+    kv += (256 - (reinterpret_cast<uintptr_t>(kv) & 255)) & 255;
+    // layer block: [main streams 8 x 256 KiB][K|V streams 8 x 64 KiB][g1 b1 g2 b2 f32]   (packing.pack_coarse_layer_x3w8)
+    const bf16x8* wmain = reinterpret_cast<const bf16x8*>(wpack);
+    const bf16x8* wkv_own = wmain + (size_t)NW * MAIN_FRAGS * 64;
+    const float* ln = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wpack) + (size_t)NW * (MAIN_FRAGS + KV_FRAGS) * 1024);
+    if (int rc = ophip_lds_attr(reinterpret_cast<const void*>(enc_x3w8_kernel<false>), LDS_BYTES, "hipFuncSetAttribute(enc_x3w8)")) return rc;
+    if (int rc = ophip_lds_attr(reinterpret_cast<const void*>(enc_x3w8_kernel<true>), LDS_BYTES, "hipFuncSetAttribute(enc_x3w8 kv)")) return rc;
+
+    EncW8Args aa;
+    aa.x[0] = x3d; aa.x[1] = x2d; aa.y[0] = y3d; aa.y[1] = y2d;
+    aa.xbs[0] = aa.ybs[0] = (long long)L3d * C; aa.xbs[1] = aa.ybs[1] = (long long)L2d * C;
+    aa.L[0] = L3d; aa.L[1] = L2d; aa.tiles[0] = t3; aa.tiles[1] = t2;
+    aa.kvbs = 2LL * KV_BLOCK_BYTES;
+    aa.srclen[0] = (float)(is_cross ? L2d : L3d);
+    aa.srclen[1] = (float)(is_cross ? L3d : L2d);
+    aa.wmain = wmain; aa.ln = ln;
+    aa.stamps = ophip_stamp_buffer();
+    if (!kv_from_prev) {
+        EncW8Args ka = aa;
+        ka.kv[0] = ka.kv[1] = nullptr;
+        ka.wkv = wkv_own;
+        ka.partial = partial;
+        ka.stamps = nullptr;
+        OPHIP_LAUNCH("kv_reduce", stream, enc_x3w8_kernel<true>, dim3(t3 + t2, B), dim3(512), LDS_BYTES, stream, ka);
+        OPHIP_CHECK_LAUNCH();
+    }
+    KvSumArgs sa;
+    sa.partial = partial; sa.kv = kv; sa.tiles[0] = t3; sa.tiles[1] = t2;
+    OPHIP_LAUNCH("kv_sum", stream, kv_sum_w8_kernel, dim3(KV_PART_FLOATS / 256, 2 * B), dim3(1024), 0, stream, sa);
+    OPHIP_CHECK_LAUNCH();
+    aa.kv[0] = kv + (is_cross ? KV_BLOCK_BYTES : 0);
+    aa.kv[1] = kv + (is_cross ? 0 : KV_BLOCK_BYTES);
+    aa.wkv = nullptr;
+    aa.partial = partial_next;
+    if (wpack_next) aa.wkv = reinterpret_cast<const bf16x8*>(wpack_next) + (size_t)NW * MAIN_FRAGS * 64;
+    OPHIP_LAUNCH("attn_apply", stream, enc_x3w8_kernel<false>, dim3(t3 + t2, B), dim3(512), LDS_BYTES, stream, aa);
+    OPHIP_CHECK_LAUNCH();
+    return 0;
+}

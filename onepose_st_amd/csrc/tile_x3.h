@@ -104,9 +104,11 @@ __device__ __forceinline__ void read_x(XFrag<NTT>& x, const char* ph, const char
 //            the last k-step stays inside the plane's allocation and is discarded);
 //   W_IS_A: D[feature][token] (weights are the A operand) / false: D[token][feature].
 // The loop body covers whole passes over the ring, so slot indices and the activation double buffer stay static.
+//   refills: the first `na` fragments of the stage come from stream `wa` at posa.., the rest from `wb` at posb.. (a stream that
+//            runs into another one: the main stream into the next layer's K|V stream)
 template <int NTT, int NF, int NKS, bool W_IS_A>
 __device__ __forceinline__ void gemm_stage(f32x4 (&acc)[NF][NTT], Ring& ring, const WStream& wa, int posa, const char* ph, const char* pl,
-                                           int rowb, int chunk0, int c16, int q) {
+                                           int rowb, int chunk0, int c16, int q, int na = 1 << 30, const WStream* wb = nullptr, int posb = 0) {
     constexpr int F = 2 * NF;
     constexpr int U = (R / F) >= 2 ? (R / F) : 2;
     constexpr int NMFMA = 3 * NF * NTT;
@@ -130,7 +132,10 @@ __device__ __forceinline__ void gemm_stage(f32x4 (&acc)[NF][NTT], Ring& ring, co
                                          : mma16x3(x[cur].h[tt], x[cur].l[tt], whi, wlo, acc[ft][tt]);
             }
 #pragma unroll
-            for (int f = 0; f < F; ++f) ring.s[(u * F + f) % R] = wa.load(posa + ks * F + f);
+            for (int f = 0; f < F; ++f) {
+                const int idx = ks * F + f;
+                ring.s[(u * F + f) % R] = (idx < na) ? wa.load(posa + idx) : wb->load(posb + idx - na);
+            }
             // issue order: the next k-step's activation reads first (one per MFMA), then the refills one per MFMA
             constexpr int NRD = 2 * NTT, NLD = F;
 #pragma unroll

@@ -116,6 +116,9 @@ class OnePosePlus_model(nn.Module):
             raise ValueError(f"hip_precision {self.precision!r}: expected 'f32', 'bf16x3' or 'bf16'")
         # backbone on the HIP convolution kernels (bf16 pipe modes only; exact-f32 mode keeps MIOpen's fp32 convolutions)
         self.hip_backbone = bool(config.get("hip_backbone", True)) and self.precision != "f32"
+        # the x3 encoder layer with eight waves per workgroup (two per SIMD, csrc/encoder_x3w8.hip: 52 against 56 us per launch at
+        # c2); OPHIP_ENC_W8=0 selects the four-wave form (csrc/encoder_x3.hip)
+        self._enc_w8 = os.environ.get("OPHIP_ENC_W8", "1") != "0"
         self._packed = None          # (key, dict of device weight blocks)
         self._packed_bb = None       # (key, backbone conv blocks)
         # fine stage (+ result read-back) on a second HIP stream: frame t's refinement then overlaps frame t + 1's input
@@ -160,8 +163,8 @@ class OnePosePlus_model(nn.Module):
             blocks["coarse_bf16"] = [packing.pack_coarse_layer_bf16(sd, f"loftr_coarse.layers.{i}.").to(device)
                                      for i in range(len(self.loftr_coarse.layer_names))]
             if self.precision == "bf16x3":
-                blocks["coarse_x3"] = [packing.pack_coarse_layer_x3(sd, f"loftr_coarse.layers.{i}.").to(device)
-                                       for i in range(len(self.loftr_coarse.layer_names))]
+                packer = packing.pack_coarse_layer_x3w8 if self._enc_w8 else packing.pack_coarse_layer_x3
+                blocks["coarse_x3"] = [packer(sd, f"loftr_coarse.layers.{i}.").to(device) for i in range(len(self.loftr_coarse.layer_names))]
             if self.precision == "bf16x3" and os.environ.get("OPHIP_FINE_X3"):
                 blocks["fine_x3"] = packing.pack_fine_layers_x3(sd, "loftr_fine.layers.", len(self.loftr_fine.layer_names)).to(device)
             blocks["fine_bf16"] = packing.pack_fine_layers_bf16(sd, "loftr_fine.layers.", len(self.loftr_fine.layer_names)).to(device)
@@ -329,13 +332,14 @@ class OnePosePlus_model(nn.Module):
                 x3d, y3d, x2d, y2d = y3d, (z3d if li == 0 else x3d), y2d, x2d
         elif self.precision == "bf16x3" and not os.environ.get("OPHIP_ENC_V1"):
             # 16-token tiles, one workgroup per CU, per-wave weight streams (csrc/encoder_x3.hip)
-            ws = torch.empty(hip.load().ophip_encoder_x3_workspace_bytes(B, N, M), device=dev, dtype=torch.uint8)
+            entry = "ophip_encoder_layer_x3w8" if self._enc_w8 else "ophip_encoder_layer_x3"
+            ws = torch.empty(getattr(hip.load(), entry.replace("layer_", "") + "_workspace_bytes")(B, N, M), device=dev, dtype=torch.uint8)
             names_c = self.loftr_coarse.layer_names
             for li, name in enumerate(names_c):
                 nxt = W["coarse_x3"][li + 1] if li + 1 < len(names_c) else None
                 if li == 0:
                     wait_previous_fine()
-                lib_call("ophip_encoder_layer_x3", P(x3d), P(x2d), P(y3d), P(y2d), B, N, M, P(W["coarse_x3"][li], None), P(nxt, None),
+                lib_call(entry, P(x3d), P(x2d), P(y3d), P(y2d), B, N, M, P(W["coarse_x3"][li], None), P(nxt, None),
                          1 if name == "cross" else 0, 1 if li > 0 else 0, li & 1, P(ws, None), S)
                 x3d, y3d, x2d, y2d = y3d, (z3d if li == 0 else x3d), y2d, x2d
         else:

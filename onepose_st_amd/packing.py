@@ -176,6 +176,38 @@ def pack_fine_layers_bf16(sd: dict, prefix: str, n_layers: int) -> torch.Tensor:
     return out
 
 
+def x3w8_program(fw: int):
+    """(main, kv) entries for wave ``fw`` (= head fw) of the 8-wave kernel csrc/encoder_x3w8.hip: each wave owns 32 output features
+    (two tiles) of every stage; the MLP's hidden layer goes in two 256-wide chunks: Q | merge | W0c0 | W2c0 | W0c1 | W2c1."""
+    def gemm(mat, rows, k0, ksteps):
+        return [(mat, r0, k0 + 32 * ks) for ks in range(ksteps) for r0 in rows]
+    rows = [32 * fw + 16 * ft for ft in range(2)]
+    main = gemm("q", rows, 0, 8) + gemm("m", rows, 0, 8)
+    for c in range(2):
+        main += gemm("w0", [256 * c + r0 for r0 in rows], 0, 16) + gemm("w2", rows, 256 * c, 8)
+    kv = [(("k" if ft < 2 else "v"), 32 * fw + 16 * (ft & 1), 32 * ks) for ks in range(8) for ft in range(4)]
+    assert 2 * len(main) == 256 and 2 * len(kv) == 64
+    return main, kv
+
+
+def pack_coarse_layer_x3w8(sd: dict, prefix: str) -> torch.Tensor:
+    """uint8 block ``[main streams: 8 waves x 256 KiB][K|V streams: 8 x 64 KiB][norm1.w norm1.b norm2.w norm2.b f32]`` for
+    ``ophip_encoder_layer_x3w8``."""
+    mats = {"q": sd[prefix + "q_proj.weight"], "k": sd[prefix + "k_proj.weight"], "v": sd[prefix + "v_proj.weight"],
+            "m": sd[prefix + "merge.weight"], "w0": sd[prefix + "mlp.0.weight"], "w2": sd[prefix + "mlp.2.weight"]}
+    mats = {k: v.detach().to(torch.float32).cpu().contiguous() for k, v in mats.items()}
+    if tuple(mats["q"].shape) != (256, 256) or tuple(mats["w0"].shape) != (512, 512) or tuple(mats["w2"].shape) != (256, 512):
+        raise ValueError("coarse encoder kernels are specialised for d_model = 256")
+    progs = [x3w8_program(fw) for fw in range(8)]
+    frags = [x3_frag(mats[m], r0, k0) for sel in (0, 1) for fw in range(8) for (m, r0, k0) in progs[fw][sel]]
+    flat = torch.stack(frags)
+    hi = flat.to(torch.bfloat16)
+    lo = (flat - hi.float()).to(torch.bfloat16)
+    out = _bytes(torch.stack([hi, lo], 1), torch.cat(_ln(sd, prefix)))
+    assert out.numel() == 8 * (256 + 64) * 1024 + 16 * 256
+    return out
+
+
 X3_FINE_LAYER_FRAGS = 160        # per wave and layer, hi and lo counted separately
 
 
