@@ -934,11 +934,13 @@ extern "C" size_t ophip_coarse_workspace_floats(int B, int N, int M) {
     return f + 64;
 }
 
-extern "C" int ophip_coarse_match(const float* feat3d, const float* feat2d, const float* keypoints3d, long long kpts_bstride,
-                                  int B, int N, int M, int wc, double temperature, float thr, int border_rm, float scale,
-                                  float* conf, float* workspace, long long* b_ids, long long* i_ids, long long* j_ids,
-                                  float* mconf, float* mkpts3d, float* mkpts_c, long long* m_bids, unsigned char* gt_mask,
-                                  int* count, int nsplit, void* stream_) {
+namespace {
+// parts: 1 = similarity / confidence kernels, 2 = select (threshold, mutual test, compaction), 3 = both
+int coarse_impl(int parts, const float* feat3d, const float* feat2d, const float* keypoints3d, long long kpts_bstride,
+                int B, int N, int M, int wc, double temperature, float thr, int border_rm, float scale,
+                float* conf, float* workspace, long long* b_ids, long long* i_ids, long long* j_ids,
+                float* mconf, float* mkpts3d, float* mkpts_c, long long* m_bids, unsigned char* gt_mask,
+                int* count, int nsplit, void* stream_) {
     if (!feat3d || !feat2d || !keypoints3d || !conf || !workspace || !b_ids || !i_ids || !j_ids || !mconf || !mkpts3d || !mkpts_c || !count)
         return ophip_bad_arg(__func__, "null pointer");
     if (B < 1 || N < 1 || M < 1 || wc < 1 || M % wc != 0) return ophip_bad_arg(__func__, "bad sizes (need M == hc * wc)");
@@ -962,6 +964,12 @@ extern "C" int ophip_coarse_match(const float* feat3d, const float* feat2d, cons
     const bool two_pass = nsplit != 0 && two_pass_env;
     int sel_nspan = nspan;
     if (two_pass) {
+        float* w2s = colmax + (size_t)B * M;
+        w2s += (16 - ((reinterpret_cast<uintptr_t>(w2s) >> 2) & 15)) & 15;
+        rowbest = reinterpret_cast<float*>(reinterpret_cast<char*>(w2s) + (size_t)B * ((size_t)N + M) * C * 4) + (size_t)B * ntc * N * 3 + (size_t)B * ntr * M;
+        sel_nspan = 1;
+    }
+    if (two_pass && (parts & 1)) {
         // ---- bf16 modes: S recomputed instead of stored (see the kernels above) ------------------------------------------
         float* w2 = colmax + (size_t)B * M;
         w2 += (16 - ((reinterpret_cast<uintptr_t>(w2) >> 2) & 15)) & 15;                 // 64-byte aligned planes
@@ -997,9 +1005,8 @@ extern "C" int ophip_coarse_match(const float* feat3d, const float* feat2d, cons
         BestArgs ba{rowbest_part, colmaxp, rowbest1, colmax, N, M, ntr, ntc};
         OPHIP_LAUNCH("best_combine", stream, best_combine_kernel, dim3((N + M + 255) / 256, B), dim3(256), 0, stream, ba);
         OPHIP_CHECK_LAUNCH();
-        rowbest = rowbest1;
-        sel_nspan = 1;
-    } else {
+        if (rowbest1 != rowbest) return ophip_bad_arg(__func__, "internal: workspace layout");
+    } else if (parts & 1) {
         SimArgs sa{feat3d, feat2d, conf, rowpart, colpart, N, M, ntr, ntc, (float)(temperature + 1e-4), ophip_stamp_buffer()};
         {
             // dynamic LDS = max(operand tiles, S staging image of the epilogue)
@@ -1024,9 +1031,42 @@ extern "C" int ophip_coarse_match(const float* feat3d, const float* feat2d, cons
         else OPHIP_LAUNCH("conf", stream, (conf_kernel<false, false>), dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
         OPHIP_CHECK_LAUNCH();
     }
-    SelectArgs se{conf, rowbest, colmax, keypoints3d, kpts_bstride, B, N, M, sel_nspan, wc, border_rm, thr, scale,
-                  b_ids, i_ids, j_ids, mconf, mkpts3d, mkpts_c, m_bids, gt_mask, count};
-    OPHIP_LAUNCH("select", stream, select_kernel, dim3(1), dim3(1024), 0, stream, se);
-    OPHIP_CHECK_LAUNCH();
+    if (parts & 2) {
+        SelectArgs se{conf, rowbest, colmax, keypoints3d, kpts_bstride, B, N, M, sel_nspan, wc, border_rm, thr, scale,
+                      b_ids, i_ids, j_ids, mconf, mkpts3d, mkpts_c, m_bids, gt_mask, count};
+        OPHIP_LAUNCH("select", stream, select_kernel, dim3(1), dim3(1024), 0, stream, se);
+        OPHIP_CHECK_LAUNCH();
+    }
     return 0;
+}
+}  // namespace
+
+extern "C" int ophip_coarse_match(const float* feat3d, const float* feat2d, const float* keypoints3d, long long kpts_bstride,
+                                  int B, int N, int M, int wc, double temperature, float thr, int border_rm, float scale,
+                                  float* conf, float* workspace, long long* b_ids, long long* i_ids, long long* j_ids,
+                                  float* mconf, float* mkpts3d, float* mkpts_c, long long* m_bids, unsigned char* gt_mask,
+                                  int* count, int nsplit, void* stream) {
+    return coarse_impl(3, feat3d, feat2d, keypoints3d, kpts_bstride, B, N, M, wc, temperature, thr, border_rm, scale, conf, workspace,
+                       b_ids, i_ids, j_ids, mconf, mkpts3d, mkpts_c, m_bids, gt_mask, count, nsplit, stream);
+}
+
+// The same stage in two calls, so that a pipeline can put the single-workgroup select kernel (and what follows it) on another
+// stream than the similarity / confidence kernels: ophip_coarse_match == ophip_coarse_match_conf then ophip_coarse_match_select
+// with identical arguments (the second call only reads conf_matrix and the partials the first left in the workspace).
+extern "C" int ophip_coarse_match_conf(const float* feat3d, const float* feat2d, const float* keypoints3d, long long kpts_bstride,
+                                       int B, int N, int M, int wc, double temperature, float thr, int border_rm, float scale,
+                                       float* conf, float* workspace, long long* b_ids, long long* i_ids, long long* j_ids,
+                                       float* mconf, float* mkpts3d, float* mkpts_c, long long* m_bids, unsigned char* gt_mask,
+                                       int* count, int nsplit, void* stream) {
+    return coarse_impl(1, feat3d, feat2d, keypoints3d, kpts_bstride, B, N, M, wc, temperature, thr, border_rm, scale, conf, workspace,
+                       b_ids, i_ids, j_ids, mconf, mkpts3d, mkpts_c, m_bids, gt_mask, count, nsplit, stream);
+}
+
+extern "C" int ophip_coarse_match_select(const float* feat3d, const float* feat2d, const float* keypoints3d, long long kpts_bstride,
+                                         int B, int N, int M, int wc, double temperature, float thr, int border_rm, float scale,
+                                         float* conf, float* workspace, long long* b_ids, long long* i_ids, long long* j_ids,
+                                         float* mconf, float* mkpts3d, float* mkpts_c, long long* m_bids, unsigned char* gt_mask,
+                                         int* count, int nsplit, void* stream) {
+    return coarse_impl(2, feat3d, feat2d, keypoints3d, kpts_bstride, B, N, M, wc, temperature, thr, border_rm, scale, conf, workspace,
+                       b_ids, i_ids, j_ids, mconf, mkpts3d, mkpts_c, m_bids, gt_mask, count, nsplit, stream);
 }

@@ -43,6 +43,10 @@ _SIGNATURES = {
     "ophip_coarse_workspace_floats": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "ophip_coarse_match": (c_i, [c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_i, ctypes.c_double, ctypes.c_float, c_i, ctypes.c_float,
                                  c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, ctypes.c_void_p]),
+    "ophip_coarse_match_conf": (c_i, [c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_i, ctypes.c_double, ctypes.c_float, c_i, ctypes.c_float,
+                                 c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, ctypes.c_void_p]),
+    "ophip_coarse_match_select": (c_i, [c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_i, ctypes.c_double, ctypes.c_float, c_i, ctypes.c_float,
+                                 c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, ctypes.c_void_p]),
     "ophip_fine_refine": (c_i, [c_f, c_ll, c_ll, c_ll, c_ll, c_i, c_i, c_f, c_ll, c_ll, c_f, c_f, c_f, c_f, c_i,
                                 c_f, c_f, c_i, ctypes.c_uint, c_i, c_i, c_i, ctypes.c_float, c_f, c_f, c_f, c_f, ctypes.c_void_p]),
     "ophip_fine_bf16_wpack_bytes": (ctypes.c_size_t, [c_i]),

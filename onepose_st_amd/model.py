@@ -370,12 +370,16 @@ class OnePosePlus_model(nn.Module):
         mconf = torch.empty(cap, **f32)
         mkc = torch.empty(cap, 2, **f32) if fine_on else mk2d
         scale = data["q_hw_i"][0] / hc
+        cm_args = (P(x3d), P(x2d), P(kpts_d), bstride(kpts_d), B, N, M, wc,
+                   float(cm["dual_softmax"]["temperature"]), float(cm["thr"]), int(cm["border_rm"]), float(scale),
+                   P(conf), P(cws), P(b_ids, torch.int64), P(i_ids, torch.int64), P(j_ids, torch.int64),
+                   P(mconf), P(mk3d), P(mkc), P(m_bids, torch.int64), P(gt_mask, torch.bool), P(count, torch.int32),
+                   {"f32": 0, "bf16": 1, "bf16x3": 3}[self.precision])
+        # the single-workgroup select kernel goes with the fine stage onto the side stream (it only feeds that stage and the
+        # read-back): the next frame's input kernels then run beside it instead of behind it
+        split_select = fine_on and self.overlap_fine
         with self.profiler.record_function("LoFTR/coarse-matching/get_coarse_match"):
-            lib_call("ophip_coarse_match", P(x3d), P(x2d), P(kpts_d), bstride(kpts_d), B, N, M, wc,
-                     float(cm["dual_softmax"]["temperature"]), float(cm["thr"]), int(cm["border_rm"]), float(scale),
-                     P(conf), P(cws), P(b_ids, torch.int64), P(i_ids, torch.int64), P(j_ids, torch.int64),
-                     P(mconf), P(mk3d), P(mkc), P(m_bids, torch.int64), P(gt_mask, torch.bool), P(count, torch.int32),
-                     {"f32": 0, "bf16": 1, "bf16x3": 3}[self.precision], S)
+            lib_call("ophip_coarse_match_conf" if split_select else "ophip_coarse_match", *cm_args, S)
         data["conf_matrix"] = conf
 
         fine_ctx = contextlib.nullcontext()
@@ -390,8 +394,11 @@ class OnePosePlus_model(nn.Module):
             sfine.wait_event(coarse_done)
             fine_ctx = torch.cuda.stream(sfine)
         keep = [desc_fine_d, W]      # inputs of the side-stream kernels stay referenced until finish()
+        keep += [x3d, x2d, cws, conf]
         with fine_ctx:
             S = hip.stream_handle()
+            if split_select:
+                lib_call("ophip_coarse_match_select", *cm_args, S)
             if fine_on:
                 # ---- a9-a11: fine refinement (grid sized by capacity, device-side count: no sync yet) ----
                 cf = cfg["loftr_fine"]
