@@ -85,7 +85,7 @@ void inv3(const double* m, double* o) {
 }
 
 // nearest rotation of a matrix with positive determinant: Newton iteration R <- (R + R^-T) / 2
-bool polar_rotation(double* R) {
+bool polar_rotation(double* R, double tol = 1e-15) {
     for (int it = 0; it < 60; ++it) {
         if (std::fabs(det3(R)) < 1e-14) return false;
         double inv[9];
@@ -97,7 +97,7 @@ bool polar_rotation(double* R) {
                 diff += std::fabs(n - R[i * 3 + j]);
                 R[i * 3 + j] = n;
             }
-        if (diff < 1e-15) break;
+        if (diff < tol) break;
     }
     return true;
 }
@@ -319,7 +319,7 @@ bool dlt_pose(const Problem& P, const int* idx, int m, double* pose) {
     const double s = std::cbrt(d);
     for (double& v : M) v /= s;
     for (double& v : t) v /= s;
-    if (!polar_rotation(M)) return false;
+    if (!polar_rotation(M, 1e-9)) return false;          // a hypothesis only has to score; the kept one is polished below
     // undo the conditioning: X_n = sc (X - mu)  =>  R X_n + t = (sc R) X + (t - sc R mu)
     for (int rI = 0; rI < 3; ++rI) {
         const double tr = t[rI] - sc * (M[rI * 3] * mu[0] + M[rI * 3 + 1] * mu[1] + M[rI * 3 + 2] * mu[2]);
@@ -533,6 +533,12 @@ struct Ransac {
             best_cnt_f = cnt_f; best_cost_f = cost_f;
             // a new best of this chunk by the float score: its exact (double) count, cost and mask decide what is kept
             Candidate c;
+            {                                            // exact rotation before the exact score
+                double Rm[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
+                if (polar_rotation(Rm))
+                    for (int rI = 0; rI < 3; ++rI)
+                        for (int cI = 0; cI < 3; ++cI) pose[rI * 4 + cI] = Rm[rI * 3 + cI];
+            }
             c.cnt = count_inliers(P, pose, thr2, mask.data(), &c.cost);
             if (c.better_than(best)) {
                 std::memcpy(c.pose, pose, sizeof(pose));

@@ -8,16 +8,29 @@ import os
 
 import numpy as np
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libonepose_pnp.so")
+_LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
+_LIB_PATH = os.path.join(_LIB_DIR, "libonepose_pnp.so")
 _lib = None
+
+
+def _cpu_has_avx2_fma() -> bool:
+    try:
+        flags = next(ln for ln in open("/proc/cpuinfo") if ln.startswith("flags")).split()
+        return "avx2" in flags and "fma" in flags
+    except (OSError, StopIteration):
+        return False
 
 
 def load():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            raise RuntimeError(f"{_LIB_PATH} not found: run __graft_entry__.build()")
-        lib = ctypes.CDLL(_LIB_PATH)
+        path = _LIB_PATH
+        fast = os.path.join(_LIB_DIR, "libonepose_pnp_avx2.so")          # same source built with -mavx2 -mfma
+        if path == os.path.join(_LIB_DIR, "libonepose_pnp.so") and os.path.exists(fast) and _cpu_has_avx2_fma():
+            path = fast
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} not found: run __graft_entry__.build()")
+        lib = ctypes.CDLL(path)
         lib.oppnp_ransac.restype = ctypes.c_int
         lib.oppnp_ransac.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_double,
                                      ctypes.c_int, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_void_p,
