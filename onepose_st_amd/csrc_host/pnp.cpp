@@ -450,11 +450,18 @@ void refine_lm(const Problem& P, const unsigned char* mask, double* pose, int it
 
 // ---- RANSAC in chunks of CH trials ------------------------------------------------------------------------------------
 // Trial t belongs to chunk t / CH and every chunk has its own generator, so the floor of min_iters trials (the reference's
-// pycolmap call: 10 000) splits into independent chunks that a pool solves in parallel; merging the chunks' best candidates
-// in chunk order makes the result independent of how many threads took part (and identical to the sequential call).
+// pycolmap call: 10 000) splits into chunks that a pool solves in parallel; merging the chunks' best candidates in chunk order
+// makes the result independent of how many threads took part (and identical to the sequential call).  Chunk 0 runs first and
+// its best float score is the rejection bound every other chunk starts from (a function of the data only), so short chunks --
+// low latency per frame, work for every thread -- still drop most hypotheses after a fraction of the points.
 namespace {
 
-constexpr int CH = 2048;
+constexpr int CH = 256;
+
+struct FloatBound {
+    int cnt = 0;
+    float cost = 3.0e38f;
+};
 
 struct Candidate {
     double pose[12];
@@ -503,11 +510,13 @@ struct Ransac {
 
     // trials [0, limit) of `chunk`; `floor_in_chunk` of them unconditionally, after that while the global trial index is
     // below what the best candidate so far (`best`: carried in, updated) asks for.  Returns the number of trials run.
-    int run_chunk(int chunk, int limit, int floor_in_chunk, Candidate& best) const {
+    // `bound`: float score (count, cost) a hypothesis has to beat to be looked at -- in: chunk 0's best for the other chunks
+    // (fixed by the data, so the result does not depend on scheduling), out: this chunk's best float score
+    int run_chunk(int chunk, int limit, int floor_in_chunk, Candidate& best, FloatBound& bound) const {
         Rng rng(seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(chunk + 1));
         std::vector<unsigned char> mask((size_t)n);
-        int best_cnt_f = 0;
-        float best_cost_f = 3.0e38f;
+        int& best_cnt_f = bound.cnt;
+        float& best_cost_f = bound.cost;
         int needed = best.cnt > 0 ? needed_for(best.cnt) : max_iters;
         int it = 0;
         for (; it < limit && (it < floor_in_chunk || (long long)chunk * CH + it < needed); ++it) {
@@ -551,13 +560,13 @@ struct Ransac {
     }
 
     // chunks after the unconditional ones, one at a time, until the confidence criterion or max_iters stops them
-    void run_tail(Candidate& best, int* iters_run) const {
+    void run_tail(Candidate& best, FloatBound bound, int* iters_run) const {
         int c = full_chunks();
         long long total = (long long)c * CH;
         const int rem = (min_iters < max_iters ? min_iters : max_iters) - c * CH;
         while (total < max_iters) {
             const int limit = (int)((max_iters - total) < CH ? (max_iters - total) : CH);
-            const int ran = run_chunk(c, limit, c == full_chunks() ? rem : 0, best);
+            const int ran = run_chunk(c, limit, c == full_chunks() ? rem : 0, best, bound);
             total += ran;
             if (ran < limit) break;
             ++c;
@@ -600,12 +609,14 @@ extern "C" int oppnp_ransac(const double* K, const float* pts2d, const float* pt
     Ransac R;
     R.setup(K, pts2d, pts3d, n, reproj_err_px, confidence, min_iters, max_iters, seed);
     Candidate best;
+    FloatBound b0;                                        // chunk 0's float best bounds every later chunk
     for (int c = 0; c < R.full_chunks(); ++c) {
         Candidate local;
-        R.run_chunk(c, CH, CH, local);
+        FloatBound b = b0;
+        R.run_chunk(c, CH, CH, local, c == 0 ? b0 : b);
         if (local.better_than(best)) best = std::move(local);
     }
-    R.run_tail(best, iters_run);
+    R.run_tail(best, b0, iters_run);
     return R.finish(best, pose_out, inlier_mask, n_inliers);
 }
 
@@ -622,6 +633,7 @@ struct Job {
     Ransac R;
     long long ticket = 0;
     std::vector<Candidate> chunk_best;      // one per unconditional chunk
+    FloatBound b0;                           // chunk 0's float best: the bound of every other chunk
     int remaining = 0;                       // unconditional chunks not finished yet (guarded by Pool::mu)
 };
 
@@ -646,7 +658,7 @@ struct Pool {
         Candidate best;
         for (auto& c : job.chunk_best)
             if (c.better_than(best)) best = std::move(c);
-        job.R.run_tail(best, nullptr);
+        job.R.run_tail(best, job.b0, nullptr);
         Result r;
         std::memcpy(r.pose, kIdentPose, sizeof(kIdentPose));
         r.n_inliers = 0;
@@ -670,7 +682,22 @@ struct Pool {
             }
             Job& job = *task.first;
             if (task.second < 0) { finish_job(job); continue; }
-            job.R.run_chunk(task.second, CH, CH, job.chunk_best[(size_t)task.second]);
+            if (task.second == 0) {                  // chunk 0 first, alone: its float best then bounds the others, which start now
+                job.R.run_chunk(0, CH, CH, job.chunk_best[0], job.b0);
+                const int nfull = (int)job.chunk_best.size();
+                if (nfull > 1) {
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        --job.remaining;
+                        for (int c = 1; c < nfull; ++c) queue.emplace_back(task.first, c);
+                    }
+                    cv_work.notify_all();
+                    continue;
+                }
+            } else {
+                FloatBound b = job.b0;
+                job.R.run_chunk(task.second, CH, CH, job.chunk_best[(size_t)task.second], b);
+            }
             bool last;
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -712,7 +739,7 @@ extern "C" long long oppnp_pool_submit(void* pool_, const double* K, const float
         std::lock_guard<std::mutex> lk(pool->mu);
         ticket = job->ticket = pool->submitted++;
         if (nfull == 0) pool->queue.emplace_back(job, -1);
-        for (int c = 0; c < nfull; ++c) pool->queue.emplace_back(job, c);
+        else pool->queue.emplace_back(job, 0);            // the other chunks follow chunk 0
     }
     pool->cv_work.notify_all();
     return ticket;
