@@ -679,7 +679,10 @@ struct ConfArgs {
     int N, M, nspan, spanw, nrb;
 };
 
-constexpr int CONF_ROWS = 32;      // rows per workgroup (measured at c2: 16 -> 106 us, 32 -> 90, 48 -> 114, 64 -> 132: fewer, less contended column atomics vs grid fill)
+#ifndef OPHIP_CONF_ROWS
+#define OPHIP_CONF_ROWS 32
+#endif
+constexpr int CONF_ROWS = OPHIP_CONF_ROWS;      // rows per workgroup (measured at c2: 16 -> 106 us, 32 -> 90, 48 -> 114, 64 -> 132: fewer, less contended column atomics vs grid fill)
 constexpr int CONF_RB = 2;         // rows per pipeline stage (two stages in flight)
 constexpr int CONF_U = 3;          // float4 groups per thread per row  => span <= 3072 columns (164 VGPRs, 3 waves per SIMD; 4 -> 212 VGPRs, 2 -> more spans: 87 / 90 / 94 us at c2)
 
@@ -696,6 +699,13 @@ __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
     const float* cst = p.colstat + (size_t)b * p.M * 2;
     const float* rst = p.rowstat + (size_t)b * p.N * 2;
 
+    // the rows' (max, 1 / sum) once, through LDS: a global load inside the row loop is an L2 round trip per row pair
+    __shared__ float rstat_s[CONF_ROWS][2];
+    if (tid < CONF_ROWS) {
+        const int i = min(i0 + tid, p.N - 1);
+        rstat_s[tid][0] = rst[2 * i];
+        rstat_s[tid][1] = 1.0f / rst[2 * i + 1];
+    }
     float cm[CONF_U][4], cinv[CONF_U][4], cbest[CONF_U][4];
 #pragma unroll
     for (int u = 0; u < CONF_U; ++u)
@@ -734,7 +744,7 @@ __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
             const int rr = r0 + q;
             if (rr < nrows) {
                 const int i = i0 + rr;
-                const float rm = rst[2 * i], rinv = 1.0f / rst[2 * i + 1];
+                const float rm = rstat_s[rr][0], rinv = rstat_s[rr][1];
                 float* row = conf + (size_t)i * p.M;
                 float bv = -1.f;
                 int bj = 0x7fffffff, bc = 0;
@@ -776,6 +786,7 @@ __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
         }
     };
     load_batch(0, s[0]);
+    __syncthreads();                                  // rstat_s
     for (int r0 = 0; r0 < nrows; r0 += 2 * CONF_RB) {
         if (r0 + CONF_RB < nrows) load_batch(r0 + CONF_RB, s[1]);
         process_batch(r0, s[0]);

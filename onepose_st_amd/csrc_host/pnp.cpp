@@ -23,6 +23,11 @@
 #include <mutex>
 #include <thread>
 #include <unordered_map>
+#if defined(__linux__)
+#include <sys/resource.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+#endif
 #include <vector>
 
 namespace {
@@ -671,6 +676,10 @@ struct Pool {
         cv_done.notify_all();
     }
     void run() {
+#if defined(__linux__)
+        // background priority: the thread that feeds the GPU must never wait for a core behind a RANSAC chunk
+        (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), 10);
+#endif
         for (;;) {
             std::pair<std::shared_ptr<Job>, int> task;
             {
