@@ -33,6 +33,8 @@ int ophip_device_info(int* cu_count, int* lds_per_block, char* arch, int arch_le
  * device time, and clears the log. */
 int ophip_timing_select(const char* kernel_name);
 int ophip_timing_read(int* launches, double* total_ms);
+/* bracket only every n-th launch of the selected kernel (default 1): an event pair costs ~2-3 us of stream time */
+int ophip_timing_every(int n);
 
 /* Diagnostics only: while a device buffer (32 x uint64 per workgroup of the largest instrumented launch) is set, the
  * fine_refine / attn_apply bf16 kernels record s_memtime at their phase boundaries into it.  NULL switches it off. */
@@ -110,6 +112,20 @@ int ophip_coarse_match(const float* feat3d, const float* feat2d, const float* ke
                        float* conf, float* workspace, long long* b_ids, long long* i_ids, long long* j_ids,
                        float* mconf, float* mkpts3d, float* mkpts_c, long long* m_bids, unsigned char* gt_mask,
                        int* count, int nsplit, void* stream);
+/* The same call in two halves, same arguments: _conf runs everything up to and including the conf_matrix store and the
+ * per-row / per-column best candidates (wide kernels); _select runs the single-workgroup mutual-NN selection that writes the
+ * match lists and *count.  _select only feeds the fine stage and the read-back, so a caller may issue it on the fine
+ * stage's stream (after an event on _conf) and let the next frame's input kernels run beside it. */
+int ophip_coarse_match_conf(const float* feat3d, const float* feat2d, const float* keypoints3d, long long kpts_bstride,
+                            int B, int N, int M, int wc, double temperature, float thr, int border_rm, float scale,
+                            float* conf, float* workspace, long long* b_ids, long long* i_ids, long long* j_ids,
+                            float* mconf, float* mkpts3d, float* mkpts_c, long long* m_bids, unsigned char* gt_mask,
+                            int* count, int nsplit, void* stream);
+int ophip_coarse_match_select(const float* feat3d, const float* feat2d, const float* keypoints3d, long long kpts_bstride,
+                              int B, int N, int M, int wc, double temperature, float thr, int border_rm, float scale,
+                              float* conf, float* workspace, long long* b_ids, long long* i_ids, long long* j_ids,
+                              float* mconf, float* mkpts3d, float* mkpts_c, long long* m_bids, unsigned char* gt_mask,
+                              int* count, int nsplit, void* stream);
 
 /* a9 + a10 + a11 -- FinePreprocess + fine LocalFeatureTransformer (d_model 128) + FineMatching
  * (loftr_module/fine_preprocess.py:32-55, loftr_module/transformer.py:133-171, utils/fine_matching.py:28-110).

@@ -44,10 +44,13 @@ hipEvent_t* g_start = nullptr;
 hipEvent_t* g_stop = nullptr;
 int g_used = 0;
 int g_dev = -1;              // device the events were created on
+int g_every = 1;             // sample: bracket every g_every-th launch of the selected kernel
+int g_seen = 0;
 }
 
 ophip_timed::ophip_timed(const char* name, hipStream_t s) : slot(-1), stream(s) {
     if (g_sel[0] == 0 || strcmp(name, g_sel) != 0 || g_used >= kMaxEvents) return;
+    if (g_seen++ % g_every != 0) return;
     slot = g_used++;
     (void)hipEventRecord(g_start[slot], stream);
 }
@@ -76,6 +79,13 @@ extern "C" int ophip_timing_select(const char* kernel_name) {
     }
     strcpy(g_sel, kernel_name);
     g_used = 0;
+    g_seen = 0;
+    return 0;
+}
+
+extern "C" int ophip_timing_every(int n) {
+    if (n < 1) return ophip_bad_arg(__func__, "n >= 1");
+    g_every = n;
     return 0;
 }
 

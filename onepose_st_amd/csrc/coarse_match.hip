@@ -63,6 +63,54 @@ __device__ __forceinline__ float half_sum(float v) {
 constexpr int SLD = 130;
 constexpr size_t SIM_STAGE_BYTES = (size_t)TM * SLD * sizeof(float);        // 66 560
 
+// row / column (max, sum exp) of the staged tile St (pitch LD floats), masked at the matrix edge.  Lanes (2k, 2k + 1) share row
+// (resp. column) k and take its even / odd elements: 64 independent LDS reads into registers (latency overlapped), then max and
+// sum exp from registers
+template <bool FAST, int LD>
+__device__ __forceinline__ void tile_stats_lds(const SimArgs& p, const float* St, int tid, int i0, int j0, int b) {
+    const int idx = tid >> 1, par = tid & 1;
+    {
+        const int ncol = min(TN, p.M - j0);
+        float v[TN / 2];
+#pragma unroll
+        for (int q = 0; q < TN / 2; ++q) v[q] = (2 * q + par < ncol) ? St[idx * LD + 2 * q + par] : -INFINITY;
+        float m = -INFINITY, e = 0.f;
+#pragma unroll
+        for (int q = 0; q < TN / 2; ++q) m = fmaxf(m, v[q]);
+        if (m != -INFINITY) {
+#pragma unroll
+            for (int q = 0; q < TN / 2; ++q) e += exp_sel<FAST>(v[q] - m);          // exp(-inf) = 0 for the masked tail
+        }
+        const float m2 = __shfl_xor(m, 1, 64), e2 = __shfl_xor(e, 1, 64);
+        float ma = par ? m2 : m, ea = par ? e2 : e, mb = par ? m : m2, eb = par ? e : e2;      // even lane's part first
+        merge_ms(ma, ea, mb, eb);
+        if (par == 0 && i0 + idx < p.N) {
+            float* o = p.rowpart + (((size_t)b * p.ntc + (j0 / TN)) * p.N + i0 + idx) * 2;
+            o[0] = ma; o[1] = ea;
+        }
+    }
+    {
+        const int nrow = min(TM, p.N - i0);
+        float v[TM / 2];
+#pragma unroll
+        for (int q = 0; q < TM / 2; ++q) v[q] = (2 * q + par < nrow) ? St[(2 * q + par) * LD + idx] : -INFINITY;
+        float m = -INFINITY, e = 0.f;
+#pragma unroll
+        for (int q = 0; q < TM / 2; ++q) m = fmaxf(m, v[q]);
+        if (m != -INFINITY) {
+#pragma unroll
+            for (int q = 0; q < TM / 2; ++q) e += exp_sel<FAST>(v[q] - m);
+        }
+        const float m2 = __shfl_xor(m, 1, 64), e2 = __shfl_xor(e, 1, 64);
+        float ma = par ? m2 : m, ea = par ? e2 : e, mb = par ? m : m2, eb = par ? e : e2;
+        merge_ms(ma, ea, mb, eb);
+        if (par == 0 && j0 + idx < p.M) {
+            float* o = p.colpart + (((size_t)b * p.ntr + (i0 / TM)) * p.M + j0 + idx) * 2;
+            o[0] = ma; o[1] = ea;
+        }
+    }
+}
+
 template <bool FAST>
 __device__ __forceinline__ void sim_epilogue(f32x16 (&acc)[2][2], const SimArgs& p, float* St, int tid, int i0, int j0, int b) {
     const int lane = tid & 63, wave = tid >> 6;
@@ -95,49 +143,7 @@ __device__ __forceinline__ void sim_epilogue(f32x16 (&acc)[2][2], const SimArgs&
                 if (gj + e < p.M) conf[(size_t)gi * p.M + gj + e] = src[e];
         }
     }
-    // ---- row / column (max, sum exp).  Lanes (2k, 2k + 1) share row (resp. column) k and take its even / odd
-    // elements: 64 independent LDS reads into registers (latency overlapped), then max and sum exp from registers ----
-    const int idx = tid >> 1, par = tid & 1;
-    {
-        const int ncol = min(TN, p.M - j0);
-        float v[TN / 2];
-#pragma unroll
-        for (int q = 0; q < TN / 2; ++q) v[q] = (2 * q + par < ncol) ? St[idx * SLD + 2 * q + par] : -INFINITY;
-        float m = -INFINITY, e = 0.f;
-#pragma unroll
-        for (int q = 0; q < TN / 2; ++q) m = fmaxf(m, v[q]);
-        if (m != -INFINITY) {
-#pragma unroll
-            for (int q = 0; q < TN / 2; ++q) e += exp_sel<FAST>(v[q] - m);          // exp(-inf) = 0 for the masked tail
-        }
-        const float m2 = __shfl_xor(m, 1, 64), e2 = __shfl_xor(e, 1, 64);
-        float ma = par ? m2 : m, ea = par ? e2 : e, mb = par ? m : m2, eb = par ? e : e2;      // even lane's part first
-        merge_ms(ma, ea, mb, eb);
-        if (par == 0 && i0 + idx < p.N) {
-            float* o = p.rowpart + (((size_t)b * p.ntc + (j0 / TN)) * p.N + i0 + idx) * 2;
-            o[0] = ma; o[1] = ea;
-        }
-    }
-    {
-        const int nrow = min(TM, p.N - i0);
-        float v[TM / 2];
-#pragma unroll
-        for (int q = 0; q < TM / 2; ++q) v[q] = (2 * q + par < nrow) ? St[(2 * q + par) * SLD + idx] : -INFINITY;
-        float m = -INFINITY, e = 0.f;
-#pragma unroll
-        for (int q = 0; q < TM / 2; ++q) m = fmaxf(m, v[q]);
-        if (m != -INFINITY) {
-#pragma unroll
-            for (int q = 0; q < TM / 2; ++q) e += exp_sel<FAST>(v[q] - m);
-        }
-        const float m2 = __shfl_xor(m, 1, 64), e2 = __shfl_xor(e, 1, 64);
-        float ma = par ? m2 : m, ea = par ? e2 : e, mb = par ? m : m2, eb = par ? e : e2;
-        merge_ms(ma, ea, mb, eb);
-        if (par == 0 && j0 + idx < p.M) {
-            float* o = p.colpart + (((size_t)b * p.ntr + (i0 / TM)) * p.M + j0 + idx) * 2;
-            o[0] = ma; o[1] = ea;
-        }
-    }
+    tile_stats_lds<FAST, SLD>(p, St, tid, i0, j0, b);
 }
 
 __global__ __launch_bounds__(256) void sim_stats_kernel(SimArgs p) {
@@ -307,332 +313,547 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_stats_bf16
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Two-pass form of the bf16 modes: S is never stored.  split_planes turns the two encoder outputs into (hi, lo) bf16 planes
-// once (scaled by 1/sqrt(C) = 1/16, exact); pass 1 computes the S tiles and keeps only their row / column (max, sum exp)
-// partials; after stat_combine, pass 2 recomputes each tile on the matrix pipe, turns it into confidences in registers,
-// stores conf_matrix ONCE (whole rows through the LDS image) and leaves per-tile row-best / column-max partials that
-// best_combine merges in a fixed order (no atomics).  HBM traffic of the stage: the N x M f32 write plus the 2 x 12 MB of
-// planes, against write S + read S + write conf before.  Workgroups are dealt to the XCDs in row bands: the blocks that share
-// an XCD (blockIdx % 8) sweep all column tiles of a contiguous range of row tiles, so an XCD's L2 holds its A rows and
-// streams B once.
+// Fragment-plane form of the bf16 modes (default).  frag_planes turns both encoder outputs once into (hi, lo) bf16 planes,
+// scaled by 1/sqrt(C) = 1/16 (exact), laid out as the MFMA operand fragments themselves: for 32-row tile T and k-step s
+// (16 features) the 1 KiB block ((T * 16 + s) * 2 + plane) holds lane l's 8 bf16 (row 32 T + (l & 31), features
+// 16 s + 8 (l >> 5) ..) at byte 16 l; rows are zero-padded to a multiple of 128.  sim_frag then has no conversion work and no
+// register staging in its k-loop: one k-step (16 KiB: 4 + 4 row tiles x 2 planes) arrives by LDS-DMA (global_load_lds_dwordx4,
+// one fragment per wave-instruction, lane-linear image = conflict-free ds_read_b128) into a ring of four buffers, three
+// k-steps ahead of the 12 MFMAs per wave that consume it (counted vmcnt + raw s_barrier, one barrier per k-step).  The old kernel split every A row 38 times and every
+// B row 55 times (once per tile) and spent 3/4 of its time outside the MFMAs (stamps, tools/stamps_sim.py).
+//
+// Epilogue: the scaled tile is staged through LDS and leaves in ONE pass: whole rows to the conf buffer and, on the way, into
+// the (max, sum exp) partials with one exponential per element (tile maximum as the common reference; see the pass).  Tiles cut
+// by the matrix edge, and tiles where a row or column sits > 59 below the tile maximum, take the exact per-row / per-column sweep
+// instead.  Workgroups are dealt to the XCDs in row bands: the blocks that share an XCD (blockIdx % 8) walk a contiguous range
+// of row tiles column-major, so an XCD's L2 keeps its A fragments and streams B once.
 // ---------------------------------------------------------------------------------------------------------------------------
-struct SplitArgs {
-    const float* x;      // [rows][C]
-    char* hi;            // [rows][C] bf16
-    char* lo;
-    long long rows;
+struct FragArgs {
+    const float* x3;     // [B][N][C]
+    const float* x2;     // [B][M][C]
+    char* a;             // [B][Npad / 32][16][2][1024]
+    char* b;             // [B][Mpad / 32][16][2][1024]
+    int N, M, nta, ntb;  // nta = Npad / 32, ntb = Mpad / 32
 };
 
-__global__ __launch_bounds__(256) void split_planes_kernel(SplitArgs p) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;        // one 8-feature chunk per thread
-    if (i >= p.rows * (C / 8)) return;
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(p.x + i * 8);
-    const f32x4 v1 = *reinterpret_cast<const f32x4*>(p.x + i * 8 + 4);
-    bf16x8 vh, vl;
+__global__ __launch_bounds__(256) void frag_planes_kernel(FragArgs p) {
+    const int b = blockIdx.y, tid = threadIdx.x;
+    int T = blockIdx.x;
+    const bool is_a = T < p.nta;
+    if (!is_a) T -= p.nta;
+    const int rows = is_a ? p.N : p.M;
+    const float* x = (is_a ? p.x3 : p.x2) + (size_t)b * rows * C;
+    char* dst = (is_a ? p.a + (size_t)b * p.nta * 32768 : p.b + (size_t)b * p.ntb * 32768) + (size_t)T * 32768;
+    const int r = tid >> 3, kseg = tid & 7, row = 32 * T + r;       // a thread owns 32 consecutive features of one row
+    f32x4 v[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        __bf16 hh, ll;
-        split_bf16(v0[j] * 0.0625f, hh, ll); vh[j] = hh; vl[j] = ll;          // feat / sqrt(C): exact power of two
-        split_bf16(v1[j] * 0.0625f, hh, ll); vh[4 + j] = hh; vl[4 + j] = ll;
+    for (int g = 0; g < 8; ++g) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        v[g] = row < rows ? *reinterpret_cast<const f32x4*>(x + (size_t)row * C + 32 * kseg + 4 * g) : z;
     }
-    *reinterpret_cast<bf16x8*>(p.hi + i * 16) = vh;
-    *reinterpret_cast<bf16x8*>(p.lo + i * 16) = vl;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {                                   // features 32 kseg + 8 g ..: k-step 2 kseg + g / 2, half g % 2
+        bf16x8 vh, vl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            __bf16 hh, ll;
+            split_bf16(v[2 * g + (j >> 2)][j & 3] * 0.0625f, hh, ll);
+            vh[j] = hh; vl[j] = ll;
+        }
+        const int s = 2 * kseg + (g >> 1), lane = r + 32 * (g & 1);
+        *reinterpret_cast<bf16x8*>(dst + (size_t)(2 * s) * 1024 + 16 * lane) = vh;
+        *reinterpret_cast<bf16x8*>(dst + (size_t)(2 * s + 1) * 1024 + 16 * lane) = vl;
+    }
 }
 
-struct Sim2Args {
-    const char *a_hi, *a_lo;     // [B][N][C] bf16 planes
-    const char *b_hi, *b_lo;     // [B][M][C]
-    float* conf;                 // [B][N][M]                         (pass 2)
-    float* rowpart;              // [B][ntc][N][2] (max, sum exp)      (pass 1)
+struct SimFragArgs {
+    const char* a;               // fragment planes of feat3d / 16 (see frag_planes_kernel)
+    const char* b;               // fragment planes of feat2d / 16
+    float* conf;                 // [B][N][M]
+    float* rowpart;              // [B][ntc][N][2] (max, sum exp)
     float* colpart;              // [B][ntr][M][2]
-    const float* rowstat;        // [B][N][2] merged                   (pass 2)
-    const float* colstat;        // [B][M][2]
-    float* rowbest;              // [B][ntc][N][3] (value, j bits, tie count bits)   (pass 2)
-    float* colmaxp;              // [B][ntr][M]                                      (pass 2)
-    int N, M, ntr, ntc, per_xcd; // per_xcd: blocks per XCD label (grid.x = 8 * per_xcd)
+    int N, M, ntr, ntc;
     float temp;
+    unsigned long long* stamps;
 };
 
 // XCD-aware tile of this block: label x = blockIdx.x % 8 owns row tiles [r0, r1) (sizes differ by at most one) and walks
 // them column-major (consecutive blocks of an XCD share the B tile, the whole range shares the A rows); false: no tile
-__device__ __forceinline__ bool xcd_tile(const Sim2Args& p, int& ti, int& tj) {
+__device__ __forceinline__ bool xcd_tile(int ntr, int ntc, int& ti, int& tj) {
     const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
-    const int q = p.ntr / 8, rem = p.ntr % 8;
+    const int q = ntr / 8, rem = ntr % 8;
     const int r0 = x * q + (x < rem ? x : rem), nr = q + (x < rem ? 1 : 0);
-    if (nr == 0 || k >= nr * p.ntc) return false;
+    if (nr == 0 || k >= nr * ntc) return false;
     tj = k / nr;
     ti = r0 + k % nr;
     return true;
 }
 
-// S tile (128 x 128, f32 accumulators) from the planes: K chunks of 64 staged through padded LDS rows (144 B: conflict-free
-// ds_read_b128), next chunk prefetched into registers under the MFMAs.  The accumulators hold a.b / 256 (planes are pre-scaled).
+// vector-ALU cross-lane moves (DPP / permlane swaps: no LDS crossbar round trip)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// over the 32 lanes that share lane >> 5, result in all of them: xor 1, 2 (quad permutes), 4 (half mirror of uniform quads),
+// 8 (mirror of uniform halves), 16 (v_permlane16_swap)
+__device__ __forceinline__ float half_sum_dpp(float v) {
+    v += dpp_f<0xB1>(v);
+    v += dpp_f<0x4E>(v);
+    v += dpp_f<0x141>(v);
+    v += dpp_f<0x140>(v);
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const unsigned a0 = a[0], a1 = a[1];
+    return __builtin_bit_cast(float, a0) + __builtin_bit_cast(float, a1);
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    unsigned u = __builtin_bit_cast(unsigned, v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const unsigned a0 = a[0], a1 = a[1];
+    v = fmaxf(__builtin_bit_cast(float, a0), __builtin_bit_cast(float, a1));
+    u = __builtin_bit_cast(unsigned, v);
+    auto c = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned c0 = c[0], c1 = c[1];
+    return fmaxf(__builtin_bit_cast(float, c0), __builtin_bit_cast(float, c1));
+}
+__device__ __forceinline__ float swap32_sum(float v) {              // v(lane) + v(lane ^ 32)
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto c = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned c0 = c[0], c1 = c[1];
+    return __builtin_bit_cast(float, c0) + __builtin_bit_cast(float, c1);
+}
+
+constexpr int FLD = 132;                                             // S staging pitch of sim_frag: rows stay 16-byte aligned
+constexpr int FRAG_CHUNK_BYTES = 16384;                              // one k-step: 16 fragments, A 8 KiB, B 8 KiB; four buffers
+constexpr size_t SIM_FRAG_STAGE = (size_t)TM * FLD * sizeof(float);  // 67 584
+constexpr size_t SIM_FRAG_LDS = SIM_FRAG_STAGE + 4 * 128 * sizeof(float) + 64;
+
 template <int NS>
-__device__ __forceinline__ void sim_tile_from_planes(f32x16 (&acc)[2][2], const Sim2Args& p, char* smem, int i0, int j0, int b, int tid) {
-    constexpr int PL = NS == 3 ? 2 : 1;
-    constexpr int PB = TM * SPITCH;
-    char* AH = smem;
-    char* AL = smem + (PL - 1) * PB;
-    char* BH = smem + PL * PB;
-    char* BL = BH + (PL - 1) * PB;
-    const int lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_frag_kernel(SimFragArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int ti, tj;
+    if (!xcd_tile(p.ntr, p.ntc, ti, tj)) return;
+#ifdef SIM_STAGGER
+    if ((((blockIdx.x >> 3) >> SIM_STAGGER_BIT) & 1) && (blockIdx.x >> 3) < 64 && blockIdx.y == 0) {
+        for (int i = 0; i < SIM_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
-    const size_t arow = (size_t)b * p.N, brow = (size_t)b * p.M;
-    bf16x8 ra[4][PL], rb[4][PL];
-    auto prefetch = [&](int kc) {
+    const int i0 = ti * TM, j0 = tj * TN;
+    const int nta = 4 * p.ntr, ntb = 4 * p.ntc;
+    // this wave's DMA sources: row tile `wave` of the A tile and of the B tile (4 KiB per chunk each, contiguous)
+    const char* ga = p.a + ((size_t)b * nta + 4 * ti + wave) * 32768 + 16 * lane;
+    const char* gb = p.b + ((size_t)b * ntb + 4 * tj + wave) * 32768 + 16 * lane;
+    // one chunk = one k-step (16 features): this wave's A and B row tiles, (hi, lo) fragments: 4 DMAs of 1 KiB
+    auto issue = [&](int s, int buf) {
+        char* la = smem + buf * FRAG_CHUNK_BYTES + wave * 2048;
+        char* lb = la + 8192;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = tid + 256 * u, row = idx >> 3, c8 = idx & 7;
-            const bool va = i0 + row < p.N, vb = j0 + row < p.M;
-            const size_t oa = ((arow + i0 + row) * C + kc * SKC + 8 * c8) * 2, ob = ((brow + j0 + row) * C + kc * SKC + 8 * c8) * 2;
-            ra[u][0] = va ? *reinterpret_cast<const bf16x8*>(p.a_hi + oa) : zero_bf8();
-            rb[u][0] = vb ? *reinterpret_cast<const bf16x8*>(p.b_hi + ob) : zero_bf8();
-            if (NS == 3) {
-                ra[u][PL - 1] = va ? *reinterpret_cast<const bf16x8*>(p.a_lo + oa) : zero_bf8();
-                rb[u][PL - 1] = vb ? *reinterpret_cast<const bf16x8*>(p.b_lo + ob) : zero_bf8();
-            }
+        for (int f = 0; f < 2; ++f) {
+            if (NS == 1 && f) continue;                              // bf16 mode: hi planes only
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + (size_t)(2 * s + f) * 1024),
+                                             (__attribute__((address_space(3))) void*)(la + f * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + (size_t)(2 * s + f) * 1024),
+                                             (__attribute__((address_space(3))) void*)(lb + f * 1024), 16, 0, 0);
         }
     };
-    auto stage = [&]() {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = tid + 256 * u, row = idx >> 3, c8 = idx & 7;
-            const int off = row * SPITCH + 16 * c8;
-            *reinterpret_cast<bf16x8*>(AH + off) = ra[u][0];
-            *reinterpret_cast<bf16x8*>(BH + off) = rb[u][0];
-            if (NS == 3) {
-                *reinterpret_cast<bf16x8*>(AL + off) = ra[u][PL - 1];
-                *reinterpret_cast<bf16x8*>(BL + off) = rb[u][PL - 1];
-            }
-        }
-    };
+    f32x16 acc[2][2];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y) acc[x][y] = zero16();
-    prefetch(0);
-    stage();
-    __syncthreads();
-    constexpr int NKC = C / SKC;
-    for (int kc = 0; kc < NKC; ++kc) {
-        if (kc + 1 < NKC) prefetch(kc + 1);
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    OPHIP_STAMP(p.stamps, wg, 0);
+    constexpr int NKS = C / 16, G = NS == 3 ? 4 : 2;                 // k-steps; DMAs per chunk and wave
+    issue(0, 0);
+    issue(1, 1);
+    issue(2, 2);
 #pragma unroll
-        for (int kb = 0; kb < SKC / 16; ++kb) {
-            bf16x8 fah[2], fal[2], fbh[2], fbl[2];
+    for (int s = 0; s < NKS; ++s) {
+        // chunk s has landed for this wave (the DMAs of the chunks behind it may stay in flight: counted wait), then for all
+        // waves (barrier); every wave is also done reading buffer (s + 3) % 4 = chunk s - 1's (lgkmcnt(0): its reads have
+        // returned).  Wait and barrier are ONE asm statement with a memory clobber: the s_barrier builtin alone is no memory
+        // barrier to the compiler, which then moves LDS reads / DMA issues across it (seen: rare wrong tiles)
+        if (s + 2 < NKS) { if (G == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+        else if (s + 1 < NKS) { if (G == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (s + 3 < NKS) issue(s + 3, (s + 3) & 3);
+        const char* base = smem + (s & 3) * FRAG_CHUNK_BYTES + 16 * lane;
+        bf16x8 fah[2], fal[2], fbh[2], fbl[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int oa = (64 * wr + 32 * t + r) * SPITCH + 16 * (2 * kb + h);
-                const int ob = (64 * wc + 32 * t + r) * SPITCH + 16 * (2 * kb + h);
-                fah[t] = *reinterpret_cast<const bf16x8*>(AH + oa);
-                fbh[t] = *reinterpret_cast<const bf16x8*>(BH + ob);
-                fal[t] = (NS == 3) ? *reinterpret_cast<const bf16x8*>(AL + oa) : zero_bf8();
-                fbl[t] = (NS == 3) ? *reinterpret_cast<const bf16x8*>(BL + ob) : zero_bf8();
-            }
-#pragma unroll
-            for (int x = 0; x < 2; ++x)
-#pragma unroll
-                for (int y = 0; y < 2; ++y) acc[x][y] = mma_bf16<NS>(fah[x], fal[x], fbh[y], fbl[y], acc[x][y]);
+        for (int t = 0; t < 2; ++t) {
+            const char* pa = base + (2 * wr + t) * 2048;
+            const char* pb = base + 8192 + (2 * wc + t) * 2048;
+            fah[t] = *reinterpret_cast<const bf16x8*>(pa);
+            fbh[t] = *reinterpret_cast<const bf16x8*>(pb);
+            fal[t] = (NS == 3) ? *reinterpret_cast<const bf16x8*>(pa + 1024) : zero_bf8();
+            fbl[t] = (NS == 3) ? *reinterpret_cast<const bf16x8*>(pb + 1024) : zero_bf8();
         }
-        __syncthreads();
-        if (kc + 1 < NKC) {
-            stage();
-            __syncthreads();
-        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) acc[x][y] = mma_bf16<NS>(fah[x], fal[x], fbh[y], fbl[y], acc[x][y]);
     }
-}
+    OPHIP_STAMP(p.stamps, wg, 1);
 
-// pass 1: row / column (max, sum exp) partials of the tile; S is not stored
-template <int NS>
-__global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_pass1_kernel(Sim2Args p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int ti, tj;
-    if (!xcd_tile(p, ti, tj)) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
-    const int i0 = ti * TM, j0 = tj * TN, b = blockIdx.y;
-    f32x16 acc[2][2];
-    sim_tile_from_planes<NS>(acc, p, smem, i0, j0, b, tid);
+    // ---- epilogue ---------------------------------------------------------------------------------------------------------
     float* St = reinterpret_cast<float*>(smem);
+    float* csw = reinterpret_cast<float*>(smem + SIM_FRAG_STAGE);      // [4 (wave)][128] column sums over each wave's 32 rows
+    float* wmx = csw + 512;                                            // [4] maximum of each wave's quarter
+    int* slow = reinterpret_cast<int*>(wmx + 4);                       // [4] per-wave "needs the exact sweep" flags
     const float inv_temp = 1.0f / p.temp;
+    const bool edge = (i0 + TM > p.N) || (j0 + TN > p.M);
+    __syncthreads();                                  // every wave is done reading the operand buffers that St overlays
+    float vmax = -INFINITY;
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg)
-                St[(64 * wr + 32 * x + acc_row(reg, h)) * SLD + 64 * wc + 32 * y + r] = acc[x][y][reg] * inv_temp;
+            for (int reg = 0; reg < 16; ++reg) {
+                const float sv = acc[x][y][reg] * inv_temp;
+                St[(64 * wr + 32 * x + acc_row(reg, h)) * FLD + 64 * wc + 32 * y + r] = sv;
+                vmax = fmaxf(vmax, sv);
+            }
+    const float mw = wave_max_dpp(vmax);
+    if (lane == 0) { wmx[wave] = mw; slow[wave] = 0; }
     __syncthreads();
-    const int idx = tid >> 1, par = tid & 1;
+    OPHIP_STAMP(p.stamps, wg, 2);
+    // One pass over the staged tile: whole rows go to the conf buffer (16 bytes per lane) and, on the way, into the statistics
+    // with ONE exponential per element -- the tile maximum m is the reference of every row and column (any reference >= the true
+    // maximum is a valid (max, sum) partial; stat_combine merges references).  A thread owns 4 columns (c4) and 16 rows
+    // (tid / 32 + 8 it): column sums accumulate in registers, a row's sum is a 32-lane DPP reduction.
+    const float m = fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3]));
+    const bool fast = !edge && (m - m == 0.f);                         // finite reference
+    const int c4 = tid & 31, rg = tid >> 5;
+    float colacc[4] = {0.f, 0.f, 0.f, 0.f};
+    float mine = 1.f;
     {
-        const int ncol = min(TN, p.M - j0);
-        float v[TN / 2];
+        float* conf = p.conf + (size_t)b * p.N * p.M;
+        const bool vec = (p.M & 3) == 0;
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int row = rg + 8 * it;
+            const int gi = i0 + row, gj = j0 + 4 * c4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(St + row * FLD + 4 * c4);
+#ifdef SIM_NO_STORE
+            if (gi < p.N && gj < p.M && v[0] == 123.456f) {
+#else
+            if (gi < p.N && gj < p.M) {
+#endif
+                if (vec) {
+                    *reinterpret_cast<f32x4*>(conf + (size_t)gi * p.M + gj) = v;
+                } else {
 #pragma unroll
-        for (int q = 0; q < TN / 2; ++q) v[q] = (2 * q + par < ncol) ? St[idx * SLD + 2 * q + par] : -INFINITY;
-        float m = -INFINITY, e = 0.f;
-#pragma unroll
-        for (int q = 0; q < TN / 2; ++q) m = fmaxf(m, v[q]);
-        if (m != -INFINITY) {
-#pragma unroll
-            for (int q = 0; q < TN / 2; ++q) e += __expf(v[q] - m);
-        }
-        const float m2 = __shfl_xor(m, 1, 64), e2 = __shfl_xor(e, 1, 64);
-        float ma = par ? m2 : m, ea = par ? e2 : e, mb = par ? m : m2, eb = par ? e : e2;      // even lane's part first
-        merge_ms(ma, ea, mb, eb);
-        if (par == 0 && i0 + idx < p.N) {
-            float* o = p.rowpart + (((size_t)b * p.ntc + tj) * p.N + i0 + idx) * 2;
-            o[0] = ma; o[1] = ea;
+                    for (int e = 0; e < 4; ++e)
+                        if (gj + e < p.M) conf[(size_t)gi * p.M + gj + e] = v[e];
+                }
+            }
+#ifdef SIM_NO_EXP
+            if (fast && it > 100) {
+#else
+            if (fast) {
+#endif
+                const float e0 = __expf(v[0] - m), e1 = __expf(v[1] - m), e2 = __expf(v[2] - m), e3 = __expf(v[3] - m);
+                colacc[0] += e0; colacc[1] += e1; colacc[2] += e2; colacc[3] += e3;
+                const float rs = half_sum_dpp((e0 + e1) + (e2 + e3));
+                mine = (c4 == it) ? rs : mine;                         // lane c4 < 16 keeps the sum of row rg + 8 c4
+            }
         }
     }
-    {
-        const int nrow = min(TM, p.N - i0);
-        float v[TM / 2];
-#pragma unroll
-        for (int q = 0; q < TM / 2; ++q) v[q] = (2 * q + par < nrow) ? St[(2 * q + par) * SLD + idx] : -INFINITY;
-        float m = -INFINITY, e = 0.f;
-#pragma unroll
-        for (int q = 0; q < TM / 2; ++q) m = fmaxf(m, v[q]);
-        if (m != -INFINITY) {
-#pragma unroll
-            for (int q = 0; q < TM / 2; ++q) e += __expf(v[q] - m);
-        }
-        const float m2 = __shfl_xor(m, 1, 64), e2 = __shfl_xor(e, 1, 64);
-        float ma = par ? m2 : m, ea = par ? e2 : e, mb = par ? m : m2, eb = par ? e : e2;
-        merge_ms(ma, ea, mb, eb);
-        if (par == 0 && j0 + idx < p.M) {
-            float* o = p.colpart + (((size_t)b * p.ntr + ti) * p.M + j0 + idx) * 2;
-            o[0] = ma; o[1] = ea;
-        }
+    OPHIP_STAMP(p.stamps, wg, 3);
+    // a sum below 1e-26 means every term sits > 59 below the reference (a row whose own maximum is that far under the tile's):
+    // its partial would lose bits against f32's range, so the workgroup takes the exact per-row / per-column sweep instead
+    constexpr float TINY = 1e-26f;
+    if (fast) {
+        const f32x4 cs = {swap32_sum(colacc[0]), swap32_sum(colacc[1]), swap32_sum(colacc[2]), swap32_sum(colacc[3])};
+        if (lane < 32) *reinterpret_cast<f32x4*>(csw + wave * 128 + 4 * c4) = cs;
+        if (!__all(mine >= TINY) && lane == 0) slow[wave] = 1;
     }
+    __syncthreads();
+    float ctot = 1.f;
+    if (fast && tid < 128) {
+        ctot = (csw[tid] + csw[128 + tid]) + (csw[256 + tid] + csw[384 + tid]);
+        if (!(ctot >= TINY)) slow[0] = 1;
+    }
+    __syncthreads();
+    if (fast && (slow[0] | slow[1] | slow[2] | slow[3]) == 0) {
+        if (c4 < 16) {
+            float* o = p.rowpart + (((size_t)b * p.ntc + tj) * p.N + i0 + rg + 8 * c4) * 2;
+            o[0] = m; o[1] = mine;
+        }
+        if (tid < 128) {
+            float* o = p.colpart + (((size_t)b * p.ntr + ti) * p.M + j0 + tid) * 2;
+            o[0] = m; o[1] = ctot;
+        }
+    } else {
+        SimArgs q{nullptr, nullptr, p.conf, p.rowpart, p.colpart, p.N, p.M, p.ntr, p.ntc, p.temp, nullptr};
+        tile_stats_lds<true, FLD>(q, St, tid, i0, j0, b);
+    }
+    OPHIP_STAMP(p.stamps, wg, 4);
 }
 
-// pass 2: the tile again -> conf = softmax over i x softmax over j from the merged statistics (one exponential per element:
-// exp((S - cm_j) + (S - rm_i)) / (csum_j rsum_i)), stored once; row best (value, lowest j, ties) and column maximum of the tile
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Role-split persistent form of sim_frag (default): one 512-thread workgroup per CU walks its XCD band's tiles.  Waves 0-3
+// ("matrix waves") run the k-loop of tile n exactly as sim_frag does (LDS-DMA ring, 12 MFMAs per k-step each); waves 4-7
+// ("store waves") meanwhile take tile n - 1 out of the staging image, one 8-row block per k-step: whole rows to the conf
+// buffer and into the (max, sum exp) partials.  All eight waves meet at the k-step barrier, so the HBM write stream and the
+// exponentials of a tile run under the MFMAs of the next one instead of in front of them (in sim_frag both co-resident
+// workgroups run in lockstep: k-loops together, then store bursts together, the matrix pipe idle half of the time), and the
+// ring runs across tile seams (the first three k-steps of tile n + 1 are in flight while tile n is handed over).
+// Per seam: barrier E (store waves are done with the image) -> column totals + range flags -> barrier F -> partials out (or the
+// exact sweep + barrier S) while the matrix waves write the next image -> barrier G.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int WS_RING = 4 * FRAG_CHUNK_BYTES;                                          // 65 536
+constexpr size_t SIM_WS_LDS = WS_RING + SIM_FRAG_STAGE + 4 * 128 * sizeof(float) + 64;  // 135 232
+
+__device__ __forceinline__ void ws_tile(int ntr, int ntc, int k, int& ti, int& tj) {    // k-th tile of this block's XCD band
+    const int x = blockIdx.x & 7;
+    const int q = ntr / 8, rem = ntr % 8;
+    const int r0 = x * q + (x < rem ? x : rem), nr = q + (x < rem ? 1 : 0);
+    tj = k / nr;
+    ti = r0 + k % nr;
+}
+
 template <int NS>
-__global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_pass2_kernel(Sim2Args p) {
+__global__ __launch_bounds__(512) void sim_ws_kernel(SimFragArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ float rstat[TM][2];       // (max, 1 / sum) of the tile's rows
-    int ti, tj;
-    if (!xcd_tile(p, ti, tj)) return;
+    float* St = reinterpret_cast<float*>(smem + WS_RING);
+    float* csw = reinterpret_cast<float*>(smem + WS_RING + SIM_FRAG_STAGE);   // [4][128] column sums over each store wave's rows
+    float* wmx = csw + 512;                                                    // [4] maximum of each matrix wave's quarter
+    int* slow = reinterpret_cast<int*>(wmx + 4);                               // [4] "needs the exact sweep" flags
+    const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
-    const int i0 = ti * TM, j0 = tj * TN, b = blockIdx.y;
-    if (tid < TM) {
-        const int i = i0 + tid;
-        const float* q = p.rowstat + ((size_t)b * p.N + min(i, p.N - 1)) * 2;
-        rstat[tid][0] = q[0];
-        rstat[tid][1] = 1.0f / q[1];
+    const bool matrix = wave < 4;
+    const int w4 = wave & 3;
+    const int r = lane & 31, h = lane >> 5, wr = w4 >> 1, wc = w4 & 1;
+    // this block's tiles: slot, slot + nslots, ... of the band's nr x ntc tiles
+    int ntl;
+    const int slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    {
+        const int x = blockIdx.x & 7, q = p.ntr / 8, rem = p.ntr % 8;
+        const int band = (q + (x < rem ? 1 : 0)) * p.ntc;
+        ntl = slot < band ? (band - slot + nslots - 1) / nslots : 0;
     }
-    // this lane's two columns: (max, 1 / sum)
-    float cm[2], cinv[2];
+    if (ntl == 0) return;
+    const int nta = 4 * p.ntr, ntb = 4 * p.ntc;
+    constexpr int G = NS == 3 ? 4 : 2;                               // DMAs per k-step and matrix wave
+    const int total = 16 * ntl;                                      // k-steps of this block
+
+    // DMA sources of the tile the ring is currently filling from (matrix wave w4: row tile w4 of the A and of the B tile)
+    const char *ga = nullptr, *gb = nullptr;
+    auto src_of = [&](int n) {
+        int ti, tj;
+        ws_tile(p.ntr, p.ntc, slot + n * nslots, ti, tj);
+        ga = p.a + ((size_t)b * nta + 4 * ti + w4) * 32768 + 16 * lane;
+        gb = p.b + ((size_t)b * ntb + 4 * tj + w4) * 32768 + 16 * lane;
+    };
+    auto issue = [&](int g) {                                        // k-step g (global index): into buffer g & 3
+        const int s = g & 15;
+        if (s == 0) src_of(g >> 4);
+        char* la = smem + (g & 3) * FRAG_CHUNK_BYTES + w4 * 2048;
+        char* lb = la + 8192;
 #pragma unroll
-    for (int y = 0; y < 2; ++y) {
-        const int j = min(j0 + 64 * wc + 32 * y + r, p.M - 1);
-        const float* q = p.colstat + ((size_t)b * p.M + j) * 2;
-        cm[y] = q[0];
-        cinv[y] = 1.0f / q[1];
-    }
+        for (int f = 0; f < 2; ++f) {
+            if (NS == 1 && f) continue;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + (size_t)(2 * s + f) * 1024),
+                                             (__attribute__((address_space(3))) void*)(la + f * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + (size_t)(2 * s + f) * 1024),
+                                             (__attribute__((address_space(3))) void*)(lb + f * 1024), 16, 0, 0);
+        }
+    };
     f32x16 acc[2][2];
-    sim_tile_from_planes<NS>(acc, p, smem, i0, j0, b, tid);           // (its barriers also publish rstat)
-    float* St = reinterpret_cast<float*>(smem);
-    const float inv_temp = 1.0f / p.temp;
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int row = 64 * wr + 32 * x + acc_row(reg, h);
-            const float rm = rstat[row][0], rinv = rstat[row][1];
+        for (int y = 0; y < 2; ++y) acc[x][y] = zero16();
+    if (tid < 4) slow[tid] = 0;
+    // matrix waves: fragments of k-step g are read from the ring during step g - 1 (two register sets), so a step's 12 MFMAs
+    // start right behind its barrier; the DMAs run three steps ahead of the MFMAs, two ahead of the reads
+    bf16x8 fa[2][2][2], fb[2][2][2];                                 // [set][row / column sub-tile][plane]
+    auto read_frags = [&](int g, int set) {
+        const char* base = smem + (g & 3) * FRAG_CHUNK_BYTES + 16 * lane;
 #pragma unroll
-            for (int y = 0; y < 2; ++y) {
-                const float sv = acc[x][y][reg] * inv_temp;
-                St[row * SLD + 64 * wc + 32 * y + r] = __expf((sv - cm[y]) + (sv - rm)) * (cinv[y] * rinv);
+        for (int t = 0; t < 2; ++t) {
+            const char* pa = base + (2 * wr + t) * 2048;
+            const char* pb = base + 8192 + (2 * wc + t) * 2048;
+            fa[set][t][0] = *reinterpret_cast<const bf16x8*>(pa);
+            fb[set][t][0] = *reinterpret_cast<const bf16x8*>(pb);
+            if (NS == 3) {
+                fa[set][t][1] = *reinterpret_cast<const bf16x8*>(pa + 1024);
+                fb[set][t][1] = *reinterpret_cast<const bf16x8*>(pb + 1024);
             }
         }
-    __syncthreads();
-    // ---- conf_matrix rows, coalesced ---------------------------------------------------------------------------
+    };
+    if (matrix) {
+        issue(0); issue(1); issue(2);
+        if (total > 2) { if (G == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");         // k-step 0 has landed for every matrix wave
+    if (matrix) read_frags(0, 0);
+
+    // store-wave state of the tile being taken out
+    const int st = tid - 256, c4 = st & 31, rg = st >> 5;
+    float colacc[4] = {0.f, 0.f, 0.f, 0.f};
+    float mine = 1.f, m = 0.f;
+    bool fast = false;
+    int pi0 = 0, pj0 = 0, pti = 0, ptj = 0;
+    const float inv_temp = 1.0f / p.temp;
     float* conf = p.conf + (size_t)b * p.N * p.M;
     const bool vec = (p.M & 3) == 0;
-#pragma unroll 4
-    for (int i = tid; i < TM * (TN / 4); i += 256) {
-        const int row = i / (TN / 4), c4 = i % (TN / 4);
-        const int gi = i0 + row, gj = j0 + 4 * c4;
-        if (gi >= p.N || gj >= p.M) continue;
-        const float* src = St + row * SLD + 4 * c4;
-        if (vec) {
-            f32x4 v = {src[0], src[1], src[2], src[3]};
-            *reinterpret_cast<f32x4*>(conf + (size_t)gi * p.M + gj) = v;
-        } else {
+
+#pragma unroll 1
+    for (int n = 0; n <= ntl; ++n) {
+        const int wgid = blockIdx.y * gridDim.x + blockIdx.x;
+        if (n < 7) OPHIP_STAMP(p.stamps, wgid, 4 * n);
+#pragma unroll 1
+        for (int sg = 0; sg < 4; ++sg) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (gj + e < p.M) conf[(size_t)gi * p.M + gj + e] = src[e];
-        }
-    }
-    // ---- row best / column maximum of the tile: lanes (2k, 2k + 1) share row (column) k, even / odd elements ----------
-    const int idx = tid >> 1, par = tid & 1;
-    {
-        const int ncol = min(TN, p.M - j0);
-        float bv = -1.f;
-        int bj = 0x7fffffff, bc = 0;
-#pragma unroll 16
-        for (int q = 0; q < TN / 2; ++q) {
-            const int jj = 2 * q + par;
-            if (jj < ncol) {
-                const float c = St[idx * SLD + jj];
-                if (c > bv) { bv = c; bj = j0 + jj; bc = 1; }
-                else if (c == bv) { bc += 1; }                 // ascending sweep: bj already holds the lowest j
+        for (int u = 0; u < 4; ++u) {
+            const int s = 4 * sg + u;
+            if (matrix) {
+                const int g = 16 * n + s;
+                // k-step g + 1 has landed for this wave (counted wait: the DMAs of step g + 2 stay in flight), then for all waves
+                // (barrier); every wave is also done reading buffer (g + 3) & 3 (step g - 1's fragments were read during step g - 2).
+                // ONE asm statement: see sim_frag_kernel
+                if (total - 1 - g >= 2) { if (G == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (n == 1 && s == 5) OPHIP_STAMP(p.stamps, wgid, 28);
+                if (g + 3 < total) issue(g + 3);                     // first: two full steps until its bytes are waited for
+                if (n == 1 && s == 5) OPHIP_STAMP(p.stamps, wgid, 29);
+                // straight-line body (no branches between the reads and the MFMAs: at a merge hipcc waits lgkmcnt(0) in front of the
+                // first MFMA, i.e. for the read-ahead just issued).  Past the last k-step both run on stale bytes, unused.
+                {
+                    const int cur = u & 1;
+                    // term-major order (small terms first per accumulator, as mma_bf16): dependent MFMAs are four apart
+                    if (NS == 3) {
+#pragma unroll
+                        for (int x = 0; x < 2; ++x)
+#pragma unroll
+                            for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][x][1], fb[cur][y][0], acc[x][y], 0, 0, 0);
+#pragma unroll
+                        for (int x = 0; x < 2; ++x)
+#pragma unroll
+                            for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][x][0], fb[cur][y][1], acc[x][y], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int x = 0; x < 2; ++x)
+#pragma unroll
+                        for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][x][0], fb[cur][y][0], acc[x][y], 0, 0, 0);
+                    read_frags(g + 1, cur ^ 1);
+                    // issue order: one fragment read behind each of the first MFMAs
+#pragma unroll
+                    for (int i = 0; i < (NS == 3 ? 12 : 4); ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (i < (NS == 3 ? 8 : 4)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (n == 1 && s == 5) OPHIP_STAMP(p.stamps, wgid, 30);
+                if (n == 1 && s == 6) OPHIP_STAMP(p.stamps, wgid, 31);
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (n > 0) {
+                    // rows rg + 8 s of the staged tile: out to the conf buffer and into the statistics, one exponential per element
+                    // (tile maximum m as the common reference; a thread owns 4 columns, a row's sum is a 32-lane DPP reduction)
+                    const int row = rg + 8 * s;
+                    const int gi = pi0 + row, gj = pj0 + 4 * c4;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(St + row * FLD + 4 * c4);
+                    if (gi < p.N && gj < p.M) {
+                        if (vec) {
+                            *reinterpret_cast<f32x4*>(conf + (size_t)gi * p.M + gj) = v;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (gj + e < p.M) conf[(size_t)gi * p.M + gj + e] = v[e];
+                        }
+                    }
+                    if (fast) {
+                        const float e0 = __expf(v[0] - m), e1 = __expf(v[1] - m), e2 = __expf(v[2] - m), e3 = __expf(v[3] - m);
+                        colacc[0] += e0; colacc[1] += e1; colacc[2] += e2; colacc[3] += e3;
+                        const float rs = half_sum_dpp((e0 + e1) + (e2 + e3));
+                        mine = (c4 == s) ? rs : mine;                  // lane c4 < 16 keeps the sum of row rg + 8 c4
+                    }
+                }
             }
         }
-        const float v2 = __shfl_xor(bv, 1, 64);
-        const int j2 = __shfl_xor(bj, 1, 64), c2 = __shfl_xor(bc, 1, 64);
-        if (v2 > bv) { bv = v2; bj = j2; bc = c2; }
-        else if (v2 == bv) { bj = min(bj, j2); bc += c2; }
-        if (par == 0 && i0 + idx < p.N) {
-            float* o = p.rowbest + (((size_t)b * p.ntc + tj) * p.N + i0 + idx) * 3;
-            o[0] = bv; o[1] = __int_as_float(bj); o[2] = __int_as_float(bc);
         }
-    }
-    {
-        const int nrow = min(TM, p.N - i0);
-        float m = 0.f;                                       // conf >= 0
-#pragma unroll 16
-        for (int q = 0; q < TM / 2; ++q) {
-            const int ii = 2 * q + par;
-            if (ii < nrow) m = fmaxf(m, St[ii * SLD + idx]);
+        if (n < 7) OPHIP_STAMP(p.stamps, wgid, 4 * n + 1);
+        // ---- seam: tile n - 1 leaves, tile n is staged ------------------------------------------------------------------------
+        constexpr float TINY = 1e-26f;      // a sum below it: every term > 59 under the reference -> the partial would lose bits
+        if (!matrix && n > 0 && fast) {
+            const f32x4 cs = {swap32_sum(colacc[0]), swap32_sum(colacc[1]), swap32_sum(colacc[2]), swap32_sum(colacc[3])};
+            if (lane < 32) *reinterpret_cast<f32x4*>(csw + w4 * 128 + 4 * c4) = cs;
+            if (!__all(mine >= TINY) && lane == 0) slow[w4] = 1;
         }
-        m = fmaxf(m, __shfl_xor(m, 1, 64));
-        if (par == 0 && j0 + idx < p.M) p.colmaxp[((size_t)b * p.ntr + ti) * p.M + j0 + idx] = m;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // E
+        float ctot = 1.f;
+        if (!matrix && n > 0 && fast && st < 128) {
+            ctot = (csw[st] + csw[128 + st]) + (csw[256 + st] + csw[384 + st]);
+            if (!(ctot >= TINY)) slow[0] = 1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // F
+        if (n < 7) OPHIP_STAMP(p.stamps, wgid, 4 * n + 2);
+        if (n > 0) {
+            const bool sweep = !fast || (slow[0] | slow[1] | slow[2] | slow[3]) != 0;      // uniform over the workgroup
+            if (sweep) {
+                if (!matrix) {
+                    SimArgs q{nullptr, nullptr, p.conf, p.rowpart, p.colpart, p.N, p.M, p.ntr, p.ntc, p.temp, nullptr};
+                    tile_stats_lds<true, FLD>(q, St, st, pi0, pj0, b);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // S
+            } else if (!matrix) {
+                if (c4 < 16) {
+                    float* o = p.rowpart + (((size_t)b * p.ntc + ptj) * p.N + pi0 + rg + 8 * c4) * 2;
+                    o[0] = m; o[1] = mine;
+                }
+                if (st < 128) {
+                    float* o = p.colpart + (((size_t)b * p.ntr + pti) * p.M + pj0 + st) * 2;
+                    o[0] = m; o[1] = ctot;
+                }
+            }
+        }
+        if (n < ntl) {
+            if (matrix) {
+                float vmax = -INFINITY;
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            const float sv = acc[x][y][reg] * inv_temp;
+                            St[(64 * wr + 32 * x + acc_row(reg, h)) * FLD + 64 * wc + 32 * y + r] = sv;
+                            vmax = fmaxf(vmax, sv);
+                        }
+                        acc[x][y] = zero16();
+                    }
+                const float mw = wave_max_dpp(vmax);
+                if (lane == 0) wmx[w4] = mw;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // G
+        if (n < 7) OPHIP_STAMP(p.stamps, wgid, 4 * n + 3);
+        if (tid < 4) slow[tid] = 0;                  // every wave has read the flags of tile n - 1; tile n's are set before the next E
+        if (n < ntl) {
+            ws_tile(p.ntr, p.ntc, slot + n * nslots, pti, ptj);
+            pi0 = pti * TM; pj0 = ptj * TN;
+            m = fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3]));
+            fast = !((pi0 + TM > p.N) || (pj0 + TN > p.M)) && (m - m == 0.f);
+            colacc[0] = colacc[1] = colacc[2] = colacc[3] = 0.f;
+            mine = 1.f;
+        }
     }
 }
 
-struct BestArgs {
-    const float* rowbest_part;   // [B][ntc][N][3]
-    const float* colmaxp;        // [B][ntr][M]
-    float* rowbest;              // [B][N][3]
-    float* colmax;               // [B][M]
-    int N, M, ntr, ntc;
-};
-
-// fixed-order merge of the per-tile partials: one thread per row (over the ntc column tiles) or column (over the ntr row tiles)
-__global__ __launch_bounds__(256) void best_combine_kernel(BestArgs p) {
-    const int g = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (g < p.N) {
-        float v = -1.f;
-        int j = 0x7fffffff, c = 0;
-        for (int t = 0; t < p.ntc; ++t) {
-            const float* q = p.rowbest_part + (((size_t)b * p.ntc + t) * p.N + g) * 3;
-            const float v2 = q[0];
-            const int j2 = __float_as_int(q[1]), c2 = __float_as_int(q[2]);
-            if (v2 > v) { v = v2; j = j2; c = c2; }
-            else if (v2 == v) { j = min(j, j2); c += c2; }
-        }
-        float* o = p.rowbest + ((size_t)b * p.N + g) * 3;
-        o[0] = v; o[1] = __int_as_float(j); o[2] = __int_as_float(c);
-    } else if (g - p.N < p.M) {
-        const int jj = g - p.N;
-        float m = 0.f;
-        for (int t = 0; t < p.ntr; ++t) m = fmaxf(m, p.colmaxp[((size_t)b * p.ntr + t) * p.M + jj]);
-        p.colmax[(size_t)b * p.M + jj] = m;
-    }
-}
 
 struct CombineArgs {
     const float *rowpart, *colpart;
@@ -677,6 +898,7 @@ struct ConfArgs {
     float* rowbest;          // [B][nspan][N][3]  (value, j as float bits, tie count as float bits)
     unsigned* colmax_bits;   // [B][M] column maxima as float bits (conf >= 0, so unsigned order == float order)
     int N, M, nspan, spanw, nrb;
+    float thr;               // match threshold (strict >): entries at or below it are never tracked
 };
 
 #ifndef OPHIP_CONF_ROWS
@@ -699,12 +921,17 @@ __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
     const float* cst = p.colstat + (size_t)b * p.M * 2;
     const float* rst = p.rowstat + (size_t)b * p.N * 2;
 
-    // the rows' (max, 1 / sum) once, through LDS: a global load inside the row loop is an L2 round trip per row pair
+    // Row / column statistics once per workgroup (rows through LDS: a global load inside the row loop is an L2 round trip per
+    // row pair).  Exact mode: (max, 1 / sum) of the true maxima.  bf16 modes: the merged partials' reference is a tile maximum,
+    // possibly far above a row's own, so both its inverse sum and its exponent can leave f32's range when multiplied out; the
+    // log form conf = exp((s - M_c - log E_c) + (s - M_r - log E_r)) has every term <= 0 and needs no division at all.
     __shared__ float rstat_s[CONF_ROWS][2];
     if (tid < CONF_ROWS) {
         const int i = min(i0 + tid, p.N - 1);
         rstat_s[tid][0] = rst[2 * i];
-        rstat_s[tid][1] = 1.0f / rst[2 * i + 1];
+        rstat_s[tid][1] = FAST ? logf(rst[2 * i + 1]) : 1.0f / rst[2 * i + 1];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { red_v[w][tid] = -1.f; red_j[w][tid] = 0x7fffffff; red_c[w][tid] = 0; }
     }
     float cm[CONF_U][4], cinv[CONF_U][4], cbest[CONF_U][4];
 #pragma unroll
@@ -713,7 +940,7 @@ __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
         for (int e = 0; e < 4; ++e) {
             const int j = jb + 4 * tid + 1024 * u + e;
             cm[u][e] = (j < je) ? cst[2 * j] : 0.f;
-            cinv[u][e] = (j < je) ? 1.0f / cst[2 * j + 1] : 1.f;
+            cinv[u][e] = (j < je) ? (FAST ? logf(cst[2 * j + 1]) : 1.0f / cst[2 * j + 1]) : (FAST ? 0.f : 1.f);
             cbest[u][e] = 0.f;
         }
     const int nrows = min(CONF_ROWS, p.N - i0);
@@ -738,6 +965,10 @@ __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
             }
         }
     };
+    // Only entries above the threshold can become matches (get_coarse_match masks conf > thr before the mutual test, and a
+    // row / column maximum that matters is itself such an entry), so the running row best, its tie count and the column maxima
+    // are tracked for those entries alone: the common element costs one compare, and a wave reduces a row only when one of
+    // its lanes saw a candidate.  Rows / columns without a candidate keep (-1, none, 0) / 0, which select reads as "no match".
     auto process_batch = [&](int r0, float (&cur)[CONF_RB][CONF_U][4]) {
 #pragma unroll
         for (int q = 0; q < CONF_RB; ++q) {
@@ -746,22 +977,20 @@ __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
                 const int i = i0 + rr;
                 const float rm = rstat_s[rr][0], rinv = rstat_s[rr][1];
                 float* row = conf + (size_t)i * p.M;
-                float bv = -1.f;
-                int bj = 0x7fffffff, bc = 0;
+                bool hit = false;
 #pragma unroll
                 for (int u = 0; u < CONF_U; ++u) {
                     const int jq = jb + 4 * tid + 1024 * u;
                     if (jq < je) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            // softmax over the 3D axis (dim=1: column stats) times softmax over the 2D axis (dim=2: row stats)
-                            const float c = (exp_sel<FAST>(cur[q][u][e] - cm[u][e]) * cinv[u][e]) * (exp_sel<FAST>(cur[q][u][e] - rm) * rinv);
+                            // softmax over the 3D axis (dim=1: column stats) times softmax over the 2D axis (dim=2: row stats);
+                            // the bf16 modes (error budget 1e-5) fold the two exponentials into one (cinv / rinv = log sums there)
+                            const float sv = cur[q][u][e];
+                            const float c = FAST ? exp_sel<true>(((sv - cm[u][e]) - cinv[u][e]) + ((sv - rm) - rinv))
+                                                 : (exp_sel<false>(sv - cm[u][e]) * cinv[u][e]) * (exp_sel<false>(sv - rm) * rinv);
                             cur[q][u][e] = c;
-                            if (jq + e < je) {
-                                cbest[u][e] = fmaxf(cbest[u][e], c);
-                                if (c > bv) { bv = c; bj = jq + e; bc = 1; }
-                                else if (c == bv) { bc += 1; bj = min(bj, jq + e); }
-                            }
+                            hit |= (c > p.thr) && (jq + e < je);
                         }
                         if (VEC) {
                             f32x4 v = {cur[q][u][0], cur[q][u][1], cur[q][u][2], cur[q][u][3]};
@@ -772,16 +1001,35 @@ __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
                         }
                     }
                 }
-                // wave reduce: max value, lowest j among the maxima, number of maxima
-                const float wv = wave_max(bv);
-                int cj = (bv == wv) ? bj : 0x7fffffff;
-                int cc = (bv == wv) ? bc : 0;
+                if (__any(hit)) {
+                    float bv = -1.f;
+                    int bj = 0x7fffffff, bc = 0;
+                    if (hit) {
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    cj = min(cj, __shfl_xor(cj, o, 64));
-                    cc += __shfl_xor(cc, o, 64);
+                        for (int u = 0; u < CONF_U; ++u) {
+                            const int jq = jb + 4 * tid + 1024 * u;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float c = cur[q][u][e];
+                                if (jq + e < je && c > p.thr) {
+                                    cbest[u][e] = fmaxf(cbest[u][e], c);
+                                    if (c > bv) { bv = c; bj = jq + e; bc = 1; }
+                                    else if (c == bv) { bc += 1; bj = min(bj, jq + e); }
+                                }
+                            }
+                        }
+                    }
+                    // wave reduce: max value, lowest j among the maxima, number of maxima
+                    const float wv = wave_max(bv);
+                    int cj = (bv == wv) ? bj : 0x7fffffff;
+                    int cc = (bv == wv) ? bc : 0;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        cj = min(cj, __shfl_xor(cj, o, 64));
+                        cc += __shfl_xor(cc, o, 64);
+                    }
+                    if (lane == 0) { red_v[wave][rr] = wv; red_j[wave][rr] = cj; red_c[wave][rr] = cc; }
                 }
-                if (lane == 0) { red_v[wave][rr] = wv; red_j[wave][rr] = cj; red_c[wave][rr] = cc; }
             }
         }
     };
@@ -939,9 +1187,7 @@ extern "C" size_t ophip_coarse_workspace_floats(int B, int N, int M) {
     f += (size_t)B * N * 2 + (size_t)B * M * 2;     // rowstat, colstat
     f += (size_t)B * conf_nspan(M) * N * 3;         // rowbest (one-pass form: per span)
     f += (size_t)B * M;                    // colmax (float bits)
-    // two-pass form of the bf16 modes: (hi, lo) bf16 planes of both inputs, per-tile row-best / column-max partials
-    f += (size_t)B * ((size_t)N + M) * C + 64;
-    f += (size_t)B * ntc * N * 3 + (size_t)B * ntr * M + (size_t)B * N * 3;
+    f += (size_t)B * (ntr + ntc) * TM * C + 64;     // fragment planes of both inputs (hi + lo bf16 = 4 bytes per element), rows padded to 128
     return f + 64;
 }
 
@@ -966,57 +1212,36 @@ int coarse_impl(int parts, const float* feat3d, const float* feat2d, const float
     float* rowbest = colstat + (size_t)B * M * 2;
     float* colmax = rowbest + (size_t)B * nspan * N * 3;
 
-    // Measured at c2 (tools/time_coarse.py, round 2): the two-pass form as built moves 1/3 of the bytes but runs its tile GEMM
-    // + epilogue twice -- split 16 + pass1 119 + combine 8 + pass2 181 + best 27 + select 19 = 345 us against 205 us for the
-    // one-pass chain (sim_stats 105, conf 85): the 128 x 128 tile kernel spends 3/4 of its time outside the MFMAs (staging,
-    // barriers, the LDS sweeps of the epilogue), so recomputing S only pays once that kernel is ~2x leaner.  It stays
-    // selectable (OPHIP_COARSE_TWOPASS=1) and parity-tested; the default is the one-pass chain.
-    static const bool two_pass_env = getenv("OPHIP_COARSE_TWOPASS") != nullptr;
-    const bool two_pass = nsplit != 0 && two_pass_env;
-    int sel_nspan = nspan;
-    if (two_pass) {
-        float* w2s = colmax + (size_t)B * M;
-        w2s += (16 - ((reinterpret_cast<uintptr_t>(w2s) >> 2) & 15)) & 15;
-        rowbest = reinterpret_cast<float*>(reinterpret_cast<char*>(w2s) + (size_t)B * ((size_t)N + M) * C * 4) + (size_t)B * ntc * N * 3 + (size_t)B * ntr * M;
-        sel_nspan = 1;
-    }
-    if (two_pass && (parts & 1)) {
-        // ---- bf16 modes: S recomputed instead of stored (see the kernels above) ------------------------------------------
+    // bf16 modes: fragment planes + LDS-DMA tile kernel (OPHIP_SIM_V1=1 selects the round-1 kernel that converts inside every tile)
+    static const bool sim_v1 = getenv("OPHIP_SIM_V1") != nullptr;
+    const int sel_nspan = nspan;
+    if ((parts & 1) && nsplit != 0 && !sim_v1) {
         float* w2 = colmax + (size_t)B * M;
         w2 += (16 - ((reinterpret_cast<uintptr_t>(w2) >> 2) & 15)) & 15;                 // 64-byte aligned planes
-        char* a_hi = reinterpret_cast<char*>(w2);
-        char* a_lo = a_hi + (size_t)B * N * C * 2;
-        char* b_hi = a_lo + (size_t)B * N * C * 2;
-        char* b_lo = b_hi + (size_t)B * M * C * 2;
-        float* rowbest_part = reinterpret_cast<float*>(b_lo + (size_t)B * M * C * 2);
-        float* colmaxp = rowbest_part + (size_t)B * ntc * N * 3;
-        float* rowbest1 = colmaxp + (size_t)B * ntr * M;
-        SplitArgs s3{feat3d, a_hi, a_lo, (long long)B * N}, s2{feat2d, b_hi, b_lo, (long long)B * M};
-        OPHIP_LAUNCH("split_planes", stream, split_planes_kernel, dim3((unsigned)(((long long)B * N * (C / 8) + 255) / 256)), dim3(256), 0, stream, s3);
-        OPHIP_LAUNCH("split_planes", stream, split_planes_kernel, dim3((unsigned)(((long long)B * M * (C / 8) + 255) / 256)), dim3(256), 0, stream, s2);
+        char* fa_ = reinterpret_cast<char*>(w2);
+        char* fb_ = fa_ + (size_t)B * ntr * 4 * 32768;
+        FragArgs fr{feat3d, feat2d, fa_, fb_, N, M, 4 * ntr, 4 * ntc};
+        OPHIP_LAUNCH("frag_planes", stream, frag_planes_kernel, dim3(4 * (ntr + ntc), B), dim3(256), 0, stream, fr);
         OPHIP_CHECK_LAUNCH();
-        const int per_xcd = ((ntr + 7) / 8) * ntc;
-        Sim2Args pa{a_hi, a_lo, b_hi, b_lo, conf, rowpart, colpart, rowstat, colstat, rowbest_part, colmaxp, N, M, ntr, ntc, per_xcd,
-                    (float)(temperature + 1e-4)};
-        const size_t tiles = (size_t)(nsplit == 3 ? 4 : 2) * TM * SPITCH;
-        const size_t lds = tiles > SIM_STAGE_BYTES ? tiles : SIM_STAGE_BYTES;
-        const void* f1 = nsplit == 3 ? reinterpret_cast<const void*>(sim_pass1_kernel<3>) : reinterpret_cast<const void*>(sim_pass1_kernel<1>);
-        const void* f2 = nsplit == 3 ? reinterpret_cast<const void*>(sim_pass2_kernel<3>) : reinterpret_cast<const void*>(sim_pass2_kernel<1>);
-        if (int rc = ophip_lds_attr(f1, lds, "hipFuncSetAttribute(sim_pass1)")) return rc;
-        if (int rc = ophip_lds_attr(f2, lds, "hipFuncSetAttribute(sim_pass2)")) return rc;
-        if (nsplit == 3) OPHIP_LAUNCH("sim_pass1", stream, sim_pass1_kernel<3>, dim3(8 * per_xcd, B), dim3(256), lds, stream, pa);
-        else OPHIP_LAUNCH("sim_pass1", stream, sim_pass1_kernel<1>, dim3(8 * per_xcd, B), dim3(256), lds, stream, pa);
+        SimFragArgs sf{fa_, fb_, conf, rowpart, colpart, N, M, ntr, ntc, (float)(temperature + 1e-4), ophip_stamp_buffer()};
+        static const bool sim_v2 = getenv("OPHIP_SIM_V2") != nullptr;      // one tile per 256-thread workgroup, two per CU
+        if (sim_v2) {
+            const int per_xcd = ((ntr + 7) / 8) * ntc;
+            const void* fn = nsplit == 3 ? reinterpret_cast<const void*>(sim_frag_kernel<3>) : reinterpret_cast<const void*>(sim_frag_kernel<1>);
+            if (int rc = ophip_lds_attr(fn, SIM_FRAG_LDS, "hipFuncSetAttribute(sim_frag)")) return rc;
+            if (nsplit == 3) OPHIP_LAUNCH("sim_stats", stream, sim_frag_kernel<3>, dim3(8 * per_xcd, B), dim3(256), SIM_FRAG_LDS, stream, sf);
+            else OPHIP_LAUNCH("sim_stats", stream, sim_frag_kernel<1>, dim3(8 * per_xcd, B), dim3(256), SIM_FRAG_LDS, stream, sf);
+        } else {
+            int dev = 0, cus = 256;
+            (void)hipGetDevice(&dev);
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            const int slots = cus >= 8 ? cus / 8 : 1;                      // persistent: one workgroup per CU, 8 XCD labels
+            const void* fn = nsplit == 3 ? reinterpret_cast<const void*>(sim_ws_kernel<3>) : reinterpret_cast<const void*>(sim_ws_kernel<1>);
+            if (int rc = ophip_lds_attr(fn, SIM_WS_LDS, "hipFuncSetAttribute(sim_ws)")) return rc;
+            if (nsplit == 3) OPHIP_LAUNCH("sim_stats", stream, sim_ws_kernel<3>, dim3(8 * slots, B), dim3(512), SIM_WS_LDS, stream, sf);
+            else OPHIP_LAUNCH("sim_stats", stream, sim_ws_kernel<1>, dim3(8 * slots, B), dim3(512), SIM_WS_LDS, stream, sf);
+        }
         OPHIP_CHECK_LAUNCH();
-        CombineArgs ca{rowpart, colpart, rowstat, colstat, reinterpret_cast<unsigned*>(colmax), N, M, ntr, ntc};
-        OPHIP_LAUNCH("stat_combine", stream, stat_combine_kernel, dim3((N + M + 31) / 32, B), dim3(256), 0, stream, ca);
-        OPHIP_CHECK_LAUNCH();
-        if (nsplit == 3) OPHIP_LAUNCH("sim_pass2", stream, sim_pass2_kernel<3>, dim3(8 * per_xcd, B), dim3(256), lds, stream, pa);
-        else OPHIP_LAUNCH("sim_pass2", stream, sim_pass2_kernel<1>, dim3(8 * per_xcd, B), dim3(256), lds, stream, pa);
-        OPHIP_CHECK_LAUNCH();
-        BestArgs ba{rowbest_part, colmaxp, rowbest1, colmax, N, M, ntr, ntc};
-        OPHIP_LAUNCH("best_combine", stream, best_combine_kernel, dim3((N + M + 255) / 256, B), dim3(256), 0, stream, ba);
-        OPHIP_CHECK_LAUNCH();
-        if (rowbest1 != rowbest) return ophip_bad_arg(__func__, "internal: workspace layout");
     } else if (parts & 1) {
         SimArgs sa{feat3d, feat2d, conf, rowpart, colpart, N, M, ntr, ntc, (float)(temperature + 1e-4), ophip_stamp_buffer()};
         {
@@ -1031,10 +1256,12 @@ int coarse_impl(int parts, const float* feat3d, const float* feat2d, const float
             else OPHIP_LAUNCH("sim_stats", stream, sim_stats_bf16_kernel<1>, dim3(ntc, ntr, B), dim3(256), lds, stream, sa);
         }
         OPHIP_CHECK_LAUNCH();
+    }
+    if (parts & 1) {
         CombineArgs ca{rowpart, colpart, rowstat, colstat, reinterpret_cast<unsigned*>(colmax), N, M, ntr, ntc};
         OPHIP_LAUNCH("stat_combine", stream, stat_combine_kernel, dim3((N + M + 31) / 32, B), dim3(256), 0, stream, ca);
         OPHIP_CHECK_LAUNCH();
-        ConfArgs fa{conf, rowstat, colstat, rowbest, reinterpret_cast<unsigned*>(colmax), N, M, nspan, spanw, nrb};
+        ConfArgs fa{conf, rowstat, colstat, rowbest, reinterpret_cast<unsigned*>(colmax), N, M, nspan, spanw, nrb, thr};
         const bool vec = M % 4 == 0, fast = nsplit != 0;
         if (vec && fast) OPHIP_LAUNCH("conf", stream, (conf_kernel<true, true>), dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
         else if (vec) OPHIP_LAUNCH("conf", stream, (conf_kernel<true, false>), dim3(nspan, nrb, B), dim3(256), 0, stream, fa);

@@ -25,6 +25,7 @@ _SIGNATURES = {
     "ophip_device_info": (c_i, [ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.c_char_p, c_i]),
     "ophip_timing_select": (c_i, [ctypes.c_char_p]),
     "ophip_timing_read": (c_i, [ctypes.POINTER(c_i), ctypes.POINTER(ctypes.c_double)]),
+    "ophip_timing_every": (c_i, [c_i]),
     "ophip_debug_stamps": (c_i, [ctypes.c_void_p]),
     "ophip_pe_add_transpose": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_void_p]),
     "ophip_transpose_cl": (c_i, [c_f, c_f, c_i, c_i, c_i, ctypes.c_void_p]),
@@ -126,8 +127,9 @@ def device_info() -> dict:
     return {"cu_count": cu.value, "lds_per_block": lds.value, "arch": buf.value.decode()}
 
 
-def timing_select(kernel_name: str):
-    """Bracket every launch of ``kernel_name`` with HIP events ("" switches timing off)."""
+def timing_select(kernel_name: str, every: int = 1):
+    """Bracket every ``every``-th launch of ``kernel_name`` with HIP events ("" switches timing off)."""
+    call("ophip_timing_every", int(every))
     call("ophip_timing_select", kernel_name.encode())
 
 

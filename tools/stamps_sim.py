@@ -15,16 +15,14 @@ def run():
     hip.call("ophip_coarse_match", hip.ptr(f3), hip.ptr(f2), hip.ptr(kp), kp.stride(0), 1, N, M, wc, 0.08, 0.1, 2, 8.0, hip.ptr(conf), hip.ptr(ws),
              *[hip.ptr(t, torch.int64) for t in ids], hip.ptr(mconf), hip.ptr(mk3), hip.ptr(mkc), None, None, hip.ptr(cnt, torch.int32), 3, hip.stream_handle())
 for _ in range(3): run()
-nwg = 38 * 55
+nwg = 256
 buf = torch.zeros(nwg * 32, dtype=torch.int64, device=dev)
 hip.call("ophip_debug_stamps", ctypes.c_void_p(buf.data_ptr())); run(); torch.cuda.synchronize(); hip.call("ophip_debug_stamps", None)
 s = buf.view(-1, 32).cpu().numpy().astype(np.int64)
-names = {1: "prologue load+stage+sync"}
-for kc in range(4):
-    names[2 + 3 * kc] = f"kc{kc} prefetch+mfma"; names[3 + 3 * kc] = f"kc{kc} sync"; names[4 + 3 * kc] = f"kc{kc} stage+sync"
-names[31] = "epilogue"
-prev = s[:, 0]
-print("WGs", nwg, "median WG cycles", np.median(s[:, 31] - s[:, 0]), "span cycles", s[:, 31].max() - s[:, 0].min())
-for k in sorted(names):
-    print(f"{names[k]:28s} {np.median(s[:, k] - prev):9.0f}")
-    prev = s[:, k]
+s = s[s[:, 0] > 0]
+print("WGs", len(s))
+for n in range(7):
+    t = s[:, 4 * n: 4 * n + 4]
+    nxt = s[:, 4 * n + 4] if n < 6 else None
+    print(f"tile {n}: k-steps {np.median(t[:,1]-t[:,0]):7.0f}  E+F {np.median(t[:,2]-t[:,1]):6.0f}  out/stage+G {np.median(t[:,3]-t[:,2]):6.0f}" + (f"  to next {np.median(nxt - t[:,3]):5.0f}" if nxt is not None else ""))
+print("step 5 of tile 1: issue", np.median(s[:,29]-s[:,28]), "mfma+reads issue", np.median(s[:,30]-s[:,29]), "to end of step 6", np.median(s[:,31]-s[:,30]))

@@ -26,7 +26,7 @@ for _ in range(3): run()
 torch.cuda.synchronize()
 print("matches", int(cnt.item()))
 tot = 0.0
-for name in ("split_planes", "sim_pass1", "sim_stats", "stat_combine", "sim_pass2", "conf", "best_combine", "select"):
+for name in ("frag_planes", "sim_stats", "stat_combine", "conf", "select"):
     hip.timing_select(name)
     for _ in range(20): run()
     torch.cuda.synchronize(); n, ms = hip.timing_read(); hip.timing_select("")
