@@ -336,34 +336,30 @@ struct FragArgs {
     int N, M, nta, ntb;  // nta = Npad / 32, ntb = Mpad / 32
 };
 
+// one wave per fragment pair: block (T, s / 4), wave s % 4; lane l converts the 8 features it will hold as an MFMA operand
+// (32 bytes in, 16 + 16 out: each wave writes two whole 1 KiB fragments, the block reads 256 contiguous bytes of each row)
 __global__ __launch_bounds__(256) void frag_planes_kernel(FragArgs p) {
-    const int b = blockIdx.y, tid = threadIdx.x;
-    int T = blockIdx.x;
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int T = blockIdx.x >> 2;
+    const int s = 4 * (blockIdx.x & 3) + wave;
     const bool is_a = T < p.nta;
     if (!is_a) T -= p.nta;
     const int rows = is_a ? p.N : p.M;
     const float* x = (is_a ? p.x3 : p.x2) + (size_t)b * rows * C;
-    char* dst = (is_a ? p.a + (size_t)b * p.nta * 32768 : p.b + (size_t)b * p.ntb * 32768) + (size_t)T * 32768;
-    const int r = tid >> 3, kseg = tid & 7, row = 32 * T + r;       // a thread owns 32 consecutive features of one row
-    f32x4 v[8];
+    char* dst = (is_a ? p.a + (size_t)b * p.nta * 32768 : p.b + (size_t)b * p.ntb * 32768) + (size_t)T * 32768 + (size_t)(2 * s) * 1024 + 16 * lane;
+    const int row = 32 * T + (lane & 31), k0 = 16 * s + 8 * (lane >> 5);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 v0 = row < rows ? *reinterpret_cast<const f32x4*>(x + (size_t)row * C + k0) : z;
+    const f32x4 v1 = row < rows ? *reinterpret_cast<const f32x4*>(x + (size_t)row * C + k0 + 4) : z;
+    bf16x8 vh, vl;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        v[g] = row < rows ? *reinterpret_cast<const f32x4*>(x + (size_t)row * C + 32 * kseg + 4 * g) : z;
+    for (int j = 0; j < 4; ++j) {
+        __bf16 hh, ll;
+        split_bf16(v0[j] * 0.0625f, hh, ll); vh[j] = hh; vl[j] = ll;          // feat / sqrt(C): exact power of two
+        split_bf16(v1[j] * 0.0625f, hh, ll); vh[4 + j] = hh; vl[4 + j] = ll;
     }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {                                   // features 32 kseg + 8 g ..: k-step 2 kseg + g / 2, half g % 2
-        bf16x8 vh, vl;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            __bf16 hh, ll;
-            split_bf16(v[2 * g + (j >> 2)][j & 3] * 0.0625f, hh, ll);
-            vh[j] = hh; vl[j] = ll;
-        }
-        const int s = 2 * kseg + (g >> 1), lane = r + 32 * (g & 1);
-        *reinterpret_cast<bf16x8*>(dst + (size_t)(2 * s) * 1024 + 16 * lane) = vh;
-        *reinterpret_cast<bf16x8*>(dst + (size_t)(2 * s + 1) * 1024 + 16 * lane) = vl;
-    }
+    *reinterpret_cast<bf16x8*>(dst) = vh;
+    *reinterpret_cast<bf16x8*>(dst + 1024) = vl;
 }
 
 struct SimFragArgs {
@@ -437,11 +433,6 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_frag_kerne
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int ti, tj;
     if (!xcd_tile(p.ntr, p.ntc, ti, tj)) return;
-#ifdef SIM_STAGGER
-    if ((((blockIdx.x >> 3) >> SIM_STAGGER_BIT) & 1) && (blockIdx.x >> 3) < 64 && blockIdx.y == 0) {
-        for (int i = 0; i < SIM_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
@@ -542,11 +533,7 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_frag_kerne
             const int row = rg + 8 * it;
             const int gi = i0 + row, gj = j0 + 4 * c4;
             const f32x4 v = *reinterpret_cast<const f32x4*>(St + row * FLD + 4 * c4);
-#ifdef SIM_NO_STORE
-            if (gi < p.N && gj < p.M && v[0] == 123.456f) {
-#else
             if (gi < p.N && gj < p.M) {
-#endif
                 if (vec) {
                     *reinterpret_cast<f32x4*>(conf + (size_t)gi * p.M + gj) = v;
                 } else {
@@ -555,11 +542,7 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_frag_kerne
                         if (gj + e < p.M) conf[(size_t)gi * p.M + gj + e] = v[e];
                 }
             }
-#ifdef SIM_NO_EXP
-            if (fast && it > 100) {
-#else
             if (fast) {
-#endif
                 const float e0 = __expf(v[0] - m), e1 = __expf(v[1] - m), e2 = __expf(v[2] - m), e3 = __expf(v[3] - m);
                 colacc[0] += e0; colacc[1] += e1; colacc[2] += e2; colacc[3] += e3;
                 const float rs = half_sum_dpp((e0 + e1) + (e2 + e3));
@@ -597,261 +580,6 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_frag_kerne
         tile_stats_lds<true, FLD>(q, St, tid, i0, j0, b);
     }
     OPHIP_STAMP(p.stamps, wg, 4);
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// Role-split persistent form of sim_frag (default): one 512-thread workgroup per CU walks its XCD band's tiles.  Waves 0-3
-// ("matrix waves") run the k-loop of tile n exactly as sim_frag does (LDS-DMA ring, 12 MFMAs per k-step each); waves 4-7
-// ("store waves") meanwhile take tile n - 1 out of the staging image, one 8-row block per k-step: whole rows to the conf
-// buffer and into the (max, sum exp) partials.  All eight waves meet at the k-step barrier, so the HBM write stream and the
-// exponentials of a tile run under the MFMAs of the next one instead of in front of them (in sim_frag both co-resident
-// workgroups run in lockstep: k-loops together, then store bursts together, the matrix pipe idle half of the time), and the
-// ring runs across tile seams (the first three k-steps of tile n + 1 are in flight while tile n is handed over).
-// Per seam: barrier E (store waves are done with the image) -> column totals + range flags -> barrier F -> partials out (or the
-// exact sweep + barrier S) while the matrix waves write the next image -> barrier G.
-// ---------------------------------------------------------------------------------------------------------------------------
-constexpr int WS_RING = 4 * FRAG_CHUNK_BYTES;                                          // 65 536
-constexpr size_t SIM_WS_LDS = WS_RING + SIM_FRAG_STAGE + 4 * 128 * sizeof(float) + 64;  // 135 232
-
-__device__ __forceinline__ void ws_tile(int ntr, int ntc, int k, int& ti, int& tj) {    // k-th tile of this block's XCD band
-    const int x = blockIdx.x & 7;
-    const int q = ntr / 8, rem = ntr % 8;
-    const int r0 = x * q + (x < rem ? x : rem), nr = q + (x < rem ? 1 : 0);
-    tj = k / nr;
-    ti = r0 + k % nr;
-}
-
-template <int NS>
-__global__ __launch_bounds__(512) void sim_ws_kernel(SimFragArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* St = reinterpret_cast<float*>(smem + WS_RING);
-    float* csw = reinterpret_cast<float*>(smem + WS_RING + SIM_FRAG_STAGE);   // [4][128] column sums over each store wave's rows
-    float* wmx = csw + 512;                                                    // [4] maximum of each matrix wave's quarter
-    int* slow = reinterpret_cast<int*>(wmx + 4);                               // [4] "needs the exact sweep" flags
-    const int b = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool matrix = wave < 4;
-    const int w4 = wave & 3;
-    const int r = lane & 31, h = lane >> 5, wr = w4 >> 1, wc = w4 & 1;
-    // this block's tiles: slot, slot + nslots, ... of the band's nr x ntc tiles
-    int ntl;
-    const int slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-    {
-        const int x = blockIdx.x & 7, q = p.ntr / 8, rem = p.ntr % 8;
-        const int band = (q + (x < rem ? 1 : 0)) * p.ntc;
-        ntl = slot < band ? (band - slot + nslots - 1) / nslots : 0;
-    }
-    if (ntl == 0) return;
-    const int nta = 4 * p.ntr, ntb = 4 * p.ntc;
-    constexpr int G = NS == 3 ? 4 : 2;                               // DMAs per k-step and matrix wave
-    const int total = 16 * ntl;                                      // k-steps of this block
-
-    // DMA sources of the tile the ring is currently filling from (matrix wave w4: row tile w4 of the A and of the B tile)
-    const char *ga = nullptr, *gb = nullptr;
-    auto src_of = [&](int n) {
-        int ti, tj;
-        ws_tile(p.ntr, p.ntc, slot + n * nslots, ti, tj);
-        ga = p.a + ((size_t)b * nta + 4 * ti + w4) * 32768 + 16 * lane;
-        gb = p.b + ((size_t)b * ntb + 4 * tj + w4) * 32768 + 16 * lane;
-    };
-    auto issue = [&](int g) {                                        // k-step g (global index): into buffer g & 3
-        const int s = g & 15;
-        if (s == 0) src_of(g >> 4);
-        char* la = smem + (g & 3) * FRAG_CHUNK_BYTES + w4 * 2048;
-        char* lb = la + 8192;
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            if (NS == 1 && f) continue;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + (size_t)(2 * s + f) * 1024),
-                                             (__attribute__((address_space(3))) void*)(la + f * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + (size_t)(2 * s + f) * 1024),
-                                             (__attribute__((address_space(3))) void*)(lb + f * 1024), 16, 0, 0);
-        }
-    };
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) acc[x][y] = zero16();
-    if (tid < 4) slow[tid] = 0;
-    // matrix waves: fragments of k-step g are read from the ring during step g - 1 (two register sets), so a step's 12 MFMAs
-    // start right behind its barrier; the DMAs run three steps ahead of the MFMAs, two ahead of the reads
-    bf16x8 fa[2][2][2], fb[2][2][2];                                 // [set][row / column sub-tile][plane]
-    auto read_frags = [&](int g, int set) {
-        const char* base = smem + (g & 3) * FRAG_CHUNK_BYTES + 16 * lane;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const char* pa = base + (2 * wr + t) * 2048;
-            const char* pb = base + 8192 + (2 * wc + t) * 2048;
-            fa[set][t][0] = *reinterpret_cast<const bf16x8*>(pa);
-            fb[set][t][0] = *reinterpret_cast<const bf16x8*>(pb);
-            if (NS == 3) {
-                fa[set][t][1] = *reinterpret_cast<const bf16x8*>(pa + 1024);
-                fb[set][t][1] = *reinterpret_cast<const bf16x8*>(pb + 1024);
-            }
-        }
-    };
-    if (matrix) {
-        issue(0); issue(1); issue(2);
-        if (total > 2) { if (G == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");         // k-step 0 has landed for every matrix wave
-    if (matrix) read_frags(0, 0);
-
-    // store-wave state of the tile being taken out
-    const int st = tid - 256, c4 = st & 31, rg = st >> 5;
-    float colacc[4] = {0.f, 0.f, 0.f, 0.f};
-    float mine = 1.f, m = 0.f;
-    bool fast = false;
-    int pi0 = 0, pj0 = 0, pti = 0, ptj = 0;
-    const float inv_temp = 1.0f / p.temp;
-    float* conf = p.conf + (size_t)b * p.N * p.M;
-    const bool vec = (p.M & 3) == 0;
-
-#pragma unroll 1
-    for (int n = 0; n <= ntl; ++n) {
-        const int wgid = blockIdx.y * gridDim.x + blockIdx.x;
-        if (n < 7) OPHIP_STAMP(p.stamps, wgid, 4 * n);
-#pragma unroll 1
-        for (int sg = 0; sg < 4; ++sg) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int s = 4 * sg + u;
-            if (matrix) {
-                const int g = 16 * n + s;
-                // k-step g + 1 has landed for this wave (counted wait: the DMAs of step g + 2 stay in flight), then for all waves
-                // (barrier); every wave is also done reading buffer (g + 3) & 3 (step g - 1's fragments were read during step g - 2).
-                // ONE asm statement: see sim_frag_kernel
-                if (total - 1 - g >= 2) { if (G == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                if (n == 1 && s == 5) OPHIP_STAMP(p.stamps, wgid, 28);
-                if (g + 3 < total) issue(g + 3);                     // first: two full steps until its bytes are waited for
-                if (n == 1 && s == 5) OPHIP_STAMP(p.stamps, wgid, 29);
-                // straight-line body (no branches between the reads and the MFMAs: at a merge hipcc waits lgkmcnt(0) in front of the
-                // first MFMA, i.e. for the read-ahead just issued).  Past the last k-step both run on stale bytes, unused.
-                {
-                    const int cur = u & 1;
-                    // term-major order (small terms first per accumulator, as mma_bf16): dependent MFMAs are four apart
-                    if (NS == 3) {
-#pragma unroll
-                        for (int x = 0; x < 2; ++x)
-#pragma unroll
-                            for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][x][1], fb[cur][y][0], acc[x][y], 0, 0, 0);
-#pragma unroll
-                        for (int x = 0; x < 2; ++x)
-#pragma unroll
-                            for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][x][0], fb[cur][y][1], acc[x][y], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int x = 0; x < 2; ++x)
-#pragma unroll
-                        for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][x][0], fb[cur][y][0], acc[x][y], 0, 0, 0);
-                    read_frags(g + 1, cur ^ 1);
-                    // issue order: one fragment read behind each of the first MFMAs
-#pragma unroll
-                    for (int i = 0; i < (NS == 3 ? 12 : 4); ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        if (i < (NS == 3 ? 8 : 4)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (n == 1 && s == 5) OPHIP_STAMP(p.stamps, wgid, 30);
-                if (n == 1 && s == 6) OPHIP_STAMP(p.stamps, wgid, 31);
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                if (n > 0) {
-                    // rows rg + 8 s of the staged tile: out to the conf buffer and into the statistics, one exponential per element
-                    // (tile maximum m as the common reference; a thread owns 4 columns, a row's sum is a 32-lane DPP reduction)
-                    const int row = rg + 8 * s;
-                    const int gi = pi0 + row, gj = pj0 + 4 * c4;
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(St + row * FLD + 4 * c4);
-                    if (gi < p.N && gj < p.M) {
-                        if (vec) {
-                            *reinterpret_cast<f32x4*>(conf + (size_t)gi * p.M + gj) = v;
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (gj + e < p.M) conf[(size_t)gi * p.M + gj + e] = v[e];
-                        }
-                    }
-                    if (fast) {
-                        const float e0 = __expf(v[0] - m), e1 = __expf(v[1] - m), e2 = __expf(v[2] - m), e3 = __expf(v[3] - m);
-                        colacc[0] += e0; colacc[1] += e1; colacc[2] += e2; colacc[3] += e3;
-                        const float rs = half_sum_dpp((e0 + e1) + (e2 + e3));
-                        mine = (c4 == s) ? rs : mine;                  // lane c4 < 16 keeps the sum of row rg + 8 c4
-                    }
-                }
-            }
-        }
-        }
-        if (n < 7) OPHIP_STAMP(p.stamps, wgid, 4 * n + 1);
-        // ---- seam: tile n - 1 leaves, tile n is staged ------------------------------------------------------------------------
-        constexpr float TINY = 1e-26f;      // a sum below it: every term > 59 under the reference -> the partial would lose bits
-        if (!matrix && n > 0 && fast) {
-            const f32x4 cs = {swap32_sum(colacc[0]), swap32_sum(colacc[1]), swap32_sum(colacc[2]), swap32_sum(colacc[3])};
-            if (lane < 32) *reinterpret_cast<f32x4*>(csw + w4 * 128 + 4 * c4) = cs;
-            if (!__all(mine >= TINY) && lane == 0) slow[w4] = 1;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // E
-        float ctot = 1.f;
-        if (!matrix && n > 0 && fast && st < 128) {
-            ctot = (csw[st] + csw[128 + st]) + (csw[256 + st] + csw[384 + st]);
-            if (!(ctot >= TINY)) slow[0] = 1;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // F
-        if (n < 7) OPHIP_STAMP(p.stamps, wgid, 4 * n + 2);
-        if (n > 0) {
-            const bool sweep = !fast || (slow[0] | slow[1] | slow[2] | slow[3]) != 0;      // uniform over the workgroup
-            if (sweep) {
-                if (!matrix) {
-                    SimArgs q{nullptr, nullptr, p.conf, p.rowpart, p.colpart, p.N, p.M, p.ntr, p.ntc, p.temp, nullptr};
-                    tile_stats_lds<true, FLD>(q, St, st, pi0, pj0, b);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // S
-            } else if (!matrix) {
-                if (c4 < 16) {
-                    float* o = p.rowpart + (((size_t)b * p.ntc + ptj) * p.N + pi0 + rg + 8 * c4) * 2;
-                    o[0] = m; o[1] = mine;
-                }
-                if (st < 128) {
-                    float* o = p.colpart + (((size_t)b * p.ntr + pti) * p.M + pj0 + st) * 2;
-                    o[0] = m; o[1] = ctot;
-                }
-            }
-        }
-        if (n < ntl) {
-            if (matrix) {
-                float vmax = -INFINITY;
-#pragma unroll
-                for (int x = 0; x < 2; ++x)
-#pragma unroll
-                    for (int y = 0; y < 2; ++y) {
-#pragma unroll
-                        for (int reg = 0; reg < 16; ++reg) {
-                            const float sv = acc[x][y][reg] * inv_temp;
-                            St[(64 * wr + 32 * x + acc_row(reg, h)) * FLD + 64 * wc + 32 * y + r] = sv;
-                            vmax = fmaxf(vmax, sv);
-                        }
-                        acc[x][y] = zero16();
-                    }
-                const float mw = wave_max_dpp(vmax);
-                if (lane == 0) wmx[w4] = mw;
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // G
-        if (n < 7) OPHIP_STAMP(p.stamps, wgid, 4 * n + 3);
-        if (tid < 4) slow[tid] = 0;                  // every wave has read the flags of tile n - 1; tile n's are set before the next E
-        if (n < ntl) {
-            ws_tile(p.ntr, p.ntc, slot + n * nslots, pti, ptj);
-            pi0 = pti * TM; pj0 = ptj * TN;
-            m = fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3]));
-            fast = !((pi0 + TM > p.N) || (pj0 + TN > p.M)) && (m - m == 0.f);
-            colacc[0] = colacc[1] = colacc[2] = colacc[3] = 0.f;
-            mine = 1.f;
-        }
-    }
 }
 
 
@@ -1080,14 +808,18 @@ struct SelectArgs {
     int* count;
 };
 
-// One workgroup compacts the surviving rows in (b, i) order.  A thread owns SEL_IT rows of a chunk of 1024 * SEL_IT rows:
+// SEL_IT workgroups compact the surviving rows in (b, i) order: every one of them decides all rows and scans all wave counts (the
+// same loads, from L2), but writes only the matches of its own 1024-row slice of each chunk -- the ~12 scattered stores per match
+// were 3/4 of the single-workgroup kernel (one CU's store issue rate).  A thread owns SEL_IT rows of a chunk of 1024 * SEL_IT rows:
 // all its row-best records are loaded first, then all its column maxima (independent gathers, one memory round trip each
 // instead of one per 1024 rows), then one scan over the SEL_IT x 16 wave counts places every match.
 constexpr int SEL_IT = 8;
+static_assert(SEL_IT * 16 == 128, "the wave-count scan of select_kernel assumes two waves of counts");
 
 __global__ __launch_bounds__(1024) void select_kernel(SelectArgs p) {
     __shared__ int wcount[SEL_IT * 16];
     __shared__ int wpref[SEL_IT * 16 + 1];
+    __shared__ int wtot[2];
     __shared__ int base_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) base_s = 0;
@@ -1119,9 +851,10 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs p) {
                 const int i = ib + it * 1024 + tid;
                 const bool live = i < p.N && v[it] > p.thr;
                 cm[it] = live ? cmx[j[it]] : 0.f;
-                kx[it] = live ? kpb[(size_t)i * 3] : 0.f;
-                ky[it] = live ? kpb[(size_t)i * 3 + 1] : 0.f;
-                kz[it] = live ? kpb[(size_t)i * 3 + 2] : 0.f;
+                const bool mine = live && it == (int)blockIdx.x;
+                kx[it] = mine ? kpb[(size_t)i * 3] : 0.f;
+                ky[it] = mine ? kpb[(size_t)i * 3 + 1] : 0.f;
+                kz[it] = mine ? kpb[(size_t)i * 3 + 2] : 0.f;
             }
 #pragma unroll
             for (int it = 0; it < SEL_IT; ++it) {
@@ -1143,18 +876,26 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs p) {
                 if (lane == 0) wcount[it * 16 + wave] = __popcll(mask);
             }
             __syncthreads();
-            if (tid < SEL_IT * 16) {
-                int acc = 0;
-                for (int u = 0; u < tid; ++u) acc += wcount[u];
-                wpref[tid] = acc;
-                if (tid == SEL_IT * 16 - 1) wpref[SEL_IT * 16] = acc + wcount[tid];
+            if (tid < SEL_IT * 16) {                 // exclusive scan of the 128 wave counts: two waves, shuffle scan + carry
+                const int own = wcount[tid];
+                int inc = own;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int up = __shfl_up(inc, o, 64);
+                    if (lane >= o) inc += up;
+                }
+                wpref[tid] = inc - own;                              // exclusive within the wave
+                if (lane == 63) wtot[wave] = inc;                    // the two waves' totals
             }
+            __syncthreads();
+            if (tid >= 64 && tid < SEL_IT * 16) wpref[tid] += wtot[0];
+            if (tid == 0) wpref[SEL_IT * 16] = wtot[0] + wtot[1];
             __syncthreads();
             const int base = base_s;
 #pragma unroll
             for (int it = 0; it < SEL_IT; ++it) {
                 const unsigned long long mask = __ballot(ok[it]);
-                if (ok[it]) {
+                if (ok[it] && it == (int)blockIdx.x) {
                     const int i = ib + it * 1024 + tid;
                     const int pos = base + wpref[it * 16 + wave] + __popcll(mask & ((1ull << lane) - 1ull));
                     p.b_ids[pos] = b; p.i_ids[pos] = i; p.j_ids[pos] = j[it];
@@ -1171,7 +912,7 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs p) {
             __syncthreads();
         }
     }
-    if (tid == 0) *p.count = base_s;
+    if (tid == 0 && blockIdx.x == 0) *p.count = base_s;
 }
 
 inline int conf_nspan(int M) { return (M + 3071) / 3072; }
@@ -1221,26 +962,14 @@ int coarse_impl(int parts, const float* feat3d, const float* feat2d, const float
         char* fa_ = reinterpret_cast<char*>(w2);
         char* fb_ = fa_ + (size_t)B * ntr * 4 * 32768;
         FragArgs fr{feat3d, feat2d, fa_, fb_, N, M, 4 * ntr, 4 * ntc};
-        OPHIP_LAUNCH("frag_planes", stream, frag_planes_kernel, dim3(4 * (ntr + ntc), B), dim3(256), 0, stream, fr);
+        OPHIP_LAUNCH("frag_planes", stream, frag_planes_kernel, dim3(16 * (ntr + ntc), B), dim3(256), 0, stream, fr);
         OPHIP_CHECK_LAUNCH();
         SimFragArgs sf{fa_, fb_, conf, rowpart, colpart, N, M, ntr, ntc, (float)(temperature + 1e-4), ophip_stamp_buffer()};
-        static const bool sim_v2 = getenv("OPHIP_SIM_V2") != nullptr;      // one tile per 256-thread workgroup, two per CU
-        if (sim_v2) {
-            const int per_xcd = ((ntr + 7) / 8) * ntc;
-            const void* fn = nsplit == 3 ? reinterpret_cast<const void*>(sim_frag_kernel<3>) : reinterpret_cast<const void*>(sim_frag_kernel<1>);
-            if (int rc = ophip_lds_attr(fn, SIM_FRAG_LDS, "hipFuncSetAttribute(sim_frag)")) return rc;
-            if (nsplit == 3) OPHIP_LAUNCH("sim_stats", stream, sim_frag_kernel<3>, dim3(8 * per_xcd, B), dim3(256), SIM_FRAG_LDS, stream, sf);
-            else OPHIP_LAUNCH("sim_stats", stream, sim_frag_kernel<1>, dim3(8 * per_xcd, B), dim3(256), SIM_FRAG_LDS, stream, sf);
-        } else {
-            int dev = 0, cus = 256;
-            (void)hipGetDevice(&dev);
-            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            const int slots = cus >= 8 ? cus / 8 : 1;                      // persistent: one workgroup per CU, 8 XCD labels
-            const void* fn = nsplit == 3 ? reinterpret_cast<const void*>(sim_ws_kernel<3>) : reinterpret_cast<const void*>(sim_ws_kernel<1>);
-            if (int rc = ophip_lds_attr(fn, SIM_WS_LDS, "hipFuncSetAttribute(sim_ws)")) return rc;
-            if (nsplit == 3) OPHIP_LAUNCH("sim_stats", stream, sim_ws_kernel<3>, dim3(8 * slots, B), dim3(512), SIM_WS_LDS, stream, sf);
-            else OPHIP_LAUNCH("sim_stats", stream, sim_ws_kernel<1>, dim3(8 * slots, B), dim3(512), SIM_WS_LDS, stream, sf);
-        }
+        const int per_xcd = ((ntr + 7) / 8) * ntc;
+        const void* fn = nsplit == 3 ? reinterpret_cast<const void*>(sim_frag_kernel<3>) : reinterpret_cast<const void*>(sim_frag_kernel<1>);
+        if (int rc = ophip_lds_attr(fn, SIM_FRAG_LDS, "hipFuncSetAttribute(sim_frag)")) return rc;
+        if (nsplit == 3) OPHIP_LAUNCH("sim_stats", stream, sim_frag_kernel<3>, dim3(8 * per_xcd, B), dim3(256), SIM_FRAG_LDS, stream, sf);
+        else OPHIP_LAUNCH("sim_stats", stream, sim_frag_kernel<1>, dim3(8 * per_xcd, B), dim3(256), SIM_FRAG_LDS, stream, sf);
         OPHIP_CHECK_LAUNCH();
     } else if (parts & 1) {
         SimArgs sa{feat3d, feat2d, conf, rowpart, colpart, N, M, ntr, ntc, (float)(temperature + 1e-4), ophip_stamp_buffer()};
@@ -1272,7 +1001,7 @@ int coarse_impl(int parts, const float* feat3d, const float* feat2d, const float
     if (parts & 2) {
         SelectArgs se{conf, rowbest, colmax, keypoints3d, kpts_bstride, B, N, M, sel_nspan, wc, border_rm, thr, scale,
                       b_ids, i_ids, j_ids, mconf, mkpts3d, mkpts_c, m_bids, gt_mask, count};
-        OPHIP_LAUNCH("select", stream, select_kernel, dim3(1), dim3(1024), 0, stream, se);
+        OPHIP_LAUNCH("select", stream, select_kernel, dim3(SEL_IT), dim3(1024), 0, stream, se);
         OPHIP_CHECK_LAUNCH();
     }
     return 0;
