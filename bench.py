@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames per rank (cycled)")
     ap.add_argument("--precision", default=os.environ.get("OPHIP_PRECISION", "bf16x3"), choices=["f32", "bf16x3", "bf16"],
                     help="matrix arithmetic of the encoder kernels (see DESIGN.md section 4)")
+    ap.add_argument("--inputs-behind", action="store_true",
+                    help="queue the input kernels (PE, transposes, keypoint encoding) behind the previous frame on the compute stream instead of "
+                         "on a side stream (the feature maps and the object block are resident and complete here, so the side stream is legitimate)")
     ap.add_argument("--streams", type=int, default=1,
                     help="compute streams the frames alternate over.  Default 1: the model already runs the fine stage and the result "
                          "read-back on side streams (frame t's refinement under frame t + 1's input kernels) while attn_apply never shares "
@@ -217,7 +220,8 @@ def main():
         with torch.cuda.stream(streams[i % len(streams)]):
             if image is not None:
                 model.backbone_features(image)
-            inflight.append(model.enqueue_features(dict(obj_b), fc, ff, image_hw, host_copy=pool is not None))
+            inflight.append(model.enqueue_features(dict(obj_b), fc, ff, image_hw, host_copy=pool is not None,
+                                                   inputs_ready=image is None and not args.inputs_behind))
         host_t["enqueue"] += time.perf_counter() - t
         if len(inflight) > len(streams):
             return complete(inflight.pop(0))

@@ -126,6 +126,7 @@ class OnePosePlus_model(nn.Module):
         # MFMA-heavy stages never share the chip
         self.overlap_fine = bool(config.get("hip_overlap_fine", True))
         self._fine_streams = {}      # (device, compute stream) -> (fine stream, last fine-done event)
+        self._prep_streams = {}      # (device, compute stream) -> input-kernel stream (enqueue_features(inputs_ready=True))
         self._pe_cache = {}          # (h, w, device) -> [M, C] device table
         # per-object cache of the frame-invariant keypoint encoding (rows a2 + a3); off by default so that a forward always does
         # all of its work unless the caller opts in (bench.py reports both)
@@ -227,13 +228,16 @@ class OnePosePlus_model(nn.Module):
         self.enqueue_features(data, feat_c, feat_f, image_hw, want_fine_debug).finish()
 
     @torch.no_grad()
-    def enqueue_features(self, data, feat_c, feat_f, image_hw=None, want_fine_debug=False, host_copy=False, _pe_applied=False):
+    def enqueue_features(self, data, feat_c, feat_f, image_hw=None, want_fine_debug=False, host_copy=False, _pe_applied=False,
+                         inputs_ready=False):
         """Enqueue the whole path for one batch on the current stream WITHOUT synchronising and return a
         :class:`PendingFrame`; ``.finish()`` waits for that frame only (an event, not the stream) and fills ``data``.
         A pipeline enqueues frame t + 1 before finishing frame t, so the GPU never idles on the host
         (``bench.py``).  The fine stage runs on a second stream (``config["hip_overlap_fine"]``, default on): the inputs
         must stay unmodified until ``finish()``.  ``host_copy=True`` also queues the D2H of the match buffers into pinned memory, which
-        ``finish()`` exposes as numpy arrays (``pending.host``) for host PnP."""
+        ``finish()`` exposes as numpy arrays (``pending.host``) for host PnP.  ``inputs_ready=True``: the caller guarantees that
+        ``feat_c``, ``feat_f`` and the object block are complete in device memory (nothing that writes them is still queued), so
+        the input kernels may run on a side stream ahead of the work already queued on the current one."""
         if not feat_c.is_cuda:
             raise hip.HipLibraryError("OnePosePlus_model runs on the HIP device only (no CPU fallback): move the "
                                       "model and its inputs to 'cuda'")
@@ -270,53 +274,72 @@ class OnePosePlus_model(nn.Module):
             if t.shape[0] not in (1, B):
                 raise ValueError(f"{name}: batch {t.shape[0]} does not match the query batch {B}")
 
-        # ---- a1: positional encoding + flatten ------------------------------------------------
-        if _pe_applied:          # the HIP backbone wrote [B, M, C] with the encoding added; the encoder may reuse that buffer
-            x2d = feat_c.permute(0, 2, 3, 1).reshape(B, M, C)
-            if x2d.data_ptr() != feat_c.data_ptr() or not x2d.is_contiguous():
-                raise ValueError("internal: the HIP backbone's coarse map must be dense channels-last")
-        else:
-            x2d = torch.empty(B, M, C, **f32)
-            pe = self._pe_table(hc, wc, dev) if self._pe_enable else None
-            lib_call("ophip_pe_add_transpose", P(dense(feat_c)), P(pe), P(x2d), B, C, M, S)
-        # ---- fine map to channels-last (input kernel of the fine stage; here so that it runs under the previous frame's
-        #      fine stage instead of in front of this frame's) ------------------------------------------------------
-        ff = ff_strides = None
-        if bool(cfg["fine_matching"]["enable"]):
-            ff = feat_f if feat_f.dtype == torch.float32 else feat_f.float()
-            if ff.stride(1) == 1:                      # channels-last memory already: strides as they are
-                ff_strides = (ff.stride(0), 1, ff.stride(2), ff.stride(3))
-            else:                                      # NCHW: one streaming transpose, then every window pixel is a 512-byte row
-                ff = ff.contiguous()
-                ff_cl = torch.empty(B, hf * wf, ff.shape[1], **f32)
-                lib_call("ophip_transpose_cl", P(ff), P(ff_cl), B, ff.shape[1], hf * wf, S)
-                ff, ff_strides = ff_cl, (hf * wf * ff_cl.shape[2], 1, wf * ff_cl.shape[2], ff_cl.shape[2])
-        # ---- a2 + a3: keypoint encoding (frame-invariant: depends on the object block only) -------------------
-        x3d = None
-        ckey = None
-        if self.cache_object:
-            # the reference keeps the object block resident across frames (OnePosePlus_inference_dataset.py:157-169); its encoding
-            # is recomputed only when the tensors (or the weights) change
-            ckey = (str(dev), B, N, kpts_d.data_ptr(), kpts_d._version, desc_in_d.data_ptr(), desc_in_d._version, id(W))
-            if self._obj_cache is not None and self._obj_cache[0] == ckey:
-                x3d = self._obj_cache[1]
-                torch.cuda.current_stream(dev).wait_event(self._obj_cache[2])
-        if x3d is None:
-            x3d = torch.empty(B, N, C, **f32)
-            if self.kpt_3d_pos_encoding is not None:
-                stats = torch.empty(4 * B + 4, **f32)
-                lib_call("ophip_kpt_encode", P(kpts_d), bstride(kpts_d), P(desc_in_d), bstride(desc_in_d), P(W["kpt"]),
-                         P(stats), P(x3d), B, N, S)
-            else:
-                src = desc_in_d if desc_in_d.shape[0] == B else desc_in_d.expand(B, -1, -1).contiguous()
-                lib_call("ophip_transpose_cl", P(src), P(x3d), B, C, N, S)
-            if self.cache_object:
-                ev = torch.cuda.Event()
-                ev.record()
-                self._obj_cache = (ckey, x3d, ev, kpts_d, desc_in_d)          # the key's tensors stay alive with the entry
-        # ---- a4-a6: coarse encoder ----------------------------------------------------------------
         main = torch.cuda.current_stream(dev)
         fkey = (str(dev), main.cuda_stream)
+        # The input kernels (a1-a3 + the fine map's transpose) depend on nothing but the caller's tensors.  With ``inputs_ready`` the
+        # caller states that those tensors are complete (no producer still queued on this stream): the kernels then go to a side
+        # stream and start at once -- on the CUs the 246-workgroup encoder of the previous frame leaves idle and beside its coarse
+        # stage -- instead of behind everything queued before; the encoder waits for their event.
+        prep_ctx, sprep = contextlib.nullcontext(), None
+        if inputs_ready and self.overlap_fine and not _pe_applied:
+            if fkey not in self._prep_streams:
+                if len(self._prep_streams) >= 16:
+                    self._prep_streams.pop(next(iter(self._prep_streams)))
+                self._prep_streams[fkey] = torch.cuda.Stream(device=dev)
+            sprep = self._prep_streams[fkey]
+            prep_ctx = torch.cuda.stream(sprep)
+        with prep_ctx:
+            S_in = hip.stream_handle()
+            # ---- a1: positional encoding + flatten ------------------------------------------------
+            if _pe_applied:          # the HIP backbone wrote [B, M, C] with the encoding added; the encoder may reuse that buffer
+                x2d = feat_c.permute(0, 2, 3, 1).reshape(B, M, C)
+                if x2d.data_ptr() != feat_c.data_ptr() or not x2d.is_contiguous():
+                    raise ValueError("internal: the HIP backbone's coarse map must be dense channels-last")
+            else:
+                x2d = torch.empty(B, M, C, **f32)
+                pe = self._pe_table(hc, wc, dev) if self._pe_enable else None
+                lib_call("ophip_pe_add_transpose", P(dense(feat_c)), P(pe), P(x2d), B, C, M, S_in)
+            # ---- fine map to channels-last (input kernel of the fine stage; here so that it runs under the previous frame's
+            #      fine stage instead of in front of this frame's) ------------------------------------------------------
+            ff = ff_strides = None
+            if bool(cfg["fine_matching"]["enable"]):
+                ff = feat_f if feat_f.dtype == torch.float32 else feat_f.float()
+                if ff.stride(1) == 1:                      # channels-last memory already: strides as they are
+                    ff_strides = (ff.stride(0), 1, ff.stride(2), ff.stride(3))
+                else:                                      # NCHW: one streaming transpose, then every window pixel is a 512-byte row
+                    ff = ff.contiguous()
+                    ff_cl = torch.empty(B, hf * wf, ff.shape[1], **f32)
+                    lib_call("ophip_transpose_cl", P(ff), P(ff_cl), B, ff.shape[1], hf * wf, S_in)
+                    ff, ff_strides = ff_cl, (hf * wf * ff_cl.shape[2], 1, wf * ff_cl.shape[2], ff_cl.shape[2])
+            # ---- a2 + a3: keypoint encoding (frame-invariant: depends on the object block only) -------------------
+            x3d = None
+            ckey = None
+            if self.cache_object:
+                # the reference keeps the object block resident across frames (OnePosePlus_inference_dataset.py:157-169); its encoding
+                # is recomputed only when the tensors (or the weights) change
+                ckey = (str(dev), B, N, kpts_d.data_ptr(), kpts_d._version, desc_in_d.data_ptr(), desc_in_d._version, id(W))
+                if self._obj_cache is not None and self._obj_cache[0] == ckey:
+                    x3d = self._obj_cache[1]
+                    torch.cuda.current_stream(dev).wait_event(self._obj_cache[2])
+            if x3d is None:
+                x3d = torch.empty(B, N, C, **f32)
+                if self.kpt_3d_pos_encoding is not None:
+                    stats = torch.empty(4 * B + 4, **f32)
+                    lib_call("ophip_kpt_encode", P(kpts_d), bstride(kpts_d), P(desc_in_d), bstride(desc_in_d), P(W["kpt"]),
+                             P(stats), P(x3d), B, N, S_in)
+                else:
+                    src = desc_in_d if desc_in_d.shape[0] == B else desc_in_d.expand(B, -1, -1).contiguous()
+                    lib_call("ophip_transpose_cl", P(src), P(x3d), B, C, N, S_in)
+                if self.cache_object:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    self._obj_cache = (ckey, x3d, ev, kpts_d, desc_in_d)          # the key's tensors stay alive with the entry
+            if sprep is not None:
+                prep_done = torch.cuda.Event()
+                prep_done.record()
+        if sprep is not None:
+            main.wait_event(prep_done)
+        # ---- a4-a6: coarse encoder ----------------------------------------------------------------
         y3d, y2d = torch.empty_like(x3d), torch.empty_like(x2d)
         z3d = torch.empty_like(x3d) if self.cache_object else x3d          # a cached encoding is read-only: ping-pong between y and z
 

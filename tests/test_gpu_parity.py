@@ -649,6 +649,33 @@ def test_dropped_pending_frame_does_not_disturb_the_next(model, sd, cfg, dev):
     assert p.done
 
 
+def test_input_kernels_on_the_side_stream_are_bit_identical(sd, cfg, dev):
+    """enqueue_features(inputs_ready=True): PE / transposes / keypoint encoding run on a side stream ahead of the work queued on
+    the compute stream (bench.py's pipeline); frames pipelined that way equal their plain forward_features() runs bit for bit."""
+    frames = [make_synthetic_inputs(sd, n_points=1100, image_hw=(128, 192), n_plant=400, seed=43, config=cfg, frame=f) for f in range(4)]
+    obj = {k: frames[0][k].to(dev) for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db")}
+    keys = ("i_ids", "j_ids", "mconf", "mkpts_query_f", "expec_f", "conf_matrix")
+    m = _model(sd, cfg, dev, "bf16x3")
+    feats = [(f["feat_c"].to(dev), f["feat_f"].to(dev)) for f in frames]
+    torch.cuda.synchronize()
+    plain = []
+    for f, (fc, ff) in zip(frames, feats):
+        d = dict(obj)
+        m.forward_features(d, fc, ff, f["image_hw"])
+        plain.append({k: d[k].clone() for k in keys})
+    pend, outs = [], []
+    for f, (fc, ff) in zip(frames, feats):                       # all four in flight before the first finish()
+        d = dict(obj)
+        pend.append((d, m.enqueue_features(d, fc, ff, f["image_hw"], inputs_ready=True)))
+    for d, p in pend:
+        p.finish()
+        outs.append(d)
+    for a, b in zip(plain, outs):
+        assert len(a["i_ids"]) > 200
+        for k in keys:
+            assert torch.equal(a[k], b[k]), k
+
+
 def test_object_cache_is_bit_identical(sd, cfg, dev):
     """config["hip_cache_object"]: the keypoint encoding (rows a2 + a3) of a resident object block is computed once and re-used
     by the following frames -- same results bit for bit as the uncached model; a changed block (or an in-place edit) re-encodes."""
