@@ -190,7 +190,7 @@ def main():
     def complete(pend):
         """finish one frame (waits on ITS event only) and hand its matches to the host PnP pool"""
         t = time.perf_counter()
-        pend.event.synchronize()
+        pend.wait()
         host_t["wait"] += time.perf_counter() - t
         t = time.perf_counter()
         data = pend.finish()

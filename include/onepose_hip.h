@@ -162,6 +162,46 @@ int ophip_fine_refine_bf16(const float* feat_f, long long fs_b, long long fs_c, 
                            int wc, int stride, float fine_scale, float* expec_f, float* mkpts_f,
                            float* dbg_win, float* dbg_f3, void* stream);
 
+/* One call per frame -- OnePosePlus_model.forward after the backbone (OnePosePlusModel.py:115-203), default split-bf16 path:
+ * rows a1-a11 on three streams (input kernels | encoder + coarse matching | selection + fine stage) and the read-back of the
+ * result block, issued from C (csrc/frame.hip) instead of ~27 separate calls from the host language.
+ * ophip_frame_desc: sizes, scalars and packed-weight pointers of the model (fixed per model and input shape).
+ * ophip_frame_layout(): byte offsets of every intermediate and output inside ONE device block of `total` bytes
+ *   (transpose_fine: the fine map arrives NCHW and needs the channels-last copy; external_x3d: the keypoint encoding is
+ *   supplied by the caller -- a cached object block -- and stays read-only).
+ * ophip_frame_enqueue(): enqueues the frame and returns; nothing is allocated or synchronised.  s_prep may be NULL (input
+ *   kernels then run on s_main, behind everything queued there); host_dst receives the first host_bytes of the result block
+ *   (>= 16: the match count; result_bytes: count | b_ids | mkpts3d | mkpts2d) by an asynchronous copy on s_copy.
+ *   The block, the inputs and host_dst must stay valid until ophip_frame_wait(*slot) returned.
+ * Result block at offset `result`: int32 count @0, int64 b_ids[cap] @16, float mkpts3d[cap][3], float mkpts_query_f[cap][2],
+ *   cap = B * N; the other outputs (conf_matrix, i_ids, j_ids, m_bids, gt_mask, mconf, mkpts_query_c, expec_f) at their offsets.
+ * ophip_frame_order_after_fine(stream): makes `stream` wait for the fine stage of the last frame enqueued on it through this
+ *   entry point (for callers that mix it with stage-by-stage calls and want attn_apply never to share the chip with it). */
+typedef struct ophip_frame_desc {
+    int B, N, M, hc, wc, hf, wf, cf;             /* cf: channels of the fine map (128) */
+    int n_coarse; unsigned coarse_cross_bits;     /* bit li set: coarse layer li is a "cross" layer */
+    int n_fine; unsigned fine_cross_bits; int fine_encoder_enable;
+    int border_rm;
+    float thr, scale_c, fine_scale;               /* scale_c = image height / hc; fine_scale = (window / 2) * image height / hf */
+    double temperature;
+    const float* pe;                              /* [M][256] positional-encoding table or NULL */
+    const float* w_kpt;                           /* keypoint-encoder block or NULL (encoding disabled) */
+    const void* w_coarse[16];                     /* packing.pack_coarse_layer_x3w8 blocks */
+    const void* w_fine;                           /* packing.pack_fine_layers_bf16 block */
+} ophip_frame_desc;
+typedef struct ophip_frame_layout_t {
+    size_t total, result_bytes;
+    size_t x2d, ffcl, x3d, y3d, y2d, z3d, stats, enc_ws, conf, cws, result, i_ids, j_ids, m_bids, gt_mask, mconf, mkc, expec;
+} ophip_frame_layout_t;
+int ophip_frame_layout(const ophip_frame_desc* desc, int transpose_fine, int external_x3d, ophip_frame_layout_t* layout);
+int ophip_frame_enqueue(const ophip_frame_desc* desc, const ophip_frame_layout_t* layout, void* block,
+                        const float* feat_c, const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x,
+                        const float* keypoints3d, long long kpts_bstride, const float* desc3d_c, long long desc_c_bstride,
+                        const float* desc3d_f, long long desc_f_bstride, long long desc_f_cstride, const float* x3d_external,
+                        void* host_dst, size_t host_bytes, void* s_main, void* s_prep, void* s_fine, void* s_copy, int* slot);
+int ophip_frame_wait(int slot);
+int ophip_frame_order_after_fine(void* compute_stream);
+
 /* Row f-1 -- ResNetFPN_8_2 image backbone (backbone/resnet.py:20-44 BasicBlock, :85-164; called at
  * OnePosePlusModel.py:121-131) as implicit-GEMM convolutions on the bf16 matrix pipe.
  * Feature maps between layers are channels-last bf16 plane pairs (hi, lo) [B][H][W][c_pad], c_pad = channels rounded up

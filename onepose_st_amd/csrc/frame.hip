@@ -1,0 +1,206 @@
+// One call per frame: the launch sequence of onepose_st_amd/model.py's default (split-bf16) path -- rows a1-a11 of
+// DESIGN.md section 1 on three streams (input kernels | encoder + coarse matching | select + fine stage) plus the read-back of the
+// result block -- issued from C.  The Python loop spends ~0.4 ms per frame on ~27 ctypes calls, ~20 tensor allocations and
+// ~10 stream / event operations; this entry point takes one device block (laid out by ophip_frame_layout) and returns after
+// enqueueing everything (~0.1 ms).  Reference: OnePosePlusModel.py:115-203 (forward after the backbone).
+// Host code only: every kernel is launched through the stage entry points of this library.
+#include "tile.h"
+#include "onepose_hip.h"
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+constexpr int kSlots = 16;          // frames that may be in flight between enqueue and wait
+struct Slot {
+    hipEvent_t prep_done = nullptr, coarse_done = nullptr, fine_done = nullptr, ready = nullptr;
+    int dev = -1;
+};
+struct DevState {
+    Slot slots[kSlots];
+    int next = 0;
+    std::unordered_map<hipStream_t, hipEvent_t> last_fine;      // compute stream -> fine_done of the last frame enqueued on it
+};
+std::mutex g_mu;
+std::unordered_map<int, DevState> g_dev;
+
+size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+int make_events(Slot& s, int dev) {
+    if (s.ready && s.dev == dev) return 0;
+    hipEvent_t* ev[4] = {&s.prep_done, &s.coarse_done, &s.fine_done, &s.ready};
+    for (auto e : ev) {
+        hipError_t rc = hipEventCreateWithFlags(e, hipEventDisableTiming);
+        if (rc != hipSuccess) return ophip_fail(rc, "hipEventCreateWithFlags(frame)");
+    }
+    s.dev = dev;
+    return 0;
+}
+
+}  // namespace
+
+#define FR_CHECK(call)                                  \
+    do {                                                \
+        const int rc__ = (call);                        \
+        if (rc__ != 0) return rc__;                     \
+    } while (0)
+#define FR_HIP(call, what)                              \
+    do {                                                \
+        const hipError_t e__ = (call);                  \
+        if (e__ != hipSuccess) return ophip_fail(e__, what); \
+    } while (0)
+
+extern "C" int ophip_frame_layout(const ophip_frame_desc* d, int transpose_fine, int external_x3d, ophip_frame_layout_t* L) {
+    if (!d || !L) return ophip_bad_arg(__func__, "null pointer");
+    if (d->B < 1 || d->N < 1 || d->M < 1 || d->hc * d->wc != d->M || d->n_coarse < 1 || d->n_coarse > 16 || d->cf < 1)
+        return ophip_bad_arg(__func__, "bad sizes");
+    const size_t B = d->B, N = d->N, M = d->M, cap = B * N, C = 256;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o = up256(o + bytes); return at; };
+    L->x2d = take(B * M * C * 4);
+    L->ffcl = transpose_fine ? take(B * (size_t)d->hf * d->wf * d->cf * 4) : 0;
+    L->x3d = external_x3d ? 0 : take(B * N * C * 4);
+    L->y3d = take(B * N * C * 4);
+    L->y2d = take(B * M * C * 4);
+    L->z3d = external_x3d ? take(B * N * C * 4) : 0;
+    L->stats = take((4 * B + 4) * 4);
+    L->enc_ws = take(ophip_encoder_x3w8_workspace_bytes(d->B, d->N, d->M));
+    L->conf = take(B * N * M * 4);
+    L->cws = take(ophip_coarse_workspace_floats(d->B, d->N, d->M) * 4);
+    L->result = take(16 + 28 * cap);
+    L->i_ids = take(cap * 8);
+    L->j_ids = take(cap * 8);
+    L->m_bids = take(cap * 8);
+    L->gt_mask = take(cap);
+    L->mconf = take(cap * 4);
+    L->mkc = take(cap * 8);
+    L->expec = take(cap * 12);
+    L->total = o;
+    L->result_bytes = 16 + 28 * cap;
+    return 0;
+}
+
+extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_layout_t* L, void* blob_,
+                                   const float* feat_c, const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x,
+                                   const float* kpts, long long kpts_bs, const float* desc_c, long long desc_c_bs,
+                                   const float* desc_f, long long desc_f_bs, long long desc_f_cs, const float* x3d_external,
+                                   void* host_dst, size_t host_bytes, void* s_main_, void* s_prep_, void* s_fine_, void* s_copy_,
+                                   int* slot_out) {
+    if (!d || !L || !blob_ || !feat_c || !feat_f || !kpts || !desc_c || !desc_f || !host_dst || !s_fine_ || !s_copy_ || !slot_out)
+        return ophip_bad_arg(__func__, "null pointer");
+    if (host_bytes < 16 || host_bytes > L->result_bytes) return ophip_bad_arg(__func__, "host_bytes");
+    if ((L->x3d == 0) != (x3d_external != nullptr)) return ophip_bad_arg(__func__, "x3d_external does not match the layout");
+    char* blob = static_cast<char*>(blob_);
+    hipStream_t s_main = (hipStream_t)s_main_, s_prep = (hipStream_t)s_prep_, s_fine = (hipStream_t)s_fine_, s_copy = (hipStream_t)s_copy_;
+    const int B = d->B, N = d->N, M = d->M, cap = B * N;
+    int dev = 0;
+    FR_HIP(hipGetDevice(&dev), "hipGetDevice");
+    Slot* slot;
+    int idx;
+    hipEvent_t prev_fine = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        DevState& st = g_dev[dev];
+        idx = st.next;
+        st.next = (st.next + 1) % kSlots;
+        slot = &st.slots[idx];
+        FR_CHECK(make_events(*slot, dev));
+        auto it = st.last_fine.find(s_main);
+        if (it != st.last_fine.end()) prev_fine = it->second;
+        if (st.last_fine.size() > 64) st.last_fine.clear();
+        st.last_fine[s_main] = slot->fine_done;
+    }
+    auto F = [&](size_t off) { return reinterpret_cast<float*>(blob + off); };
+    auto I64 = [&](size_t off) { return reinterpret_cast<long long*>(blob + off); };
+
+    // ---- input kernels (a1-a3 + the fine map's transpose): on their own stream when the caller's tensors are complete ----------
+    hipStream_t sin = s_prep ? s_prep : s_main;
+    float* x2d = F(L->x2d);
+    FR_CHECK(ophip_pe_add_transpose(feat_c, d->pe, x2d, B, 256, M, sin));
+    const float* ff = feat_f;
+    if (L->ffcl) {                                          // NCHW fine map -> channels-last rows (fs_* then describe the copy)
+        FR_CHECK(ophip_transpose_cl(feat_f, F(L->ffcl), B, d->cf, d->hf * d->wf, sin));
+        ff = F(L->ffcl);
+        fs_b = (long long)d->hf * d->wf * d->cf; fs_c = 1; fs_y = (long long)d->wf * d->cf; fs_x = d->cf;
+    }
+    float* x3d = x3d_external ? const_cast<float*>(x3d_external) : F(L->x3d);
+    if (!x3d_external) {
+        if (d->w_kpt) FR_CHECK(ophip_kpt_encode(kpts, kpts_bs, desc_c, desc_c_bs, d->w_kpt, F(L->stats), x3d, B, N, sin));
+        else {
+            if (B > 1 && desc_c_bs == 0) return ophip_bad_arg(__func__, "shared descriptors need the keypoint encoder");
+            FR_CHECK(ophip_transpose_cl(desc_c, x3d, B, 256, N, sin));
+        }
+    }
+    if (s_prep) {
+        FR_HIP(hipEventRecord(slot->prep_done, s_prep), "hipEventRecord(prep)");
+        FR_HIP(hipStreamWaitEvent(s_main, slot->prep_done, 0), "hipStreamWaitEvent(prep)");
+    }
+    // ---- a4-a6: coarse encoder; attn_apply never shares the chip with the previous frame's fine stage -------------------------
+    if (prev_fine) FR_HIP(hipStreamWaitEvent(s_main, prev_fine, 0), "hipStreamWaitEvent(previous fine)");
+    float *y3d = F(L->y3d), *y2d = F(L->y2d), *y2 = y2d, *x2 = x2d;
+    float* z3d = x3d_external ? F(L->z3d) : x3d;          // a cached encoding is read-only: ping-pong between y and z
+    float *x3 = x3d, *y3 = y3d;
+    for (int li = 0; li < d->n_coarse; ++li) {
+        const void* nxt = li + 1 < d->n_coarse ? d->w_coarse[li + 1] : nullptr;
+        FR_CHECK(ophip_encoder_layer_x3w8(x3, x2, y3, y2, B, N, M, d->w_coarse[li], nxt, (d->coarse_cross_bits >> li) & 1, li > 0 ? 1 : 0, li & 1,
+                                          blob + L->enc_ws, s_main));
+        float* nx3 = y3;
+        y3 = li == 0 ? z3d : x3;
+        x3 = nx3;
+        float* t2 = x2; x2 = y2; y2 = t2;
+    }
+    // ---- a7 + a8: coarse matching; selection, fine stage and read-back on their side streams -----------------------------------
+    float* conf = F(L->conf);
+    float* cws = F(L->cws);
+    int* count = reinterpret_cast<int*>(blob + L->result);
+    long long* b_ids = I64(L->result + 16);
+    float* mk3d = F(L->result + 16 + 8 * (size_t)cap);
+    float* mk2d = F(L->result + 16 + 20 * (size_t)cap);
+    unsigned char* gt_mask = reinterpret_cast<unsigned char*>(blob + L->gt_mask);
+    FR_CHECK(ophip_coarse_match_conf(x3, x2, kpts, kpts_bs, B, N, M, d->wc, d->temperature, d->thr, d->border_rm, d->scale_c, conf, cws,
+                                     b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count, 3, s_main));
+    FR_HIP(hipEventRecord(slot->coarse_done, s_main), "hipEventRecord(coarse)");
+    FR_HIP(hipStreamWaitEvent(s_fine, slot->coarse_done, 0), "hipStreamWaitEvent(coarse)");
+    FR_CHECK(ophip_coarse_match_select(x3, x2, kpts, kpts_bs, B, N, M, d->wc, d->temperature, d->thr, d->border_rm, d->scale_c, conf, cws,
+                                       b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count, 3, s_fine));
+    // ---- a9-a11: fine refinement (grid sized by capacity, device-side count) ----------------------------------------------------
+    FR_CHECK(ophip_fine_refine_bf16(ff, fs_b, fs_c, fs_y, fs_x, d->hf, d->wf, desc_f, desc_f_bs, desc_f_cs, b_ids, I64(L->i_ids), I64(L->j_ids), count, cap,
+                                    F(L->mkc), d->w_fine, d->n_fine, d->fine_cross_bits, d->fine_encoder_enable, 3, d->wc, d->hf / d->hc, d->fine_scale,
+                                    F(L->expec), mk2d, nullptr, nullptr, s_fine));
+    FR_HIP(hipEventRecord(slot->fine_done, s_fine), "hipEventRecord(fine)");
+    // ---- read-back of the result block (count | b_ids | 3D points | refined 2D points) behind the fine stage ---------------------
+    FR_HIP(hipStreamWaitEvent(s_copy, slot->fine_done, 0), "hipStreamWaitEvent(fine)");
+    FR_HIP(hipMemcpyAsync(host_dst, blob + L->result, host_bytes, hipMemcpyDeviceToHost, s_copy), "hipMemcpyAsync(result block)");
+    FR_HIP(hipEventRecord(slot->ready, s_copy), "hipEventRecord(ready)");
+    *slot_out = idx;
+    return 0;
+}
+
+extern "C" int ophip_frame_wait(int slot) {
+    if (slot < 0 || slot >= kSlots) return ophip_bad_arg(__func__, "slot");
+    int dev = 0;
+    FR_HIP(hipGetDevice(&dev), "hipGetDevice");
+    hipEvent_t ev;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        ev = g_dev[dev].slots[slot].ready;
+    }
+    if (!ev) return ophip_bad_arg(__func__, "slot was never used on this device");
+    FR_HIP(hipEventSynchronize(ev), "hipEventSynchronize(frame)");
+    return 0;
+}
+
+extern "C" int ophip_frame_order_after_fine(void* compute_stream) {
+    int dev = 0;
+    FR_HIP(hipGetDevice(&dev), "hipGetDevice");
+    hipEvent_t ev = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto& m = g_dev[dev].last_fine;
+        auto it = m.find((hipStream_t)compute_stream);
+        if (it != m.end()) { ev = it->second; m.erase(it); }
+    }
+    if (ev) FR_HIP(hipStreamWaitEvent((hipStream_t)compute_stream, ev, 0), "hipStreamWaitEvent(fine)");
+    return 0;
+}

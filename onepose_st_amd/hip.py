@@ -19,6 +19,25 @@ c_f = ctypes.c_void_p      # device float*
 c_i = ctypes.c_int
 c_ll = ctypes.c_longlong
 
+
+
+class FrameDesc(ctypes.Structure):
+    """``ophip_frame_desc`` (include/onepose_hip.h)"""
+    _fields_ = [("B", c_i), ("N", c_i), ("M", c_i), ("hc", c_i), ("wc", c_i), ("hf", c_i), ("wf", c_i), ("cf", c_i),
+                ("n_coarse", c_i), ("coarse_cross_bits", ctypes.c_uint),
+                ("n_fine", c_i), ("fine_cross_bits", ctypes.c_uint), ("fine_encoder_enable", c_i),
+                ("border_rm", c_i),
+                ("thr", ctypes.c_float), ("scale_c", ctypes.c_float), ("fine_scale", ctypes.c_float),
+                ("temperature", ctypes.c_double),
+                ("pe", ctypes.c_void_p), ("w_kpt", ctypes.c_void_p), ("w_coarse", ctypes.c_void_p * 16), ("w_fine", ctypes.c_void_p)]
+
+
+class FrameLayout(ctypes.Structure):
+    """``ophip_frame_layout_t``: byte offsets inside the frame's device block"""
+    _fields_ = [(n, ctypes.c_size_t) for n in ("total", "result_bytes", "x2d", "ffcl", "x3d", "y3d", "y2d", "z3d", "stats", "enc_ws", "conf", "cws",
+                                               "result", "i_ids", "j_ids", "m_bids", "gt_mask", "mconf", "mkc", "expec")]
+
+
 _SIGNATURES = {
     "ophip_abi_version": (c_i, []),
     "ophip_last_error": (ctypes.c_char_p, []),
@@ -27,6 +46,13 @@ _SIGNATURES = {
     "ophip_timing_read": (c_i, [ctypes.POINTER(c_i), ctypes.POINTER(ctypes.c_double)]),
     "ophip_timing_every": (c_i, [c_i]),
     "ophip_debug_stamps": (c_i, [ctypes.c_void_p]),
+    "ophip_frame_layout": (c_i, [ctypes.POINTER(FrameDesc), c_i, c_i, ctypes.POINTER(FrameLayout)]),
+    "ophip_frame_enqueue": (c_i, [ctypes.POINTER(FrameDesc), ctypes.POINTER(FrameLayout), ctypes.c_void_p,
+                                  c_f, c_f, c_ll, c_ll, c_ll, c_ll, c_f, c_ll, c_f, c_ll, c_f, c_ll, c_ll, c_f,
+                                  ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                  ctypes.POINTER(c_i)]),
+    "ophip_frame_wait": (c_i, [c_i]),
+    "ophip_frame_order_after_fine": (c_i, [ctypes.c_void_p]),
     "ophip_pe_add_transpose": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_void_p]),
     "ophip_transpose_cl": (c_i, [c_f, c_f, c_i, c_i, c_i, ctypes.c_void_p]),
     "ophip_kpt_encode": (c_i, [c_f, c_ll, c_f, c_ll, c_f, c_f, c_f, c_i, c_i, ctypes.c_void_p]),

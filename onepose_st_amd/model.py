@@ -132,6 +132,11 @@ class OnePosePlus_model(nn.Module):
         # all of its work unless the caller opts in (bench.py reports both)
         self.cache_object = bool(config.get("hip_cache_object", False))
         self._obj_cache = None
+        # the default path as ONE C call per frame (csrc/frame.hip: same kernels, same streams, one device block per frame) instead of
+        # ~27 ctypes calls + ~20 allocations + ~10 stream / event operations from Python: 0.39 -> ~0.1 ms of host time per frame
+        self.frame_call = bool(config.get("hip_frame_call", os.environ.get("OPHIP_FRAME_CALL", "1") != "0"))
+        self._frame_plans = {}
+        self._frame_call_pending = set()     # compute streams whose last frame went through the C entry point
 
         pretrained = config["loftr_backbone"]["pretrained"]
         if pretrained is not None:
@@ -276,6 +281,23 @@ class OnePosePlus_model(nn.Module):
 
         main = torch.cuda.current_stream(dev)
         fkey = (str(dev), main.cuda_stream)
+        if (self.frame_call and self.precision == "bf16x3" and self._enc_w8 and self.overlap_fine and not _pe_applied and not want_fine_debug
+                and not self.debug and isinstance(self.profiler, _NullProfiler) and bool(cfg["fine_matching"]["enable"])
+                and not os.environ.get("OPHIP_ENC_V1") and not os.environ.get("OPHIP_FINE_X3")
+                and (self.kpt_3d_pos_encoding is not None or B == 1 or desc_in_d.shape[0] == B)
+                and len(self.loftr_coarse.layer_names) <= 16):
+            x3d_ext = None
+            if self.cache_object:
+                ckey = (str(dev), B, N, kpts_d.data_ptr(), kpts_d._version, desc_in_d.data_ptr(), desc_in_d._version, id(W))
+                if self._obj_cache is not None and self._obj_cache[0] == ckey:
+                    x3d_ext = self._obj_cache[1]
+                    main.wait_event(self._obj_cache[2])
+            if not self.cache_object or x3d_ext is not None:          # a cache miss takes the stage-by-stage path below, which fills the cache
+                return self._enqueue_frame_call(data, feat_c, feat_f, kpts_d, desc_in_d, desc_fine_d, x3d_ext, W, dev, main, fkey,
+                                                B, N, M, hc, wc, hf, wf, host_copy, inputs_ready)
+        if fkey in self._frame_call_pending:                          # order this frame's encoder behind the C path's last fine stage
+            self._frame_call_pending.discard(fkey)
+            lib_call("ophip_frame_order_after_fine", ctypes.c_void_p(main.cuda_stream))
         # The input kernels (a1-a3 + the fine map's transpose) depend on nothing but the caller's tensors.  With ``inputs_ready`` the
         # caller states that those tensors are complete (no producer still queued on this stream): the kernels then go to a side
         # stream and start at once -- on the CUs the 246-workgroup encoder of the previous frame leaves idle and beside its coarse
@@ -470,6 +492,85 @@ class OnePosePlus_model(nn.Module):
         return pend
 
 
+    def _side_stream(self, table, fkey, dev):
+        st = table.get(fkey)
+        if st is None:
+            if len(table) >= 16:
+                table.pop(next(iter(table)))
+            st = table[fkey] = torch.cuda.Stream(device=dev)
+        return st
+
+    def _enqueue_frame_call(self, data, feat_c, feat_f, kpts_d, desc_in_d, desc_fine_d, x3d_ext, W, dev, main, fkey,
+                            B, N, M, hc, wc, hf, wf, host_copy, inputs_ready):
+        """The whole frame through ``ophip_frame_enqueue`` (csrc/frame.hip): one device block, one C call."""
+        cfg = self.config
+        fc = feat_c if (feat_c.dtype == torch.float32 and feat_c.is_contiguous()) else feat_c.float().contiguous()
+        ff = feat_f if feat_f.dtype == torch.float32 else feat_f.float()
+        transpose_fine = ff.stride(1) != 1
+        if transpose_fine:
+            ff = ff.contiguous()
+        cf_ch = ff.shape[1]
+        cm, lf = cfg["coarse_matching"], cfg["loftr_fine"]
+        img_h = data["q_hw_i"][0]
+        pkey = (str(dev), B, N, M, hc, wc, hf, wf, cf_ch, bool(transpose_fine), x3d_ext is not None, int(img_h), id(W))
+        plan = self._frame_plans.get(pkey)
+        if plan is None:
+            d = hip.FrameDesc()
+            d.B, d.N, d.M, d.hc, d.wc, d.hf, d.wf, d.cf = B, N, M, hc, wc, hf, wf, cf_ch
+            names_c, names_f = self.loftr_coarse.layer_names, self.loftr_fine.layer_names
+            d.n_coarse, d.coarse_cross_bits = len(names_c), sum(1 << i for i, n in enumerate(names_c) if n == "cross")
+            d.n_fine, d.fine_cross_bits = len(names_f), sum(1 << i for i, n in enumerate(names_f) if n == "cross")
+            d.fine_encoder_enable = 1 if lf["enable"] else 0
+            d.border_rm = int(cm["border_rm"])
+            d.thr, d.scale_c = float(cm["thr"]), float(img_h / hc)
+            d.fine_scale = float((lf["window_size"] // 2) * (img_h / hf))
+            d.temperature = float(cm["dual_softmax"]["temperature"])
+            pe = self._pe_table(hc, wc, dev) if self._pe_enable else None
+            d.pe = pe.data_ptr() if pe is not None else None
+            d.w_kpt = W["kpt"].data_ptr() if self.kpt_3d_pos_encoding is not None else None
+            for li in range(len(names_c)):
+                d.w_coarse[li] = W["coarse_x3"][li].data_ptr()
+            d.w_fine = W["fine_bf16"].data_ptr()
+            L = hip.FrameLayout()
+            hip.call("ophip_frame_layout", ctypes.byref(d), 1 if transpose_fine else 0, 1 if x3d_ext is not None else 0, ctypes.byref(L))
+            if len(self._frame_plans) >= 8:
+                self._frame_plans.pop(next(iter(self._frame_plans)))
+            plan = self._frame_plans[pkey] = (d, L, W, pe)                 # W and the table stay alive with the pointers
+        d, L = plan[0], plan[1]
+
+        def bstride(t):
+            return 0 if t.shape[0] == 1 or t.stride(0) == 0 else t.stride(0)
+        prev = self._fine_streams.get(fkey)
+        if prev is not None and prev[1] is not None:                      # a stage-by-stage frame before this one: order behind its fine stage
+            main.wait_event(prev[1])
+            prev[1] = None
+        if fkey not in self._fine_streams:
+            if len(self._fine_streams) >= 16:
+                self._fine_streams.pop(next(iter(self._fine_streams)))
+            self._fine_streams[fkey] = [torch.cuda.Stream(device=dev), None]
+        sfine = self._fine_streams[fkey][0]
+        sprep = self._side_stream(self._prep_streams, fkey, dev) if inputs_ready else None
+        scopy = self._side_stream(PendingFrame._copy_streams, (dev, main.cuda_stream), dev)
+        cap = B * N
+        blob = torch.empty(L.total, dtype=torch.uint8, device=dev)
+        nbytes = int(L.result_bytes) if host_copy else 16
+        pin = PendingFrame._take_pin((cap, bool(host_copy)), nbytes)
+        if transpose_fine:
+            fs = (0, 0, 0, 0)                                             # filled in by the callee for its channels-last copy
+        else:
+            fs = (ff.stride(0), 1, ff.stride(2), ff.stride(3))
+        slot = ctypes.c_int(-1)
+        P = hip.ptr
+        hip.call("ophip_frame_enqueue", ctypes.byref(d), ctypes.byref(L), ctypes.c_void_p(blob.data_ptr()),
+                 P(fc), P(ff), fs[0], fs[1], fs[2], fs[3], P(kpts_d), bstride(kpts_d), P(desc_in_d), bstride(desc_in_d),
+                 P(desc_fine_d), bstride(desc_fine_d), desc_fine_d.stride(1), P(x3d_ext), ctypes.c_void_p(pin.data_ptr()), nbytes,
+                 ctypes.c_void_p(main.cuda_stream), ctypes.c_void_p(sprep.cuda_stream) if sprep is not None else None,
+                 ctypes.c_void_p(sfine.cuda_stream), ctypes.c_void_p(scopy.cuda_stream), ctypes.byref(slot))
+        self._frame_call_pending.add(fkey)
+        data["conf_matrix"] = blob[L.conf:L.conf + 4 * B * N * M].view(torch.float32).view(B, N, M)
+        keep = [fc, ff, kpts_d, desc_in_d, desc_fine_d, x3d_ext, W]
+        return PendingFrame._from_block(self, data, dev, B, N, M, cap, blob, L, slot.value, pin, host_copy, keep)
+
 def _result_views(blob, cap):
     """(blob, count int32[1], b_ids int64[cap], mkpts3d f32[cap,3], mkpts2d f32[cap,2]) views of one byte block."""
     o_b, o_3, o_2 = 16, 16 + 8 * cap, 16 + 20 * cap
@@ -493,10 +594,10 @@ class PendingFrame:
         self.bufs = bufs
         self.host = None
         key = (cap, bool(host_copy))
-        pool = PendingFrame._pinned_pool.setdefault(key, [])
         nbytes = bufs["blob"].numel() if host_copy else 16
-        self._pin = pool.pop() if pool else torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        self._pin = PendingFrame._take_pin(key, nbytes)
         self._key, self._host_copy = key, bool(host_copy)
+        self._slot = None
         # the D2H of the result block runs on a side stream behind an event: on the compute stream the PCIe round trip
         # (~40 us per frame) would sit between this frame's last kernel and the next frame's first one
         main = torch.cuda.current_stream(dev)
@@ -514,6 +615,46 @@ class PendingFrame:
             self.event.record(side)
         self.done = False
 
+    @staticmethod
+    def _take_pin(key, nbytes):
+        pool = PendingFrame._pinned_pool.setdefault(key, [])
+        return pool.pop() if pool else torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+
+    @classmethod
+    def _from_block(cls, model, data, dev, B, N, M, cap, blob, layout, slot, pin, host_copy, keep):
+        """A frame enqueued by ``ophip_frame_enqueue``: outputs are views into its device block, made at ``finish()``."""
+        self = cls.__new__(cls)
+        self.model, self.data, self.dev = model, data, dev
+        self.B, self.N, self.M, self.cap, self.fine_on, self.want_dbg = B, N, M, cap, True, False
+        self.bufs, self.host = None, None
+        self._block, self._layout, self._slot, self._keep = blob, layout, slot, keep
+        self._pin, self._key, self._host_copy = pin, (cap, bool(host_copy)), bool(host_copy)
+        self.event = None
+        self.done = False
+        return self
+
+    def wait(self):
+        """Block until this frame's results (and its read-back) are complete; ``finish()`` calls it."""
+        self._wait()
+
+    def _wait(self):
+        if self._slot is not None:
+            hip.call("ophip_frame_wait", self._slot)
+        else:
+            self.event.synchronize()
+
+    def _block_views(self):
+        blob, L, cap = self._block, self._layout, self.cap
+        res = blob[L.result:L.result + L.result_bytes]
+        _, count, b_ids, mk3d, mk2d = _result_views(res, cap)
+
+        def v(off, nbytes, dt):
+            return blob[off:off + nbytes].view(dt)
+        return dict(blob=res, b_ids=b_ids, i_ids=v(L.i_ids, 8 * cap, torch.int64), j_ids=v(L.j_ids, 8 * cap, torch.int64),
+                    mconf=v(L.mconf, 4 * cap, torch.float32), mk3d=mk3d, mkc=v(L.mkc, 8 * cap, torch.float32).view(cap, 2), count=count,
+                    m_bids=v(L.m_bids, 8 * cap, torch.int64), gt_mask=v(L.gt_mask, cap, torch.bool),
+                    expec=v(L.expec, 12 * cap, torch.float32).view(cap, 3), mkf=mk2d, dbg_w=None, dbg_3=None, keep=self._keep)
+
     def _release_pin(self):
         if self._pin is not None:
             pool = PendingFrame._pinned_pool.setdefault(self._key, [])
@@ -528,7 +669,7 @@ class PendingFrame:
         if self.done or self._pin is None:
             return
         try:
-            self.event.synchronize()
+            self._wait()
         finally:
             self._release_pin()
             self.done = True
@@ -543,13 +684,15 @@ class PendingFrame:
         """Wait for this frame (event), read K, fill ``data`` exactly like the reference's ``forward``."""
         if self.done:
             return self.data
-        self.event.synchronize()                    # the one host wait of the frame
+        self._wait()                                # the one host wait of the frame
         K = int(self._pin[:4].view(torch.int32)[0])
         B, N, M, cap = self.B, self.N, self.M, self.cap
         if self._host_copy:
             _, _, hb, h3, h2 = _result_views(self._pin, cap)
             self.host = {"K": K, "mkpts_3d_db": h3[:K].numpy().copy(), "mkpts_2d": h2[:K].numpy().copy(), "b_ids": hb[:K].numpy().copy()}
         self._release_pin()
+        if self.bufs is None:
+            self.bufs = self._block_views()
         bf = self.bufs
         data, dev = self.data, self.dev
         b_ids, i_ids, j_ids = bf["b_ids"][:K], bf["i_ids"][:K], bf["j_ids"][:K]

@@ -262,6 +262,30 @@ def test_coarse_match_vs_oracle(dev, B, N, hc, wc, nsplit, rtol):
     assert torch.equal(mk3.cpu(), ref["mkpts_3d_db"]) and torch.equal(mkc.cpu(), ref["mkpts_query_c"])
 
 
+@pytest.mark.parametrize("nsplit,rtol", [(0, 1e-4), (3, 1e-3)])
+def test_coarse_match_wide_logit_range(dev, nsplit, rtol):
+    """A few very strong pairs (logit ~110) among ordinary ones (|logit| < 10) in interior 128 x 128 tiles: the bf16 modes' tile
+    kernel takes the tile maximum as the reference of its row / column sums, so the other rows' partials would underflow -- those
+    tiles must fall back to the exact sweep, and the merged statistics (references far above a row's own maximum) must not
+    overflow in the conf pass (log form).  N = M = 512: 4 x 4 tiles, none cut by the matrix edge."""
+    hc, wc, N = 16, 32, 512
+    g = torch.Generator().manual_seed(11)
+    f3 = torch.randn(1, N, 256, generator=g) * 1.5
+    f2 = torch.randn(1, hc * wc, 256, generator=g)
+    rows = torch.randperm(N, generator=g)[:24]
+    cells = torch.randperm(hc * wc, generator=g)[:24]
+    f2[0, cells] = f3[0, rows] * 4.0
+    kp = torch.randn(1, N, 3, generator=g)
+    ref_conf = orc.dual_softmax_confidence(f3, f2, 0.08)
+    ref = orc.coarse_match_select(ref_conf, (hc, wc), (hc * 8, wc * 8), kp, 0.1, 2)
+    conf, (b_ids, i_ids, j_ids), mconf, mk3, mkc = _coarse_match(dev, f3, f2, kp, wc, nsplit=nsplit)
+    assert bool(torch.isfinite(conf).all())
+    close(conf, ref_conf, rtol=rtol, atol=1e-7, msg="conf_matrix")
+    assert len(ref["i_ids"]) >= 10
+    assert torch.equal(i_ids.cpu(), ref["i_ids"]) and torch.equal(j_ids.cpu(), ref["j_ids"])
+    close(mconf, ref["mconf"], rtol=rtol, atol=1e-6)
+
+
 def test_coarse_match_tie_and_border_semantics(dev):
     """Exact ties: two identical 2D cells, the first of them in the removed border.  The reference mask
     (coarse_matching.py:145-166) is false at the border copy and true at the interior copy, so `mask.max(dim=2)`
@@ -674,6 +698,36 @@ def test_input_kernels_on_the_side_stream_are_bit_identical(sd, cfg, dev):
         assert len(a["i_ids"]) > 200
         for k in keys:
             assert torch.equal(a[k], b[k]), k
+
+
+def test_frame_call_equals_the_stage_by_stage_path(sd, cfg, dev):
+    """config["hip_frame_call"] (default on): the frame as ONE C call (csrc/frame.hip, one device block) against the same frame issued
+    stage by stage from Python -- every output bit for bit, NCHW and channels-last fine maps, with and without the input stream,
+    and interleaved with stage-by-stage frames on the same stream."""
+    keys = ("b_ids", "i_ids", "j_ids", "m_bids", "gt_mask", "mconf", "mkpts_3d_db", "mkpts_query_c", "mkpts_query_f", "expec_f", "conf_matrix")
+    c_on, c_off = copy.deepcopy(cfg), copy.deepcopy(cfg)
+    c_on["hip_frame_call"], c_off["hip_frame_call"] = True, False
+    models = []
+    for c in (c_on, c_off):
+        m = OnePosePlus_model(c).eval()
+        m.load_state_dict(sd, strict=True)
+        models.append(m.to(dev))
+    fast, slow = models
+    assert fast.frame_call and not slow.frame_call
+    frames = [make_synthetic_inputs(sd, n_points=900, image_hw=(128, 160), n_plant=350, seed=47, config=cfg, frame=f) for f in range(3)]
+    obj = {k: frames[0][k].to(dev) for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db")}
+    for f in frames:
+        fc, ff = f["feat_c"].to(dev), f["feat_f"].to(dev)
+        for ffv in (ff, ff.contiguous(memory_format=torch.channels_last)):
+            a, b, c = dict(obj), dict(obj), dict(obj)
+            slow.forward_features(a, fc, ffv, f["image_hw"])
+            fast.forward_features(b, fc, ffv, f["image_hw"])
+            torch.cuda.synchronize()
+            fast.enqueue_features(c, fc, ffv, f["image_hw"], inputs_ready=True, host_copy=True).finish()
+            assert len(a["i_ids"]) > 150
+            for k in keys:
+                assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
+    assert fast._frame_plans and not slow._frame_plans
 
 
 def test_object_cache_is_bit_identical(sd, cfg, dev):

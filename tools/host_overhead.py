@@ -25,7 +25,7 @@ tw0 = time.perf_counter()
 for _ in range(N):
     t = time.perf_counter(); cur = model.enqueue_features(dict(obj), fc, ff, hw, host_copy=HC); t_enq += time.perf_counter() - t
     if prev is not None:
-        t = time.perf_counter(); prev.event.synchronize(); t_wait += time.perf_counter() - t
+        t = time.perf_counter(); prev.wait(); t_wait += time.perf_counter() - t
         t = time.perf_counter(); prev.finish()
         if pool is not None:
             if prev.host is not None:
