@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames per rank (cycled)")
     ap.add_argument("--precision", default=os.environ.get("OPHIP_PRECISION", "bf16x3"), choices=["f32", "bf16x3", "bf16"],
                     help="matrix arithmetic of the encoder kernels (see DESIGN.md section 4)")
+    ap.add_argument("--main-region-only", action="store_true",
+                    help="skip the side measurements (other PnP policy, matcher only, object cache): the process then runs the contract's region "
+                         "alone -- what tools/run_profile_r02.sh traces, so that the rocprofv3 averages describe the same conditions as the line")
     ap.add_argument("--inputs-behind", action="store_true",
                     help="queue the input kernels (PE, transposes, keypoint encoding) behind the previous frame on the compute stream instead of "
                          "on a side stream (the feature maps and the object block are resident and complete here, so the side stream is legitimate)")
@@ -305,14 +308,17 @@ def main():
 
     # side measurements first (the other PnP policy, the matcher alone), the contract's region last with the kernel timing on
     other = {"reference": "adaptive", "adaptive": "reference"}[args.pnp_policy]
-    dt_other = timed_region(pools[other]) if pools else None
-    dt_matcher = timed_region(None)
-    model.cache_object = True                           # per-object cache of the keypoint encoding (config["hip_cache_object"]): a sequence's
-    dt_cached = timed_region(None)                      # frames share one resident object block; matcher only, to compare with dt_matcher
-    model.cache_object, model._obj_cache = False, None
-    # an event pair costs the stream 2-3 us: bracketing all 6 launches of every frame takes 5 % off `value` (1078 vs 1137 frames/s);
-    # every 7th launch (coprime with the 6 layers, so every layer is sampled equally) gives the same average
-    time_every = int(os.environ.get("OPHIP_BENCH_TIME_EVERY", "7"))
+    dt_other = dt_matcher = dt_cached = None
+    if not args.main_region_only:
+        dt_other = timed_region(pools[other]) if pools else None
+        dt_matcher = timed_region(None)
+        model.cache_object = True                       # per-object cache of the keypoint encoding (config["hip_cache_object"]): a sequence's
+        dt_cached = timed_region(None)                  # frames share one resident object block; matcher only, to compare with dt_matcher
+        model.cache_object, model._obj_cache = False, None
+    # the timed launches carry a start / stop event pair filled with the dispatch's own timestamps (hipExtLaunchKernelGGL); such a launch
+    # costs the stream a few us more than a plain one: timing all 6 launches of every frame took 9 % off `value`, every 11th launch
+    # (coprime with the 6 layers, so every layer is sampled equally) ~2 %, with the same average
+    time_every = int(os.environ.get("OPHIP_BENCH_TIME_EVERY", "11"))
     hip.timing_select("attn_apply", every=time_every)
     dt = timed_region(pools.get(args.pnp_policy))
     if os.environ.get("OPHIP_BENCH_TRACE") and rank == 0:
@@ -346,10 +352,10 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "setup_steps_untimed": setup_steps + 4 * args.warmup,      # settle blocks before the W warm-up steps + the warm-ups of the side regions
+        "setup_steps_untimed": setup_steps + (1 if args.main_region_only else 4) * args.warmup,      # settle blocks before the W warm-up steps + the warm-ups of the side regions
         "ms_per_step": dt / args.steps * 1e3,
-        "value_matcher_only": frames_total / dt_matcher,
-        "value_matcher_only_object_cached": frames_total / dt_cached,
+        "value_matcher_only": (frames_total / dt_matcher) if dt_matcher else None,
+        "value_matcher_only_object_cached": (frames_total / dt_cached) if dt_cached else None,
         ("value_pnp_" + other): (frames_total / dt_other) if dt_other else None,
         "higher_is_better": True,
         "scaling": "weak",

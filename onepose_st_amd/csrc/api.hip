@@ -48,14 +48,13 @@ int g_every = 1;             // sample: bracket every g_every-th launch of the s
 int g_seen = 0;
 }
 
-ophip_timed::ophip_timed(const char* name, hipStream_t s) : slot(-1), stream(s) {
-    if (g_sel[0] == 0 || strcmp(name, g_sel) != 0 || g_used >= kMaxEvents) return;
-    if (g_seen++ % g_every != 0) return;
-    slot = g_used++;
-    (void)hipEventRecord(g_start[slot], stream);
-}
-ophip_timed::~ophip_timed() {
-    if (slot >= 0) (void)hipEventRecord(g_stop[slot], stream);
+bool ophip_timed_events(const char* name, hipEvent_t* start, hipEvent_t* stop) {
+    if (g_sel[0] == 0 || strcmp(name, g_sel) != 0 || g_used >= kMaxEvents) return false;
+    if (g_seen++ % g_every != 0) return false;
+    const int slot = g_used++;
+    *start = g_start[slot];
+    *stop = g_stop[slot];
+    return true;
 }
 
 extern "C" int ophip_timing_select(const char* kernel_name) {

@@ -19,6 +19,7 @@
 //     KV as the B operand of phi(Q) KV without touching LDS.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -150,20 +151,20 @@ int ophip_bad_arg(const char* where, const char* what);
 // raise a kernel's dynamic-LDS limit (cached per kernel and device)
 int ophip_lds_attr(const void* fn, size_t bytes, const char* what);
 
-// Optional per-kernel HIP-event timing (bench.py's roofline leg): when `name` is the kernel selected with
-// ophip_timing_select(), the scope records an event pair around the launch on the launch stream.
-struct ophip_timed {
-    ophip_timed(const char* name, hipStream_t s);
-    ~ophip_timed();
-    int slot;
-    hipStream_t stream;
-};
+// Optional per-kernel HIP-event timing (bench.py's roofline leg): when NAME is the kernel selected with ophip_timing_select(), the
+// launch goes through hipExtLaunchKernelGGL with a start / stop event pair, which the runtime fills with the dispatch's OWN begin
+// and end timestamps -- the kernel's duration as rocprofv3 reports it, with no extra barrier packets on the stream (an
+// hipEventRecord pair around the launch read 7 us more than the trace at c2 and cost the stream 2-3 us per pair).
+bool ophip_timed_events(const char* name, hipEvent_t* start, hipEvent_t* stop);
 
-// launch + optional event bracket; NAME is the string ophip_timing_select() matches
-#define OPHIP_LAUNCH(NAME, STREAM, ...)                         \
-    do {                                                        \
-        ophip_timed t__(NAME, (STREAM));                        \
-        hipLaunchKernelGGL(__VA_ARGS__);                        \
+// launch + optional event pair; NAME is the string ophip_timing_select() matches
+#define OPHIP_LAUNCH(NAME, STREAM, KERNEL, GRID, BLOCK, LDSBYTES, STREAM2, ...)                                  \
+    do {                                                                                                         \
+        hipEvent_t s__ = nullptr, e__ = nullptr;                                                                 \
+        if (ophip_timed_events(NAME, &s__, &e__))                                                                \
+            hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, LDSBYTES, STREAM2, s__, e__, 0, __VA_ARGS__);             \
+        else                                                                                                     \
+            hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDSBYTES, STREAM2, __VA_ARGS__);                             \
     } while (0)
 
 // Diagnostic cycle stamps (NULL in production): ophip_debug_stamps(buf) makes the instrumented kernels record

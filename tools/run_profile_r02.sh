@@ -9,7 +9,7 @@ O=gpurun_out/r02prof
 mkdir -p $O
 python3 bench.py --steps 100 --warmup 10 > $O/bench.json 2> $O/bench.err
 cat $O/bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --main-region-only > $O/bench_under_rocprof.json 2> $O/prof.err
 echo stats done
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-pnp > /dev/null 2> $O/pmc_f.err
 echo fetch done
