@@ -2,14 +2,16 @@
 // Reference: utils/coarse_matching.py:76-123 (forward: sim = <A/sqrt(C), Bq/sqrt(C)> / (T + 1e-4),
 // conf = softmax(sim, dim=1) * softmax(sim, dim=2)) and :125-242 (get_coarse_match, inference branch).
 //
-// Launch chain (all f32, deterministic -- no float atomics, every cross-workgroup reduction is a
-// fixed-order combine of per-tile partials):
-//   sim_stats     128x128 tiles of S = A Bq^T / (256 T') on v_mfma_f32_32x32x2_f32, LDS-staged K chunks;
-//                 writes S into the conf buffer and per-tile (max, sum exp) for rows and columns
+// Launch chain (deterministic -- no float atomics, every cross-workgroup reduction is a fixed-order combine of per-tile
+// partials):
+//   frag_planes   (bf16 modes) both inputs once into (hi, lo) bf16 MFMA operand fragments, scaled by 1/sqrt(C)
+//   sim_frag      (bf16 modes) 128x128 tiles of S on v_mfma_f32_32x32x16_bf16, operands by LDS-DMA into a four-buffer ring;
+//   sim_stats     (exact-f32 mode) the same tiles on v_mfma_f32_32x32x2_f32 with LDS-staged K chunks;
+//                 both write S into the conf buffer and per-tile (max, sum exp) partials for rows and columns
 //   stat_combine  online-softmax merge of the partials -> row (max, sum), column (max, sum)
-//   conf          in-place S -> conf, coalesced 16 B/lane streaming (HBM-bound); per row the best
-//                 (value, lowest j, tie count) as partials; column maxima by integer atomicMax on the
-//                 float bits (max is order independent => still deterministic)
+//   conf          in-place S -> conf, coalesced 16 B/lane streaming (HBM-bound); per row the best candidate above the
+//                 threshold (value, lowest j, tie count) as partials; column maxima of the candidates by integer atomicMax
+//                 on the float bits (max is order independent => still deterministic)
 //   select        threshold (strict >), border removal (top/left only: the reference's `-b:0` slices are
 //                 empty), mutual test, first-true-j semantics on exact ties, compaction in ascending (b, i)
 #include "tile_bf16.h"
@@ -43,23 +45,11 @@ __device__ __forceinline__ void merge_ms(float& m, float& e, float m2, float e2)
     m = mm;
 }
 
-__device__ __forceinline__ float half_max(float v) {     // over the 32 lanes that share lane>>5
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ float half_sum(float v) {
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-// Shared epilogue of the similarity kernels.  The S tile (128 x 128 f32) is staged through LDS (row pitch 130 floats:
-// conflict-free for the two-lanes-per-row / per-column sweeps below), then
+// Epilogue of the round-1 similarity kernels (exact-f32 mode; OPHIP_SIM_V1).  The S tile (128 x 128 f32) is staged through LDS
+// (row pitch 130 floats: conflict-free for the two-lanes-per-row / per-column sweeps below), then
 //   * stored with whole-row 16-byte accesses (the accumulator layout would need 64 scalar stores per lane),
 //   * reduced to per-row and per-column (max, sum exp): two lanes per row (resp. column), each sweeping every other
 //     element sequentially -- no cross-lane shuffles except the final pair merge.
-// In-kernel stamps had the previous register-level epilogue (640 shuffles per wave) at 63 % of the kernel.
 constexpr int SLD = 130;
 constexpr size_t SIM_STAGE_BYTES = (size_t)TM * SLD * sizeof(float);        // 66 560
 
