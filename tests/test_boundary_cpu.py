@@ -93,3 +93,38 @@ def test_custom_ops_are_registered_without_a_cpu_implementation():
         torch.ops.onepose_hip.pe_add_transpose(torch.zeros(1, 256, 2, 2), None, torch.zeros(1, 4, 256))
     with pytest.raises(NotImplementedError):
         torch.ops.onepose_hip.coarse_match(torch.zeros(1, 8, 256), torch.zeros(1, 4, 256), torch.zeros(1, 8, 3), 2, 0.08, 0.1, 2, 8.0, 3)
+
+
+def test_frame_layout_is_aligned_and_disjoint():
+    """ophip_frame_layout (host arithmetic only, runs without a GPU): the one-call frame path carves every intermediate and output of a
+    frame out of one device block -- regions 256-byte aligned, pairwise disjoint, inside `total`; optional regions absent when not asked for."""
+    import ctypes
+    d = hip.FrameDesc()
+    d.B, d.N, d.M, d.hc, d.wc, d.hf, d.wf, d.cf = 2, 1000, 1200, 30, 40, 120, 160, 128
+    d.n_coarse, d.n_fine = 6, 2
+    sizes = {"x2d": 2 * 1200 * 256 * 4, "ffcl": 2 * 120 * 160 * 128 * 4, "x3d": 2 * 1000 * 256 * 4, "y3d": 2 * 1000 * 256 * 4, "y2d": 2 * 1200 * 256 * 4,
+             "z3d": 2 * 1000 * 256 * 4, "conf": 2 * 1000 * 1200 * 4, "result": 16 + 28 * 2000, "i_ids": 16000, "j_ids": 16000, "m_bids": 16000,
+             "gt_mask": 2000, "mconf": 8000, "mkc": 16000, "expec": 24000, "stats": 48}
+    for transpose_fine, external in ((1, 0), (0, 1), (0, 0)):
+        L = hip.FrameLayout()
+        hip.call("ophip_frame_layout", ctypes.byref(d), transpose_fine, external, ctypes.byref(L))
+        assert L.result_bytes == 16 + 28 * 2000
+        assert (L.ffcl != 0) == bool(transpose_fine) and (L.z3d != 0) == bool(external)
+        assert (L.x3d == 0) == bool(external) or L.x2d == 0          # x2d is the first region (offset 0)
+        regions = []
+        for name, nbytes in sizes.items():
+            off = getattr(L, name)
+            if name in ("ffcl", "z3d") and off == 0:
+                continue
+            if name == "x3d" and external:
+                continue
+            assert off % 256 == 0 and off + nbytes <= L.total, name
+            regions.append((off, off + nbytes, name))
+        for name in ("enc_ws", "cws"):
+            regions.append((getattr(L, name), getattr(L, name) + 1, name))
+        regions.sort()
+        for (a0, a1, an), (b0, b1, bn) in zip(regions, regions[1:]):
+            assert a1 <= b0, (an, bn)
+    d.M = 1201                                                      # hc * wc != M
+    with pytest.raises(ValueError):
+        hip.call("ophip_frame_layout", ctypes.byref(d), 0, 0, ctypes.byref(hip.FrameLayout()))
