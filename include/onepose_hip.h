@@ -92,6 +92,11 @@ int ophip_encoder_layer_x3(const float* x3d, const float* x2d, float* y3d, float
  * K/V formats, its own weight block (packing.pack_coarse_layer_x3w8, ophip_encoder_x3w8_wpack_bytes() bytes). */
 size_t ophip_encoder_x3w8_workspace_bytes(int B, int L3d, int L2d);
 size_t ophip_encoder_x3w8_wpack_bytes(void);
+/* ..._frag: the same layer; the output rows are also written as the similarity kernel's operand fragments (see
+ * ophip_coarse_frag_planes) -- for the LAST layer of the encoder. */
+int ophip_encoder_layer_x3w8_frag(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
+                                  const void* wpack, const void* wpack_next, int is_cross, int kv_from_prev, int slot,
+                                  void* workspace, void* frag3d, void* frag2d, void* stream);
 int ophip_encoder_layer_x3w8(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
                              const void* wpack, const void* wpack_next, int is_cross, int kv_from_prev, int slot,
                              void* workspace, void* stream);
@@ -107,6 +112,11 @@ int ophip_encoder_layer_x3w8(const float* x3d, const float* x2d, float* y3d, flo
  * temperature is passed as double so that (float)(temperature + 1e-4) matches the reference's scalar.
  * nsplit selects the arithmetic of the similarity GEMM: 0 exact f32 MFMA, 1 bf16, 3 split-bf16. */
 size_t ophip_coarse_workspace_floats(int B, int N, int M);
+/* bf16 modes: the similarity kernel reads its operands as (hi, lo) bf16 MFMA fragments that a first kernel derives from
+ * feat3d / feat2d.  A producer that writes them itself (ophip_encoder_layer_x3w8_frag) gets their place inside the workspace
+ * from ophip_coarse_frag_planes() and passes nsplit | OPHIP_COARSE_PLANES_READY: that kernel is then skipped. */
+#define OPHIP_COARSE_PLANES_READY 0x100
+int ophip_coarse_frag_planes(float* workspace, int B, int N, int M, void** planes3d, void** planes2d);
 int ophip_coarse_match(const float* feat3d, const float* feat2d, const float* keypoints3d, long long kpts_bstride,
                        int B, int N, int M, int wc, double temperature, float thr, int border_rm, float scale,
                        float* conf, float* workspace, long long* b_ids, long long* i_ids, long long* j_ids,

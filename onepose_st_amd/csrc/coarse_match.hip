@@ -15,6 +15,7 @@
 //   select        threshold (strict >), border removal (top/left only: the reference's `-b:0` slices are
 //                 empty), mutual test, first-true-j semantics on exact ties, compaction in ascending (b, i)
 #include "tile_bf16.h"
+#include "onepose_hip.h"
 #include <math.h>
 #include <stdlib.h>
 
@@ -923,6 +924,16 @@ extern "C" size_t ophip_coarse_workspace_floats(int B, int N, int M) {
 }
 
 namespace {
+// where the fragment planes of the bf16 modes live inside the workspace (behind the partials; 64-byte aligned)
+void frag_plane_ptrs(float* workspace, int B, int N, int M, char** a, char** b) {
+    const size_t ntr = (N + TM - 1) / TM, ntc = (M + TN - 1) / TN;
+    float* w2 = workspace + (size_t)B * ntc * N * 2 + (size_t)B * ntr * M * 2 + (size_t)B * N * 2 + (size_t)B * M * 2
+                + (size_t)B * conf_nspan(M) * N * 3 + (size_t)B * M;
+    w2 += (16 - ((reinterpret_cast<uintptr_t>(w2) >> 2) & 15)) & 15;
+    *a = reinterpret_cast<char*>(w2);
+    *b = *a + (size_t)B * ntr * 4 * 32768;
+}
+
 // parts: 1 = similarity / confidence kernels, 2 = select (threshold, mutual test, compaction), 3 = both
 int coarse_impl(int parts, const float* feat3d, const float* feat2d, const float* keypoints3d, long long kpts_bstride,
                 int B, int N, int M, int wc, double temperature, float thr, int border_rm, float scale,
@@ -932,7 +943,10 @@ int coarse_impl(int parts, const float* feat3d, const float* feat2d, const float
     if (!feat3d || !feat2d || !keypoints3d || !conf || !workspace || !b_ids || !i_ids || !j_ids || !mconf || !mkpts3d || !mkpts_c || !count)
         return ophip_bad_arg(__func__, "null pointer");
     if (B < 1 || N < 1 || M < 1 || wc < 1 || M % wc != 0) return ophip_bad_arg(__func__, "bad sizes (need M == hc * wc)");
+    const bool planes_ready = (nsplit & OPHIP_COARSE_PLANES_READY) != 0;       // the caller wrote the fragment planes (ophip_coarse_frag_planes)
+    nsplit &= ~OPHIP_COARSE_PLANES_READY;
     if (nsplit != 0 && nsplit != 1 && nsplit != 3) return ophip_bad_arg(__func__, "nsplit must be 0 (exact f32), 1 (bf16) or 3 (split bf16)");
+    if (planes_ready && nsplit == 0) return ophip_bad_arg(__func__, "fragment planes are an input of the bf16 modes only");
     hipStream_t stream = (hipStream_t)stream_;
     const int ntr = (N + TM - 1) / TM, ntc = (M + TN - 1) / TN, nrb = (N + CONF_ROWS - 1) / CONF_ROWS;
     const int nspan = conf_nspan(M), spanw = conf_spanw(M);
@@ -947,13 +961,13 @@ int coarse_impl(int parts, const float* feat3d, const float* feat2d, const float
     static const bool sim_v1 = getenv("OPHIP_SIM_V1") != nullptr;
     const int sel_nspan = nspan;
     if ((parts & 1) && nsplit != 0 && !sim_v1) {
-        float* w2 = colmax + (size_t)B * M;
-        w2 += (16 - ((reinterpret_cast<uintptr_t>(w2) >> 2) & 15)) & 15;                 // 64-byte aligned planes
-        char* fa_ = reinterpret_cast<char*>(w2);
-        char* fb_ = fa_ + (size_t)B * ntr * 4 * 32768;
-        FragArgs fr{feat3d, feat2d, fa_, fb_, N, M, 4 * ntr, 4 * ntc};
-        OPHIP_LAUNCH("frag_planes", stream, frag_planes_kernel, dim3(16 * (ntr + ntc), B), dim3(256), 0, stream, fr);
-        OPHIP_CHECK_LAUNCH();
+        char *fa_, *fb_;
+        frag_plane_ptrs(workspace, B, N, M, &fa_, &fb_);
+        if (!planes_ready) {
+            FragArgs fr{feat3d, feat2d, fa_, fb_, N, M, 4 * ntr, 4 * ntc};
+            OPHIP_LAUNCH("frag_planes", stream, frag_planes_kernel, dim3(16 * (ntr + ntc), B), dim3(256), 0, stream, fr);
+            OPHIP_CHECK_LAUNCH();
+        }
         SimFragArgs sf{fa_, fb_, conf, rowpart, colpart, N, M, ntr, ntc, (float)(temperature + 1e-4), ophip_stamp_buffer()};
         const int per_xcd = ((ntr + 7) / 8) * ntc;
         const void* fn = nsplit == 3 ? reinterpret_cast<const void*>(sim_frag_kernel<3>) : reinterpret_cast<const void*>(sim_frag_kernel<1>);
@@ -997,6 +1011,14 @@ int coarse_impl(int parts, const float* feat3d, const float* feat2d, const float
     return 0;
 }
 }  // namespace
+
+extern "C" int ophip_coarse_frag_planes(float* workspace, int B, int N, int M, void** planes3d, void** planes2d) {
+    if (!workspace || !planes3d || !planes2d || B < 1 || N < 1 || M < 1) return ophip_bad_arg(__func__, "bad argument");
+    char *a, *b;
+    frag_plane_ptrs(workspace, B, N, M, &a, &b);
+    *planes3d = a; *planes2d = b;
+    return 0;
+}
 
 extern "C" int ophip_coarse_match(const float* feat3d, const float* feat2d, const float* keypoints3d, long long kpts_bstride,
                                   int B, int N, int M, int wc, double temperature, float thr, int border_rm, float scale,

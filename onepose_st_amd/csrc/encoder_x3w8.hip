@@ -41,6 +41,8 @@ struct EncW8Args {
     const float* ln;
     float* partial;
     unsigned long long* stamps;
+    char* frag[2];             // optional: the output rows also as the similarity kernel's operand fragments (csrc/coarse_match.hip:
+    int frag_rows[2];          // frag_planes layout, rows padded to frag_rows = a multiple of 128); NULL: not written
 };
 
 __device__ __forceinline__ int stash_off(int row, int chunk) { return row * (C * 4) + ((chunk ^ (row & 15)) << 4); }
@@ -323,6 +325,16 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
     }
     __syncthreads();                                 // also: every wave is done with the X planes
     float* yg = a.y[s] + (size_t)b * a.ybs[s];
+    const int frag_rows = a.frag_rows[s];
+    char* fragp = a.frag[s] ? a.frag[s] + (size_t)b * (frag_rows / 32) * 32768 : nullptr;
+    if (fragp && lt == a.tiles[s] - 1) {           // rows between this stream's last workgroup and the 128-row padding: zeros
+        const int r0 = a.tiles[s] * TOK;
+        for (int i = threadIdx.x; i < (frag_rows - r0) * 64; i += NW * 64) {      // 16-byte chunks: (row, k-step, plane, half)
+            const int row = r0 + (i >> 6), c = i & 63, ks = c >> 2, plane = (c >> 1) & 1, half = c & 1;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(fragp + ((size_t)(row >> 5) * 16 + ks) * 2048 + plane * 1024 + 16 * ((row & 31) + 32 * half)) = z;
+        }
+    }
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
         float mean, rstd;
@@ -336,6 +348,20 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
             if (tok < L) *reinterpret_cast<f32x4*>(yg + (size_t)tok * C + 32 * fw + 16 * ft + 4 * q) = v;
             else v = zero4();
             if (tail) store_quad(v, XH, XL, ROWB, tt, c16, 32 * fw + 16 * ft + 4 * q);
+            if (fragp && tok < frag_rows) {
+                // features 32 fw + 16 ft + 4 q ..+3 of row tok -> k-step 2 fw + ft, half q >> 1, elements 4 (q & 1) ..+3 of lane slot
+                // (tok % 32) + 32 (q >> 1) in the 1 KiB fragment of row tile tok / 32; scaled by 1/16 like frag_planes_kernel
+                bf16x4 vh, vl;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    __bf16 hh, ll;
+                    split_bf16(v[r] * 0.0625f, hh, ll);
+                    vh[r] = hh; vl[r] = ll;
+                }
+                char* dst = fragp + ((size_t)(tok >> 5) * 16 + (2 * fw + ft)) * 2048 + 16 * ((tok & 31) + 32 * (q >> 1)) + 8 * (q & 1);
+                *reinterpret_cast<bf16x4*>(dst) = vh;
+                *reinterpret_cast<bf16x4*>(dst + 1024) = vl;
+            }
         }
     }
     OPHIP_STAMP(a.stamps, wg, 10);
@@ -407,9 +433,10 @@ extern "C" size_t ophip_encoder_x3w8_workspace_bytes(int B, int L3d, int L2d) {
 
 extern "C" size_t ophip_encoder_x3w8_wpack_bytes(void) { return (size_t)NW * (MAIN_FRAGS + KV_FRAGS) * 1024 + 4 * C * 4; }
 
-extern "C" int ophip_encoder_layer_x3w8(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
-                                        const void* wpack, const void* wpack_next, int is_cross, int kv_from_prev, int slot,
-                                        void* workspace, void* stream_) {
+namespace {
+int layer_x3w8(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
+               const void* wpack, const void* wpack_next, int is_cross, int kv_from_prev, int slot,
+               void* workspace, void* stream_, void* frag3d, void* frag2d) {
     if (!x3d || !x2d || !y3d || !y2d || !wpack || !workspace) return ophip_bad_arg(__func__, "null pointer");
     if (B < 1 || L3d < 1 || L2d < 1) return ophip_bad_arg(__func__, "B, L3d, L2d must be >= 1");
     if (slot != 0 && slot != 1) return ophip_bad_arg(__func__, "slot must be 0 or 1");
@@ -438,9 +465,12 @@ extern "C" int ophip_encoder_layer_x3w8(const float* x3d, const float* x2d, floa
     aa.srclen[1] = (float)(is_cross ? L3d : L2d);
     aa.wmain = wmain; aa.ln = ln;
     aa.stamps = ophip_stamp_buffer();
+    aa.frag[0] = static_cast<char*>(frag3d); aa.frag[1] = static_cast<char*>(frag2d);
+    aa.frag_rows[0] = (L3d + 127) / 128 * 128; aa.frag_rows[1] = (L2d + 127) / 128 * 128;
     if (!kv_from_prev) {
         EncW8Args ka = aa;
         ka.kv[0] = ka.kv[1] = nullptr;
+        ka.frag[0] = ka.frag[1] = nullptr;
         ka.wkv = wkv_own;
         ka.partial = partial;
         ka.stamps = nullptr;
@@ -459,4 +489,21 @@ extern "C" int ophip_encoder_layer_x3w8(const float* x3d, const float* x2d, floa
     OPHIP_LAUNCH("attn_apply", stream, enc_x3w8_kernel<false>, dim3(t3 + t2, B), dim3(512), LDS_BYTES, stream, aa);
     OPHIP_CHECK_LAUNCH();
     return 0;
+}
+}  // namespace
+
+extern "C" int ophip_encoder_layer_x3w8(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
+                                        const void* wpack, const void* wpack_next, int is_cross, int kv_from_prev, int slot,
+                                        void* workspace, void* stream) {
+    return layer_x3w8(x3d, x2d, y3d, y2d, B, L3d, L2d, wpack, wpack_next, is_cross, kv_from_prev, slot, workspace, stream, nullptr, nullptr);
+}
+
+// The same layer; its output rows are ALSO written as the (hi, lo) bf16 operand fragments of the similarity kernel (scaled by
+// 1/16, rows padded with zeros to a multiple of 128: the layout of csrc/coarse_match.hip's frag_planes kernel), so that the last
+// encoder layer feeds ophip_coarse_match_conf directly (nsplit | OPHIP_COARSE_PLANES_READY) and that kernel's launch disappears.
+extern "C" int ophip_encoder_layer_x3w8_frag(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
+                                             const void* wpack, const void* wpack_next, int is_cross, int kv_from_prev, int slot,
+                                             void* workspace, void* frag3d, void* frag2d, void* stream) {
+    if (!frag3d || !frag2d) return ophip_bad_arg(__func__, "null fragment buffer");
+    return layer_x3w8(x3d, x2d, y3d, y2d, B, L3d, L2d, wpack, wpack_next, is_cross, kv_from_prev, slot, workspace, stream, frag3d, frag2d);
 }

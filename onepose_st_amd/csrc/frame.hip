@@ -141,8 +141,16 @@ extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_
     float *y3d = F(L->y3d), *y2d = F(L->y2d), *y2 = y2d, *x2 = x2d;
     float* z3d = x3d_external ? F(L->z3d) : x3d;          // a cached encoding is read-only: ping-pong between y and z
     float *x3 = x3d, *y3 = y3d;
+    // the last layer also writes its output as the similarity kernel's operand fragments (into the coarse workspace): no
+    // frag_planes launch in front of the similarity tiles
+    void *planes3d = nullptr, *planes2d = nullptr;
+    FR_CHECK(ophip_coarse_frag_planes(F(L->cws), B, N, M, &planes3d, &planes2d));
     for (int li = 0; li < d->n_coarse; ++li) {
         const void* nxt = li + 1 < d->n_coarse ? d->w_coarse[li + 1] : nullptr;
+        if (li + 1 == d->n_coarse)
+            FR_CHECK(ophip_encoder_layer_x3w8_frag(x3, x2, y3, y2, B, N, M, d->w_coarse[li], nxt, (d->coarse_cross_bits >> li) & 1, li > 0 ? 1 : 0, li & 1,
+                                                   blob + L->enc_ws, planes3d, planes2d, s_main));
+        else
         FR_CHECK(ophip_encoder_layer_x3w8(x3, x2, y3, y2, B, N, M, d->w_coarse[li], nxt, (d->coarse_cross_bits >> li) & 1, li > 0 ? 1 : 0, li & 1,
                                           blob + L->enc_ws, s_main));
         float* nx3 = y3;
@@ -159,7 +167,8 @@ extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_
     float* mk2d = F(L->result + 16 + 20 * (size_t)cap);
     unsigned char* gt_mask = reinterpret_cast<unsigned char*>(blob + L->gt_mask);
     FR_CHECK(ophip_coarse_match_conf(x3, x2, kpts, kpts_bs, B, N, M, d->wc, d->temperature, d->thr, d->border_rm, d->scale_c, conf, cws,
-                                     b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count, 3, s_main));
+                                     b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count,
+                                     3 | OPHIP_COARSE_PLANES_READY, s_main));
     // With the input kernels on their own stream nothing is left on the compute stream that could run beside the fine stage
     // (the next encoder waits for it anyway), so selection + fine stage stay in order on the compute stream: a dependent kernel
     // on the same queue starts ~2 us after its producer, one behind a cross-stream event 10-17 us after (rocprof trace).

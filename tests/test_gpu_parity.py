@@ -177,6 +177,49 @@ def test_encoder_layer_x3(sd, dev, cross, B, L3, L2, kern):
                  hip.ptr(ws, None), hip.stream_handle())
 
 
+@pytest.mark.parametrize("B,N,hc,wc", [(1, 100, 5, 15), (2, 333, 13, 20), (1, 1000, 30, 40)])
+def test_encoder_layer_writes_the_similarity_fragments(sd, dev, B, N, hc, wc):
+    """ophip_encoder_layer_x3w8_frag: the layer's output rows, also as the similarity kernel's (hi, lo) operand fragments inside the
+    coarse workspace (rows padded with zeros to 128).  Coarse matching fed that way (nsplit | OPHIP_COARSE_PLANES_READY) must give
+    bit for bit what it gives when its own frag_planes kernel converts the same rows -- at sizes that are no multiple of 48 or 128."""
+    import ctypes
+    M = hc * wc
+    g = torch.Generator().manual_seed(9)
+    x3, x2 = torch.randn(B, N, 256, generator=g).to(dev), torch.randn(B, M, 256, generator=g).to(dev)
+    kp = torch.randn(B, N, 3, generator=g).to(dev)
+    p = "loftr_coarse.layers.5."
+    w = packing.pack_coarse_layer_x3w8(sd, p).to(dev)
+    ws = torch.empty(hip.load().ophip_encoder_x3w8_workspace_bytes(B, N, M), dtype=torch.uint8, device=dev)
+    cap = B * N
+
+    def coarse(flag, cws, y3, y2):
+        conf = torch.empty(B, N, M, device=dev)
+        ids = [torch.empty(cap, dtype=torch.int64, device=dev) for _ in range(3)]
+        mconf, mk3, mkc = torch.empty(cap, device=dev), torch.empty(cap, 3, device=dev), torch.empty(cap, 2, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        hip.call("ophip_coarse_match", hip.ptr(y3), hip.ptr(y2), hip.ptr(kp), kp.stride(0), B, N, M, wc, 0.08, 0.1, 2, 8.0, hip.ptr(conf), hip.ptr(cws),
+                 *[hip.ptr(t, torch.int64) for t in ids], hip.ptr(mconf), hip.ptr(mk3), hip.ptr(mkc), None, None, hip.ptr(cnt, torch.int32),
+                 3 | flag, hip.stream_handle())
+        K = int(cnt.item())
+        return conf, [t[:K].clone() for t in ids], mconf[:K].clone()
+
+    y3a, y2a = torch.empty_like(x3), torch.empty_like(x2)
+    hip.call("ophip_encoder_layer_x3w8", hip.ptr(x3), hip.ptr(x2), hip.ptr(y3a), hip.ptr(y2a), B, N, M, hip.ptr(w, None), None, 1, 0, 0,
+             hip.ptr(ws, None), hip.stream_handle())
+    cws_a = torch.empty(hip.load().ophip_coarse_workspace_floats(B, N, M), device=dev)
+    ref = coarse(0, cws_a, y3a, y2a)
+
+    y3b, y2b = torch.empty_like(x3), torch.empty_like(x2)
+    cws_b = torch.full((hip.load().ophip_coarse_workspace_floats(B, N, M),), float("nan"), device=dev)      # padding must be written, not assumed
+    pa, pb = ctypes.c_void_p(), ctypes.c_void_p()
+    hip.call("ophip_coarse_frag_planes", hip.ptr(cws_b), B, N, M, ctypes.byref(pa), ctypes.byref(pb))
+    hip.call("ophip_encoder_layer_x3w8_frag", hip.ptr(x3), hip.ptr(x2), hip.ptr(y3b), hip.ptr(y2b), B, N, M, hip.ptr(w, None), None, 1, 0, 0,
+             hip.ptr(ws, None), pa, pb, hip.stream_handle())
+    got = coarse(0x100, cws_b, y3b, y2b)
+    assert torch.equal(y3a, y3b) and torch.equal(y2a, y2b)
+    assert torch.equal(ref[0], got[0]) and all(torch.equal(a, b) for a, b in zip(ref[1], got[1])) and torch.equal(ref[2], got[2])
+
+
 @pytest.mark.parametrize("kern", ["x3", "x3w8"])
 @pytest.mark.parametrize("B,L3,L2", [(1, 100, 75), (2, 333, 260)])
 def test_encoder_x3_chain_with_fused_kv_tail(sd, dev, B, L3, L2, kern):
