@@ -561,11 +561,18 @@ class OnePosePlus_model(nn.Module):
             fs = (ff.stride(0), 1, ff.stride(2), ff.stride(3))
         slot = ctypes.c_int(-1)
         P = hip.ptr
-        hip.call("ophip_frame_enqueue", ctypes.byref(d), ctypes.byref(L), ctypes.c_void_p(blob.data_ptr()),
-                 P(fc), P(ff), fs[0], fs[1], fs[2], fs[3], P(kpts_d), bstride(kpts_d), P(desc_in_d), bstride(desc_in_d),
-                 P(desc_fine_d), bstride(desc_fine_d), desc_fine_d.stride(1), P(x3d_ext), ctypes.c_void_p(pin.data_ptr()), nbytes,
-                 ctypes.c_void_p(main.cuda_stream), ctypes.c_void_p(sprep.cuda_stream) if sprep is not None else None,
-                 ctypes.c_void_p(sfine.cuda_stream), ctypes.c_void_p(scopy.cuda_stream), ctypes.byref(slot))
+        try:
+            hip.call("ophip_frame_enqueue", ctypes.byref(d), ctypes.byref(L), ctypes.c_void_p(blob.data_ptr()),
+                     P(fc), P(ff), fs[0], fs[1], fs[2], fs[3], P(kpts_d), bstride(kpts_d), P(desc_in_d), bstride(desc_in_d),
+                     P(desc_fine_d), bstride(desc_fine_d), desc_fine_d.stride(1), P(x3d_ext), ctypes.c_void_p(pin.data_ptr()), nbytes,
+                     ctypes.c_void_p(main.cuda_stream), ctypes.c_void_p(sprep.cuda_stream) if sprep is not None else None,
+                     ctypes.c_void_p(sfine.cuda_stream), ctypes.c_void_p(scopy.cuda_stream), ctypes.byref(slot))
+        except Exception:
+            # part of the frame may be queued on the side streams already: nothing may touch the block or the pinned buffer again
+            # before those streams are idle
+            torch.cuda.synchronize(dev)
+            PendingFrame._pinned_pool.setdefault((cap, bool(host_copy)), []).append(pin)
+            raise
         self._frame_call_pending.add(fkey)
         data["conf_matrix"] = blob[L.conf:L.conf + 4 * B * N * M].view(torch.float32).view(B, N, M)
         keep = [fc, ff, kpts_d, desc_in_d, desc_fine_d, x3d_ext, W]
