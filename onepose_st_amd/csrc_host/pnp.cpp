@@ -488,53 +488,72 @@ bool solve6(double* H, double* g, double* dx) {          // Cholesky-free Gaussi
 
 // Levenberg-Marquardt on the masked points; pose updated in place (left-multiplied rotation increment)
 void refine_lm(const Problem& P, const unsigned char* mask, double* pose, int iters) {
-    const double fx = P.K[0], fy = P.K[4], sk = P.K[1];
+    const double fx = P.K[0], fy = P.K[4], sk = P.K[1], cx = P.K[2], cy = P.K[5];
     double lambda = 1e-3;
+    // the masked points once as a structure of arrays (padded to a multiple of four with weight 0): every pass below runs four
+    // points per step on 4 x double vectors -- the refinement is the serial tail of a frame's pose (1 of its ~1.5 ms of latency)
+    std::vector<double> sx, sy, sz, su, sv, sw;
+    for (int i = 0; i < P.n; ++i) {
+        if (!mask[i]) continue;
+        sx.push_back(P.X[3 * i]); sy.push_back(P.X[3 * i + 1]); sz.push_back(P.X[3 * i + 2]);
+        su.push_back(P.px[2 * i]); sv.push_back(P.px[2 * i + 1]); sw.push_back(1.0);
+    }
+    while (sx.size() % 4) { sx.push_back(0.0); sy.push_back(0.0); sz.push_back(1.0); su.push_back(0.0); sv.push_back(0.0); sw.push_back(0.0); }
+    const int n4 = (int)sx.size() / 4;
+    auto ld = [](const std::vector<double>& v, int g) { vd r; std::memcpy(&r, &v[4 * (size_t)g], sizeof(r)); return r; };
+    auto hsum = [](vd v) { return (v[0] + v[1]) + (v[2] + v[3]); };
+    const vd zero = vsplat(0.0);
     auto cost_of = [&](const double* ps) {
-        double c = 0.0;
-        for (int i = 0; i < P.n; ++i) {
-            if (!mask[i]) continue;
-            const double* x = &P.X[3 * i];
-            const double xc = ps[0] * x[0] + ps[1] * x[1] + ps[2] * x[2] + ps[3];
-            const double yc = ps[4] * x[0] + ps[5] * x[1] + ps[6] * x[2] + ps[7];
-            const double zc = ps[8] * x[0] + ps[9] * x[1] + ps[10] * x[2] + ps[11];
-            if (zc <= 1e-12) { c += 1e12; continue; }
-            const double xn = xc / zc, yn = yc / zc;
-            const double du = fx * xn + sk * yn + P.K[2] - P.px[2 * i], dv = fy * yn + P.K[5] - P.px[2 * i + 1];
-            c += du * du + dv * dv;
+        vd c = zero;
+        for (int g = 0; g < n4; ++g) {
+            const vd x = ld(sx, g), y = ld(sy, g), z = ld(sz, g), w = ld(sw, g);
+            const vd xc = vsplat(ps[0]) * x + vsplat(ps[1]) * y + vsplat(ps[2]) * z + vsplat(ps[3]);
+            const vd yc = vsplat(ps[4]) * x + vsplat(ps[5]) * y + vsplat(ps[6]) * z + vsplat(ps[7]);
+            const vd zc = vsplat(ps[8]) * x + vsplat(ps[9]) * y + vsplat(ps[10]) * z + vsplat(ps[11]);
+            const vl front = zc > vsplat(1e-12);
+            const vd izc = vsplat(1.0) / vsel(front, zc, vsplat(1.0));
+            const vd xn = xc * izc, yn = yc * izc;
+            const vd du = vsplat(fx) * xn + vsplat(sk) * yn + vsplat(cx) - ld(su, g), dv = vsplat(fy) * yn + vsplat(cy) - ld(sv, g);
+            c += w * vsel(front, du * du + dv * dv, vsplat(1e12));
         }
-        return c;
+        return hsum(c);
     };
     double cur = cost_of(pose);
     for (int it = 0; it < iters; ++it) {
         double H[36], g[6];
-        std::memset(H, 0, sizeof(H));
-        std::memset(g, 0, sizeof(g));
-        for (int i = 0; i < P.n; ++i) {
-            if (!mask[i]) continue;
-            const double* x = &P.X[3 * i];
-            const double pc[3] = {pose[0] * x[0] + pose[1] * x[1] + pose[2] * x[2] + pose[3],
-                                  pose[4] * x[0] + pose[5] * x[1] + pose[6] * x[2] + pose[7],
-                                  pose[8] * x[0] + pose[9] * x[1] + pose[10] * x[2] + pose[11]};
-            if (pc[2] <= 1e-12) continue;
-            const double iz = 1.0 / pc[2], xn = pc[0] * iz, yn = pc[1] * iz;
-            const double ru = fx * xn + sk * yn + P.K[2] - P.px[2 * i], rv = fy * yn + P.K[5] - P.px[2 * i + 1];
+        vd Hv[21], gv[6];
+        for (vd& v : Hv) v = zero;
+        for (vd& v : gv) v = zero;
+        for (int gI = 0; gI < n4; ++gI) {
+            const vd x = ld(sx, gI), y = ld(sy, gI), z = ld(sz, gI);
+            const vd pc0 = vsplat(pose[0]) * x + vsplat(pose[1]) * y + vsplat(pose[2]) * z + vsplat(pose[3]);
+            const vd pc1 = vsplat(pose[4]) * x + vsplat(pose[5]) * y + vsplat(pose[6]) * z + vsplat(pose[7]);
+            const vd pc2 = vsplat(pose[8]) * x + vsplat(pose[9]) * y + vsplat(pose[10]) * z + vsplat(pose[11]);
+            const vl front = pc2 > vsplat(1e-12);
+            const vd w = vsel(front, ld(sw, gI), zero);          // points behind the camera (and the padding) contribute nothing
+            const vd iz = vsplat(1.0) / vsel(front, pc2, vsplat(1.0)), xn = pc0 * iz, yn = pc1 * iz;
+            const vd ru = w * (vsplat(fx) * xn + vsplat(sk) * yn + vsplat(cx) - ld(su, gI)), rv = w * (vsplat(fy) * yn + vsplat(cy) - ld(sv, gI));
             // d(u,v)/d(pc)
-            const double Ju[3] = {fx * iz, sk * iz, -(fx * xn + sk * yn) * iz};
-            const double Jv[3] = {0.0, fy * iz, -fy * yn * iz};
+            const vd Ju[3] = {w * vsplat(fx) * iz, w * vsplat(sk) * iz, -w * (vsplat(fx) * xn + vsplat(sk) * yn) * iz};
+            const vd Jv[3] = {zero, w * vsplat(fy) * iz, -w * vsplat(fy) * yn * iz};
             // d(pc)/d(w) = -[pc - t]_x ... with the left increment R' = exp(w) R: pc' = exp(w) (pc - t) + t + dt
-            const double q[3] = {pc[0] - pose[3], pc[1] - pose[7], pc[2] - pose[11]};
-            const double dW[3][3] = {{0, q[2], -q[1]}, {-q[2], 0, q[0]}, {q[1], -q[0], 0}};
-            double ju[6], jv[6];
-            for (int k = 0; k < 3; ++k) {
-                ju[k] = Ju[0] * dW[0][k] + Ju[1] * dW[1][k] + Ju[2] * dW[2][k];
-                jv[k] = Jv[0] * dW[0][k] + Jv[1] * dW[1][k] + Jv[2] * dW[2][k];
-                ju[3 + k] = Ju[k];
-                jv[3 + k] = Jv[k];
-            }
+            const vd q[3] = {pc0 - vsplat(pose[3]), pc1 - vsplat(pose[7]), pc2 - vsplat(pose[11])};
+            vd ju[6], jv[6];
+            // dW = [[0, q2, -q1], [-q2, 0, q0], [q1, -q0, 0]];  ju[k] = sum_r Ju[r] dW[r][k]
+            ju[0] = -Ju[1] * q[2] + Ju[2] * q[1]; ju[1] = Ju[0] * q[2] - Ju[2] * q[0]; ju[2] = -Ju[0] * q[1] + Ju[1] * q[0];
+            jv[0] = -Jv[1] * q[2] + Jv[2] * q[1]; jv[1] = Jv[0] * q[2] - Jv[2] * q[0]; jv[2] = -Jv[0] * q[1] + Jv[1] * q[0];
+            for (int k = 0; k < 3; ++k) { ju[3 + k] = Ju[k]; jv[3 + k] = Jv[k]; }
+            int e = 0;
             for (int a = 0; a < 6; ++a) {
-                g[a] -= ju[a] * ru + jv[a] * rv;
-                for (int b2 = a; b2 < 6; ++b2) H[a * 6 + b2] += ju[a] * ju[b2] + jv[a] * jv[b2];      // upper triangle
+                gv[a] -= ju[a] * ru + jv[a] * rv;
+                for (int b2 = a; b2 < 6; ++b2) Hv[e++] += ju[a] * ju[b2] + jv[a] * jv[b2];      // upper triangle
+            }
+        }
+        {
+            int e = 0;
+            for (int a = 0; a < 6; ++a) {
+                g[a] = hsum(gv[a]);
+                for (int b2 = a; b2 < 6; ++b2) H[a * 6 + b2] = hsum(Hv[e++]);
             }
         }
         for (int a = 1; a < 6; ++a)
