@@ -296,9 +296,11 @@ def main():
         for i in range(args.steps):
             step(i)
         drain()
+        t_gpu = time.perf_counter()
         join_poses()
         sync_all()
         dt_ = time.perf_counter() - t0
+        host_t["tail"] = dt_ - (t_gpu - t0)          # after the last frame left the GPU: its pose (and the final barrier)
         if world > 1:
             import torch.distributed as dist
             tt = torch.tensor([dt_], device=dev, dtype=torch.float64)
@@ -322,7 +324,8 @@ def main():
     hip.timing_select("attn_apply", every=time_every)
     dt = timed_region(pools.get(args.pnp_policy))
     if os.environ.get("OPHIP_BENCH_TRACE") and rank == 0:
-        print("host us/step: " + ", ".join(f"{k} {1e6 * v / args.steps:.0f}" for k, v in host_t.items()) + f"; wall {1e6 * dt / args.steps:.0f}", file=sys.stderr)
+        print("host us/step: " + ", ".join(f"{k} {1e6 * v / args.steps:.0f}" for k, v in host_t.items() if k != "tail")
+              + f"; wall {1e6 * dt / args.steps:.0f}; after the last frame left the GPU {1e6 * host_t.get('tail', 0.0):.0f} us in all", file=sys.stderr)
     launches, kern_ms = hip.timing_read()
     hip.timing_select("")
 
