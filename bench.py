@@ -3,21 +3,27 @@
     python bench.py --gpus N --steps K --warmup W [--batch B] [--workload c2|c1|c4] [--no-cpu-baseline]
 
 One process per GPU over RCCL: for N > 1 either ``torch.distributed.run`` starts the ranks, or -- when ``python bench.py
---gpus N`` is run directly -- this process starts them itself as children (``onepose_st_amd/launch.py``) and relays
-rank 0's JSON line.  A *step* is one pass of the hot path over
-one batch of ``--batch`` frames (default 1) whose inputs are already resident in HBM: backbone-output feature
-maps of a frame (``feat_c [B,256,60,80]``, ``feat_f [B,128,240,320]``) + the shared 3D object block -> match
-indices, confidences and sub-pixel keypoints (rows a1-a11 of SURVEY.md section 8a; the ResNet backbone and PnP
-are outside the timed region).  Frames shard across ranks with no data-path collective: rank 0
-builds weights + the 3D object block and broadcasts them once (RCCL) before the timed region; every rank then
-matches its own frames ("scaling": "weak").
+--gpus N`` is run directly -- this process starts them itself as children (``onepose_st_amd/launch.py``; the parent imports
+nothing that touches the GPU) and relays rank 0's JSON line.  A *step* is one pass of the hot path over one batch of
+``--batch`` frames (default 1) whose inputs are already resident in HBM: backbone-output feature maps of a frame
+(``feat_c [B,256,60,80]``, ``feat_f [B,128,240,320]``) + the shared 3D object block -> match indices, confidences and
+sub-pixel keypoints (rows a1-a11 of SURVEY.md section 8a) AND the host PnP/RANSAC of every frame with the reference's trial
+policy (C++ pool, overlapped with the following frames, every pose joined before the clock stops).  The ResNet backbone is
+outside the timed region unless ``--with-backbone``.  Frames shard across ranks with no data-path collective: rank 0 builds
+weights + the 3D object block and broadcasts them once (RCCL) before the timed region; every rank then matches its own
+frames ("scaling": "weak").  Each rank pins itself to its own slice of the host's CPUs and sizes its PnP pool from that
+slice (``onepose_st_amd/hostsize.py``).
 
 Rank 0 prints ONE JSON line with the driver's contract fields plus
-  "roofline"      dominant kernel (attn_apply: fused Q-proj + linear attention + merge + MLP + 2 LayerNorms),
-                  algorithmic FLOPs per launch / average launch duration from HIP events recorded around every
-                  launch of that kernel inside the timed region, against the dense f32 MFMA peak
+  "roofline"      dominant kernel (attn_apply: fused Q-proj + linear attention + merge + MLP + 2 LayerNorms + the next layer's
+                  K/V reduce), algorithmic FLOPs per launch / average launch duration from HIP events (dispatch timestamps of
+                  every 11th launch of that kernel inside the timed region), against the dense bf16 MFMA peak (2.5 PFLOP/s);
+                  "traffic" / "mfma_busy..." come from the committed counter pass and are printed only when that pass was
+                  taken on the library build that is running (source hash recorded in the pmc file)
   "cpu_baseline"  the oracle (CPU restatement of the reference, torch fp32) timed on this box's host cores on a
-                  bounded sample of the same workload (rank 0, N = 1 only).
+                  bounded sample of the same workload (rank 0, N = 1 only)
+  "host"          this rank's CPU slice, PnP threads, the pool's measured ceiling (frames/s of RANSAC alone on recorded matches)
+                  and "host_bound": true when that ceiling is below the matcher-only rate.
 """
 from __future__ import annotations
 
@@ -27,42 +33,23 @@ import os
 import sys
 import time
 
-import torch
-
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-from onepose_st_amd import hip  # noqa: E402
-from onepose_st_amd.config import default_config  # noqa: E402
-from onepose_st_amd.launch import launched_by_torchrun, spawn_ranks  # noqa: E402
-from onepose_st_amd.model import OnePosePlus_model  # noqa: E402
-from onepose_st_amd.pnp import PnPPool  # noqa: E402
-from onepose_st_amd.sharding import OBJECT_KEYS as OBJ_KEYS, broadcast_object_block, frame_chunk  # noqa: E402
-from onepose_st_amd.synthetic import CONFIG_SIZES, make_synthetic_inputs, make_synthetic_state_dict  # noqa: E402
+from onepose_st_amd import hostsize  # noqa: E402        (pure host logic; torch and the HIP binding are imported inside main(),
+from onepose_st_amd.launch import launched_by_torchrun, spawn_ranks, visible_gpu_count  # noqa: E402   after the launcher branch)
+
+WORKLOADS = ("c1", "c2", "c4")
 
 # MI355X_MICROARCH.md dense matrix peaks: f32 (v_mfma_f32_32x32x2_f32) 157.3 TFLOP/s; bf16 (v_mfma_f32_32x32x16_bf16) 2.5 PFLOP/s.
 # Split-bf16 issues 3 bf16 MFMAs per algorithmic product and is priced against the bf16 peak with 1x algorithmic FLOPs.
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}
 
 
-def host_cores() -> int:
-    """CPU threads this job may really use: the cgroup CPU quota or the affinity mask, not the machine's core
-    count (a GPU box exposes 256 logical CPUs but a one-GPU job owns a 16-core share)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            txt = open(path).read().split()
-            if path.endswith("cpu.max"):
-                if txt[0] != "max":
-                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
-            else:
-                q = int(txt[0])
-                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-                if q > 0:
-                    n = min(n, max(1, q // per))
-        except (OSError, ValueError, IndexError):
-            pass
-    return max(1, min(n, int(os.environ.get("OPHIP_CPU_THREADS", "16"))))
+def host_cores(rank: int = 0, world: int = 1) -> int:
+    """CPU threads rank ``rank`` of ``world`` may really use: its slice of (affinity mask, cgroup quota), at most 16 per
+    rank (``onepose_st_amd/hostsize.py``).  A GPU box exposes 256 logical CPUs; a one-GPU job owns a 16-core share."""
+    return len(hostsize.rank_cpus(rank, world))
 
 
 def attn_apply_flops(n_tokens: int, fused_kv: bool, n_layers: int = 6, C: int = 256, D: int = 32) -> float:
@@ -81,7 +68,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1, help="frames per step")
-    ap.add_argument("--workload", default="c2", choices=sorted(CONFIG_SIZES))
+    ap.add_argument("--workload", default="c2", choices=WORKLOADS)
     ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames per rank (cycled)")
     ap.add_argument("--precision", default=os.environ.get("OPHIP_PRECISION", "bf16x3"), choices=["f32", "bf16x3", "bf16"],
                     help="matrix arithmetic of the encoder kernels (see DESIGN.md section 4)")
@@ -103,7 +90,7 @@ def main():
                     help="RANSAC trial policy of the timed region: 'reference' = what the reference's inference loop runs (pycolmap branch of "
                          "ransac_PnP: at least 10 000 trials per frame, metric_utils.py:155-165); 'adaptive' = its OpenCV branch (stops at the "
                          "confidence).  The other policy and the matcher alone are timed too and reported beside `value`")
-    ap.add_argument("--pnp-threads", type=int, default=0, help="host threads of the PnP pool (0: this rank's share of the host cores minus 2)")
+    ap.add_argument("--pnp-threads", type=int, default=0, help="host threads of the PnP pool (0: this rank's CPU slice minus 2 feeder cores, hostsize.pnp_threads)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses cuda:0 (one-GPU box, with --dist-backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -113,8 +100,9 @@ def main():
     # ---- N > 1 without a launcher: this process becomes the driver and starts one child per GPU (it never touches the GPU
     #      itself and never exec's; the reference fans out from its driver too, inference_OnePosePlus.py:81-98) --------------
     if args.gpus > 1 and not launched_by_torchrun():
-        if not args.share_device and torch.cuda.device_count() < args.gpus:      # device_count() does not initialise HIP
-            raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible "
+        n_vis = visible_gpu_count()                      # from the environment / KFD topology: the parent never brings up HIP
+        if not args.share_device and n_vis is not None and n_vis < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but only {n_vis} GPU(s) are visible "
                              "(one-GPU rehearsal: --share-device --dist-backend gloo)")
         raise SystemExit(spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
                                      keep=lambda ln: ln.lstrip().startswith("{")))      # stdout carries the ONE JSON line only
@@ -123,6 +111,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # this rank's slice of the host: pinned before any thread pool exists (PnP workers and torch's intra-op threads inherit it)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    my_cpus = hostsize.pin_rank(local % max(local_world, 1), max(local_world, 1))
+    pnp_threads = args.pnp_threads if args.pnp_threads > 0 else hostsize.pnp_threads(len(my_cpus))
+    import torch
     if os.environ.get("OPHIP_BENCH_LAUNCH_PROBE"):
         # launcher rehearsal without a GPU (tests/test_launch.py): rendezvous over gloo, one all-reduce, one JSON line from rank 0
         import torch.distributed as dist
@@ -131,11 +124,25 @@ def main():
         seen = torch.tensor([float(rank + 1)])
         if world > 1:
             dist.all_reduce(seen)
+        sizes = torch.tensor([float(len(my_cpus)), float(pnp_threads), float(my_cpus[0])])
+        if world > 1:
+            gathered = [torch.zeros(3) for _ in range(world)]
+            dist.all_gather(gathered, sizes)
+        else:
+            gathered = [sizes]
         if rank == 0:
-            print(json.dumps({"probe": True, "n_gpus": world, "rank_sum": float(seen.item()), "local_rank": local}))
+            print(json.dumps({"probe": True, "n_gpus": world, "rank_sum": float(seen.item()), "local_rank": local,
+                              "host_cores": [int(g[0]) for g in gathered], "pnp_threads": [int(g[1]) for g in gathered],
+                              "first_cpu": [int(g[2]) for g in gathered]}))
         if world > 1:
             dist.destroy_process_group()
         return
+    from onepose_st_amd import hip
+    from onepose_st_amd.config import default_config
+    from onepose_st_amd.model import OnePosePlus_model
+    from onepose_st_amd.pnp import PnPPool
+    from onepose_st_amd.sharding import OBJECT_KEYS as OBJ_KEYS, broadcast_object_block, frame_chunk
+    from onepose_st_amd.synthetic import CONFIG_SIZES, make_synthetic_inputs, make_synthetic_state_dict
     if args.share_device:
         local = 0
     torch.cuda.set_device(local)
@@ -180,11 +187,11 @@ def main():
 
     # host PnP (metric: "2D-3D match + PnP"): frame t's pose is solved on host threads (C++, GIL released) while the GPU
     # matches frame t + 1; every pose is joined before the clock stops
-    pnp_threads = args.pnp_threads if args.pnp_threads > 0 else max(1, host_cores() // world - 2)
     pools = {} if args.no_pnp else {pol: PnPPool(first["K"].numpy(), threads=pnp_threads, pnp_reprojection_error=7, policy=pol)
                                     for pol in ("reference", "adaptive")}
     pool = pools.get(args.pnp_policy)
     pending = []
+    last_host = [None]      # the most recent frame's matches on the host: what the PnP-ceiling measurement replays
 
     inflight = []
 
@@ -199,6 +206,8 @@ def main():
         data = pend.finish()
         host_t["finish"] += time.perf_counter() - t
         t = time.perf_counter()
+        if pend.host is not None:
+            last_host[0] = pend.host
         if pool is not None:
             hst = pend.host
             if B == 1:
@@ -329,6 +338,28 @@ def main():
     launches, kern_ms = hip.timing_read()
     hip.timing_select("")
 
+    # what the host side can sustain by itself: this rank's pool alone on recorded matches, every rank at once (they share the host);
+    # when that ceiling is below the matcher's rate, `value` is a host number and the line says so ("host_bound")
+    pnp_ceiling = None
+    if pools and last_host[0] is not None and last_host[0]["K"] > 0:
+        pl, hst = pools[args.pnp_policy], last_host[0]
+        sel = slice(None) if B == 1 else (hst["b_ids"] == 0)
+        p2, p3 = hst["mkpts_2d"][sel], hst["mkpts_3d_db"][sel]
+        sync_all()
+        n_rep = 64
+        t0 = time.perf_counter()
+        tickets = [pl.submit(p2, p3) for _ in range(n_rep)]
+        pl.wait_all()
+        for tk in tickets:
+            pl.result(tk)
+        rate = n_rep / (time.perf_counter() - t0)
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([rate], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+            rate = float(tt.item())
+        pnp_ceiling = rate * world
+
     # HBM bytes and matrix-pipe busy cycles per launch of the roofline kernel: from the committed counter passes (separate
     # rocprofv3 --pmc runs, tools/run_profile_r02.sh), not live
     traffic, mfma_busy = None, None
@@ -379,6 +410,12 @@ def main():
             "pnp_inliers_per_frame": n_inliers,
             "streams": len(streams),
             "parallelism": f"frames sharded over {world} rank(s), one RCCL broadcast of weights + 3D block ({bcast_bytes} B)",
+        },
+        "host": {
+            "host_cores_per_rank": len(my_cpus), "cpus_of_rank0": [my_cpus[0], my_cpus[-1]], "pinned": world > 1,
+            "pnp_threads_per_rank": pnp_threads, "pnp_policy": args.pnp_policy,
+            "pnp_ceiling_fps": pnp_ceiling,          # RANSAC pools alone on recorded matches, all ranks at once (min over ranks x N)
+            "host_bound": (pnp_ceiling < (frames_total / dt_matcher if dt_matcher else value)) if pnp_ceiling else None,
         },
         "roofline": {
             "kernel": {"bf16x3": ("enc_x3w8_kernel<false>" if os.environ.get("OPHIP_ENC_W8", "1") != "0" else "enc_x3_kernel<false>") + " (attn_apply)", "bf16": "attn_apply_bf16_kernel<1, 1>", "f32": "attn_apply_kernel"}[args.precision]

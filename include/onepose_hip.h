@@ -64,8 +64,8 @@ size_t ophip_encoder_workspace_floats(int B, int L3d, int L2d);
 int ophip_encoder_layer(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
                         const float* wpack, int is_cross, float* workspace, void* stream);
 
-/* Same layer on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, f32 accumulate).  nsplit = 1: plain bf16 operands;
- * nsplit = 3: split-bf16 (x = hi + lo, three MFMAs per product, ~f32-grade results).  wpack: packing.pack_coarse_layer_bf16
+/* Same layer on the bf16 matrix pipe with PLAIN bf16 operands (v_mfma_f32_32x32x16_bf16, f32 accumulate; the "bf16"
+ * arithmetic mode).  nsplit must be 1 (the split-bf16 layer is ophip_encoder_layer_x3w8).  wpack: packing.pack_coarse_layer_bf16
  * (ophip_encoder_bf16_wpack_bytes() bytes); workspace: ophip_encoder_bf16_workspace_bytes() bytes, 256-byte aligned.
  * Layer chaining: when wpack_next (the NEXT layer's block) is given, attn_apply also produces that layer's K/V partial
  * slabs from the output tile while it is still on chip; the next call then passes kv_from_prev = 1 (skips its own
@@ -77,19 +77,12 @@ int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, float* y3d, flo
                              const void* wpack, const void* wpack_next, int nsplit, int is_cross, int kv_from_prev, int slot,
                              void* workspace, void* stream);
 
-/* The same layer, split-bf16 only, second-generation mapping (csrc/encoder_x3.hip): v_mfma_f32_16x16x32_bf16 on 48-token
- * workgroups (one per CU), the layer's weights pre-ordered into one linear stream per wave (packing.pack_coarse_layer_x3,
- * ophip_encoder_x3_wpack_bytes() bytes, 16-byte aligned), epilogues overlapped with the next GEMM inside a wave.
- * Arguments and layer chaining (wpack_next / kv_from_prev / slot) as ophip_encoder_layer_bf16;
- * workspace: ophip_encoder_x3_workspace_bytes() bytes.  Replaces transformer.py:65-94 + linear_attention.py:29-61. */
-size_t ophip_encoder_x3_workspace_bytes(int B, int L3d, int L2d);
-size_t ophip_encoder_x3_wpack_bytes(void);
-int ophip_encoder_layer_x3(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
-                           const void* wpack, const void* wpack_next, int is_cross, int kv_from_prev, int slot,
-                           void* workspace, void* stream);
-
-/* ophip_encoder_layer_x3 with eight waves per workgroup (two per SIMD; csrc/encoder_x3w8.hip): same arguments, same slab and
- * K/V formats, its own weight block (packing.pack_coarse_layer_x3w8, ophip_encoder_x3w8_wpack_bytes() bytes). */
+/* The default layer: split-bf16 (x = hi + lo, three MFMAs per product, f32 accumulate), v_mfma_f32_16x16x32_bf16 on 48-token
+ * workgroups of eight waves (one workgroup per CU, two waves per SIMD; csrc/encoder_x3w8.hip), the layer's weights pre-ordered
+ * into one linear stream per wave (packing.pack_coarse_layer_x3w8, ophip_encoder_x3w8_wpack_bytes() bytes, 16-byte aligned),
+ * epilogues overlapped with the next GEMM inside a wave.  Arguments and layer chaining (wpack_next / kv_from_prev / slot) as
+ * ophip_encoder_layer_bf16; workspace: ophip_encoder_x3w8_workspace_bytes() bytes.
+ * Replaces transformer.py:65-94 + linear_attention.py:29-61. */
 size_t ophip_encoder_x3w8_workspace_bytes(int B, int L3d, int L2d);
 size_t ophip_encoder_x3w8_wpack_bytes(void);
 /* ..._frag: the same layer; the output rows are also written as the similarity kernel's operand fragments (see
@@ -150,18 +143,6 @@ int ophip_fine_refine(const float* feat_f, long long fs_b, long long fs_c, long 
                       int wc, int stride, float fine_scale, float* expec_f, float* mkpts_f,
                       float* dbg_win, float* dbg_f3, void* stream);
 
-/* The same stage, split-bf16 only, second-generation mapping (csrc/fine_x3.hip): three matches per workgroup on
- * v_mfma_f32_16x16x32_bf16, the layers' weights streamed once per three matches (packing.pack_fine_layers_x3,
- * ophip_fine_x3_wpack_bytes(nlayers) bytes, 16-byte aligned).  The fine map must be channels-last (fs_c == 1).
- * Other arguments as ophip_fine_refine.  Replaces fine_preprocess.py:32-55, transformer.py (fine cfg), fine_matching.py:28-110. */
-size_t ophip_fine_x3_wpack_bytes(int nlayers);
-int ophip_fine_refine_x3(const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x, int hf, int wf,
-                         const float* desc3d_f, long long ds_b, long long ds_c,
-                         const long long* b_ids, const long long* i_ids, const long long* j_ids, const int* count, int max_matches,
-                         const float* mkpts_c, const void* wpack, int nlayers, unsigned cross_bits, int encoder_enable,
-                         int wc, int stride, float fine_scale, float* expec_f, float* mkpts_f,
-                         float* dbg_win, float* dbg_f3, void* stream);
-
 /* ophip_fine_refine on the bf16 matrix pipe (nsplit = 1 plain bf16, 3 split-bf16); one match per 4-wave workgroup.
  * wpack: packing.pack_fine_layers_bf16 (ophip_fine_bf16_wpack_bytes(nlayers) bytes).  Other arguments as above. */
 size_t ophip_fine_bf16_wpack_bytes(int nlayers);
@@ -182,7 +163,9 @@ int ophip_fine_refine_bf16(const float* feat_f, long long fs_b, long long fs_c, 
  * ophip_frame_enqueue(): enqueues the frame and returns; nothing is allocated or synchronised.  s_prep may be NULL (input
  *   kernels then run on s_main, behind everything queued there); host_dst receives the first host_bytes of the result block
  *   (>= 16: the match count; result_bytes: count | b_ids | mkpts3d | mkpts2d) by an asynchronous copy on s_copy.
- *   The block, the inputs and host_dst must stay valid until ophip_frame_wait(*slot) returned.
+ *   The block, the inputs and host_dst must stay valid until ophip_frame_wait(*slot) returned.  *slot receives a TICKET
+ *   (generation * 16 + ring index): the 16 event sets are reused round-robin; before one is reused enqueue waits for the frame
+ *   that held it, and ophip_frame_wait() of a ticket whose set has been handed out again returns at once (that frame is done).
  * Result block at offset `result`: int32 count @0, int64 b_ids[cap] @16, float mkpts3d[cap][3], float mkpts_query_f[cap][2],
  *   cap = B * N; the other outputs (conf_matrix, i_ids, j_ids, m_bids, gt_mask, mconf, mkpts_query_c, expec_f) at their offsets.
  * ophip_frame_order_after_fine(stream): makes `stream` wait for the fine stage of the last frame enqueued on it through this
@@ -209,7 +192,7 @@ int ophip_frame_enqueue(const ophip_frame_desc* desc, const ophip_frame_layout_t
                         const float* keypoints3d, long long kpts_bstride, const float* desc3d_c, long long desc_c_bstride,
                         const float* desc3d_f, long long desc_f_bstride, long long desc_f_cstride, const float* x3d_external,
                         void* host_dst, size_t host_bytes, void* s_main, void* s_prep, void* s_fine, void* s_copy, int* slot);
-int ophip_frame_wait(int slot);
+int ophip_frame_wait(int ticket);
 int ophip_frame_order_after_fine(void* compute_stream);
 
 /* Row f-1 -- ResNetFPN_8_2 image backbone (backbone/resnet.py:20-44 BasicBlock, :85-164; called at

@@ -2,8 +2,10 @@
  *
  * Replaces the reference's `ransac_PnP` (src/utils/metric_utils.py:121-209; called at inference.py:181-189 with
  * pnp_reprojection_error = 7, and at :328-336), which delegates to pycolmap / OpenCV.  north_star keeps PnP on the
- * host.  The estimator is the build's own (6-point DLT hypotheses, adaptive RANSAC, Levenberg-Marquardt refinement;
- * deterministic for a given seed) -- see onepose_st_amd/csrc_host/pnp.cpp.
+ * host.  The estimator is the build's own (P3P or 6-point DLT hypotheses, RANSAC with the reference branch's trial policy,
+ * Levenberg-Marquardt refinement; deterministic for a given seed) -- see onepose_st_amd/csrc_host/pnp.cpp.
+ * `solver`: 1 = P3P minimal samples, every root scored (what pycolmap.absolute_pose_estimation runs: metric_utils.py:155-165,
+ * the `use_pycolmap_ransac=True` branch); 0 = 6-point DLT with a P3P fallback for coplanar samples (the OpenCV branch, :188-196).
  */
 #ifndef ONEPOSE_PNP_H
 #define ONEPOSE_PNP_H
@@ -18,8 +20,12 @@ int oppnp_abi_version(void);
  * Returns 0 on success, 1 when no pose was found (fewer than 6 correspondences / inliers: pose_out = identity, like the
  * reference's cv2.error branch), -1 on invalid arguments. */
 int oppnp_ransac(const double* K, const float* pts2d, const float* pts3d, int n, double reproj_err_px, double confidence,
-                 int min_iters, int max_iters, unsigned long long seed, double* pose_out, unsigned char* inlier_mask,
+                 int min_iters, int max_iters, unsigned long long seed, int solver, double* pose_out, unsigned char* inlier_mask,
                  int* n_inliers, int* iters_run);
+
+/* The P3P minimal solver alone: rays3x2 = three normalised image points (x, y) = K^-1 (u, v, 1), X3x3 = their world points;
+ * poses4x12 receives up to four [R | t] (row-major); returns their number. */
+int oppnp_p3p(const double* rays3x2, const double* X3x3, double* poses4x12);
 
 /* Asynchronous pool: library-owned host threads solve poses while the caller keeps feeding the GPU (the per-frame path
  * has no Python in it).  submit copies its inputs and returns a ticket 0, 1, 2, ...; wait_all blocks until every
@@ -27,7 +33,7 @@ int oppnp_ransac(const double* K, const float* pts2d, const float* pts3d, int n,
 void* oppnp_pool_create(int threads);
 void oppnp_pool_destroy(void* pool);
 long long oppnp_pool_submit(void* pool, const double* K, const float* pts2d, const float* pts3d, int n, double reproj_err_px,
-                            double confidence, int min_iters, int max_iters, unsigned long long seed);
+                            double confidence, int min_iters, int max_iters, unsigned long long seed, int solver);
 long long oppnp_pool_wait_all(void* pool);
 int oppnp_pool_result(void* pool, long long ticket, double* pose_out, int* n_inliers);
 

@@ -202,107 +202,6 @@ __global__ __launch_bounds__(256) void sim_stats_kernel(SimArgs p) {
     sim_epilogue<false>(acc, p, reinterpret_cast<float*>(smem_f), tid, i0, j0, b);
 }
 
-// Same tile on the bf16 matrix pipe.  K chunks of 64 features are staged as (hi, lo) bf16 planes with a 144-byte row
-// pitch (128 + 16: conflict-free ds_read_b128 for rows distinct mod 16); 72 KiB of LDS -> two workgroups per CU.
-constexpr int SKC = 64, SPITCH = SKC * 2 + 16;
-
-template <int NS>
-__global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_stats_bf16_kernel(SimArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int PL = NS == 3 ? 2 : 1;
-    constexpr int PB = TM * SPITCH;                    // bytes per plane
-    char* AH = smem;
-    char* AL = smem + (PL - 1) * PB;
-    char* BH = smem + PL * PB;
-    char* BL = BH + (PL - 1) * PB;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
-    const int j0 = blockIdx.x * TN, i0 = blockIdx.y * TM, b = blockIdx.z;
-    const float* A = p.a + (size_t)b * p.N * C;
-    const float* Bq = p.bq + (size_t)b * p.M * C;
-
-    f32x4 ra[4][2], rb[4][2];
-    auto prefetch = [&](int kc) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = tid + 256 * u, row = idx >> 3, c8 = idx & 7;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const float* sa = A + (size_t)(i0 + row) * C + kc * SKC + 8 * c8;
-            const float* sb = Bq + (size_t)(j0 + row) * C + kc * SKC + 8 * c8;
-            const bool va = i0 + row < p.N, vb = j0 + row < p.M;
-            ra[u][0] = va ? *reinterpret_cast<const f32x4*>(sa) : z;
-            ra[u][1] = va ? *reinterpret_cast<const f32x4*>(sa + 4) : z;
-            rb[u][0] = vb ? *reinterpret_cast<const f32x4*>(sb) : z;
-            rb[u][1] = vb ? *reinterpret_cast<const f32x4*>(sb + 4) : z;
-        }
-    };
-    auto stage = [&]() {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = tid + 256 * u, row = idx >> 3, c8 = idx & 7;
-            bf16x8 ah, al, bh, bl;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                __bf16 hh, ll;
-                split_bf16(ra[u][j >> 2][j & 3] * 0.0625f, hh, ll);     // feat / sqrt(C), exact power of two
-                ah[j] = hh; al[j] = ll;
-                split_bf16(rb[u][j >> 2][j & 3] * 0.0625f, hh, ll);
-                bh[j] = hh; bl[j] = ll;
-            }
-            const int off = row * SPITCH + 16 * c8;
-            *reinterpret_cast<bf16x8*>(AH + off) = ah;
-            *reinterpret_cast<bf16x8*>(BH + off) = bh;
-            if (NS == 3) {
-                *reinterpret_cast<bf16x8*>(AL + off) = al;
-                *reinterpret_cast<bf16x8*>(BL + off) = bl;
-            }
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) acc[x][y] = zero16();
-    const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    OPHIP_STAMP(p.stamps, wg, 0);
-    prefetch(0);
-    stage();
-    __syncthreads();
-    OPHIP_STAMP(p.stamps, wg, 1);
-    constexpr int NKC = C / SKC;
-    for (int kc = 0; kc < NKC; ++kc) {
-        if (kc + 1 < NKC) prefetch(kc + 1);
-#pragma unroll
-        for (int kb = 0; kb < SKC / 16; ++kb) {
-            bf16x8 fah[2], fal[2], fbh[2], fbl[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int oa = (64 * wr + 32 * t + r) * SPITCH + 16 * (2 * kb + h);
-                const int ob = (64 * wc + 32 * t + r) * SPITCH + 16 * (2 * kb + h);
-                fah[t] = *reinterpret_cast<const bf16x8*>(AH + oa);
-                fbh[t] = *reinterpret_cast<const bf16x8*>(BH + ob);
-                fal[t] = (NS == 3) ? *reinterpret_cast<const bf16x8*>(AL + oa) : zero_bf8();
-                fbl[t] = (NS == 3) ? *reinterpret_cast<const bf16x8*>(BL + ob) : zero_bf8();
-            }
-#pragma unroll
-            for (int x = 0; x < 2; ++x)
-#pragma unroll
-                for (int y = 0; y < 2; ++y) acc[x][y] = mma_bf16<NS>(fah[x], fal[x], fbh[y], fbl[y], acc[x][y]);
-        }
-        OPHIP_STAMP(p.stamps, wg, 2 + 3 * kc);
-        __syncthreads();
-        OPHIP_STAMP(p.stamps, wg, 3 + 3 * kc);
-        if (kc + 1 < NKC) {
-            stage();
-            __syncthreads();
-        }
-        OPHIP_STAMP(p.stamps, wg, 4 + 3 * kc);
-    }
-    sim_epilogue<true>(acc, p, reinterpret_cast<float*>(smem), tid, i0, j0, b);
-    OPHIP_STAMP(p.stamps, wg, 31);
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------
 // Fragment-plane form of the bf16 modes (default).  frag_planes turns both encoder outputs once into (hi, lo) bf16 planes,
 // scaled by 1/sqrt(C) = 1/16 (exact), laid out as the MFMA operand fragments themselves: for 32-row tile T and k-step s
@@ -957,10 +856,9 @@ int coarse_impl(int parts, const float* feat3d, const float* feat2d, const float
     float* rowbest = colstat + (size_t)B * M * 2;
     float* colmax = rowbest + (size_t)B * nspan * N * 3;
 
-    // bf16 modes: fragment planes + LDS-DMA tile kernel (OPHIP_SIM_V1=1 selects the round-1 kernel that converts inside every tile)
-    static const bool sim_v1 = getenv("OPHIP_SIM_V1") != nullptr;
+    // bf16 modes: fragment planes + LDS-DMA tile kernel; exact-f32 mode: the f32-MFMA tile kernel (true maxima, libm)
     const int sel_nspan = nspan;
-    if ((parts & 1) && nsplit != 0 && !sim_v1) {
+    if ((parts & 1) && nsplit != 0) {
         char *fa_, *fb_;
         frag_plane_ptrs(workspace, B, N, M, &fa_, &fb_);
         if (!planes_ready) {
@@ -977,17 +875,11 @@ int coarse_impl(int parts, const float* feat3d, const float* feat2d, const float
         OPHIP_CHECK_LAUNCH();
     } else if (parts & 1) {
         SimArgs sa{feat3d, feat2d, conf, rowpart, colpart, N, M, ntr, ntc, (float)(temperature + 1e-4), ophip_stamp_buffer()};
-        {
-            // dynamic LDS = max(operand tiles, S staging image of the epilogue)
-            const size_t tiles = nsplit == 0 ? (size_t)(TM + TN) * LDT * sizeof(float) : (size_t)(nsplit == 3 ? 4 : 2) * TM * SPITCH;
-            const size_t lds = tiles > SIM_STAGE_BYTES ? tiles : SIM_STAGE_BYTES;
-            const void* fn = nsplit == 0 ? reinterpret_cast<const void*>(sim_stats_kernel)
-                           : nsplit == 3 ? reinterpret_cast<const void*>(sim_stats_bf16_kernel<3>) : reinterpret_cast<const void*>(sim_stats_bf16_kernel<1>);
-            if (int rc = ophip_lds_attr(fn, lds, "hipFuncSetAttribute(sim_stats)")) return rc;
-            if (nsplit == 0) OPHIP_LAUNCH("sim_stats", stream, sim_stats_kernel, dim3(ntc, ntr, B), dim3(256), lds, stream, sa);
-            else if (nsplit == 3) OPHIP_LAUNCH("sim_stats", stream, sim_stats_bf16_kernel<3>, dim3(ntc, ntr, B), dim3(256), lds, stream, sa);
-            else OPHIP_LAUNCH("sim_stats", stream, sim_stats_bf16_kernel<1>, dim3(ntc, ntr, B), dim3(256), lds, stream, sa);
-        }
+        // dynamic LDS = max(operand tiles, S staging image of the epilogue)
+        const size_t tiles = (size_t)(TM + TN) * LDT * sizeof(float);
+        const size_t lds = tiles > SIM_STAGE_BYTES ? tiles : SIM_STAGE_BYTES;
+        if (int rc = ophip_lds_attr(reinterpret_cast<const void*>(sim_stats_kernel), lds, "hipFuncSetAttribute(sim_stats)")) return rc;
+        OPHIP_LAUNCH("sim_stats", stream, sim_stats_kernel, dim3(ntc, ntr, B), dim3(256), lds, stream, sa);
         OPHIP_CHECK_LAUNCH();
     }
     if (parts & 1) {

@@ -327,12 +327,9 @@ int launch_conv_tile(const ConvArgs& a, int B, hipStream_t stream) {
 // activation fragment NT times (less L2 / vector-memory / LDS traffic per FLOP) but give fewer, register-heavier waves.
 // Measured per layer at 480 x 640 (tools/bench_backbone_hip.py, B = 1 and 4): (2, 2) wins whenever it yields >= 2 waves
 // per SIMD; below that the 1/4-resolution maps take (2, 1), the 1/8-resolution maps (1, 1); stride-2 convolutions (large
-// input patch per tile) prefer to stay at 2 channel tiles per wave; (4, x) never won and is reachable only through
-// OPHIP_CONV_TH / OPHIP_CONV_NT (diagnostics).
+// input patch per tile) prefer to stay at 2 channel tiles per wave; (4, x) never won and is not built.
 template <int KS, int STRIDE, int NS>
 int launch_conv(const ConvArgs& a, int B, hipStream_t stream) {
-    static const int th_env = [] { const char* e = getenv("OPHIP_CONV_TH"); return e ? atoi(e) : 0; }();
-    static const int nt_env = [] { const char* e = getenv("OPHIP_CONV_NT"); return e ? atoi(e) : 0; }();
     const long w22 = (long)((a.Wout + TW - 1) / TW) * ((a.Hout + 1) / 2) * B * ((a.ctiles + 3) / 4) * 2;      // waves of the (2, 2) shape
     int th = 2, nt = 2;
     if (KS == 3 && STRIDE == 1) {
@@ -344,16 +341,10 @@ int launch_conv(const ConvArgs& a, int B, hipStream_t stream) {
     } else if (w22 < 2000) {
         th = 1;
     }
-    if (th_env == 1 || th_env == 2 || th_env == 4) th = th_env;
-    if (nt_env == 1 || nt_env == 2) nt = nt_env;
     // wave rows per workgroup: 2 (a 4-wave workgroup on a shared patch: halo 1.6x instead of 2.1x at TH = 2) when the map is
-    // tall enough to keep the grid full; OPHIP_CONV_WR forces it
-    static const int wr_env = [] { const char* e = getenv("OPHIP_CONV_WR"); return e ? atoi(e) : 0; }();
-    int wrows = (th <= 2 && KS == 3 && STRIDE == 1 && w22 >= 2000) ? 2 : 1;
-    if (wr_env == 1 || wr_env == 2) wrows = wr_env;
-    if (th == 4) wrows = 1;
+    // tall enough to keep the grid full
+    const int wrows = (KS == 3 && STRIDE == 1 && w22 >= 2000) ? 2 : 1;
 #define OPHIP_CONV_CASE(TH_, NT_, WR_) if (th == TH_ && nt == NT_ && wrows == WR_) return launch_conv_tile<KS, STRIDE, NS, TH_, NT_, WR_>(a, B, stream);
-    OPHIP_CONV_CASE(4, 2, 1) OPHIP_CONV_CASE(4, 1, 1)
     OPHIP_CONV_CASE(2, 2, 1) OPHIP_CONV_CASE(2, 1, 1) OPHIP_CONV_CASE(1, 2, 1) OPHIP_CONV_CASE(1, 1, 1)
     OPHIP_CONV_CASE(2, 2, 2) OPHIP_CONV_CASE(2, 1, 2) OPHIP_CONV_CASE(1, 2, 2) OPHIP_CONV_CASE(1, 1, 2)
 #undef OPHIP_CONV_CASE

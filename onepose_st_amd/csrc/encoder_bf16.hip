@@ -230,264 +230,6 @@ __device__ __forceinline__ void layernorm_featrow(f32x16 (&m)[2][TT], const floa
     }
 }
 
-// LayerNorm for the 8-wave feature-split kernel: wave w holds features 32 w .. 32 w + 31 of all TT token tiles.
-template <int TT>
-__device__ __forceinline__ void layernorm_featrow8(f32x16 (&m)[1][TT], const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                   float* scratch, int w, int lane) {
-    const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt) {
-        float s = 0.f;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) s += m[0][tt][reg];
-        s += __shfl_xor(s, 32, 64);
-        if (h == 0) scratch[w * 64 + 32 * tt + r] = s;
-    }
-    __syncthreads();
-    float mean[TT];
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt) {
-        const int tok = 32 * tt + r;
-        float t = 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) t += scratch[q * 64 + tok];
-        mean[tt] = t * (1.0f / C);
-        float qq = 0.f;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const float d = m[0][tt][reg] - mean[tt];
-            qq += d * d;
-        }
-        qq += __shfl_xor(qq, 32, 64);
-        if (h == 0) scratch[512 + w * 64 + tok] = qq;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt) {
-        const int tok = 32 * tt + r;
-        float t = 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) t += scratch[512 + q * 64 + tok];
-        const float rstd = 1.0f / sqrtf(t * (1.0f / C) + 1e-5f);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int f0 = 32 * w + 8 * g + 4 * h;
-            const f32x4 gv = *reinterpret_cast<const f32x4*>(gamma + f0);
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(beta + f0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) m[0][tt][4 * g + j] = (m[0][tt][4 * g + j] - mean[tt]) * rstd * gv[j] + bv[j];
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// attn_apply, 8-wave feature-split form ("F8"): a workgroup owns 64 tokens (two MFMA token tiles) and its 8 waves split the
-// FEATURE tiles -- wave w = head w = features 32 w .. 32 w + 31 -- so every weight fragment is fetched by exactly one wave and
-// feeds two token tiles: half the weight stream per token of the 32-token form, at two waves per SIMD (the 4-wave TT = 2
-// form has the same traffic but one wave per SIMD).  The MLP's first GEMM has only 4 output tiles per 128-wide hidden chunk:
-// wave (t, khalf) contracts tile t over the x half (khalf 0) or the msg half (khalf 1) of K = 512; the msg halves hand their
-// partial sums over through the (idle) hidden-chunk planes as f32.
-// Measured at c2 (OPHIP_ENC_F8=1, parity-green): 70 us per launch, the same as the default 32-token form (two independent
-// workgroups per CU, 69-71 us) and the 4-wave TT = 2 form (70 us), also at 4 frames per step: halving the weight stream buys
-// nothing because the eight waves of one workgroup move through GEMM and epilogue phases in barrier lock-step, so MFMA and
-// VALU / LDS phases do not overlap inside it -- what two independent workgroups get for free.  It stays an option.
-// ---------------------------------------------------------------------------------------------------------------------------
-template <int NS>
-__global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void attn_apply_f8_kernel(AttnBArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int PL = NS == 3 ? 2 : 1;
-    constexpr int TT = 2, TOK = 64, NT_ = 512;
-    constexpr int F8PD = 4;                          // weight-ring depth (k-blocks)
-    constexpr int XB = TOK * ROWB, HB = TOK * HROWB;
-    char* XH = smem;
-    char* XL = smem + (PL - 1) * XB;
-    char* YH = smem + PL * XB;
-    char* YL = YH + (PL - 1) * XB;
-    char* HH = smem + 2 * PL * XB;
-    char* HL = HH + (PL - 1) * HB;
-    float* scratch = reinterpret_cast<float*>(HH);          // LayerNorm exchange / MLP partial sums; H is idle then
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int tile = blockIdx.x, b = blockIdx.y;
-    const int s = tile >= a.tiles[0] ? 1 : 0;
-    const int lt = s ? tile - a.tiles[0] : tile;
-    const int L = a.L[s], tok0 = lt * TOK;
-    const float* xg = a.x[s] + (size_t)b * a.xbs[s];
-
-    const bf16x8 *wq_hi = a.w_hi + (size_t)w * TS + lane, *wq_lo = a.w_lo + (size_t)w * TS + lane;
-    const bf16x8 *wm_hi = a.w_hi + 3 * C * C / 8 + (size_t)w * TS + lane, *wm_lo = a.w_lo + 3 * C * C / 8 + (size_t)w * TS + lane;
-    const int mt = w & 3, khalf = w >> 2;            // MLP-up role: output tile of the chunk, K half
-    const bf16x8 *w0_hi = a.w_hi + 4 * C * C / 8 + (size_t)mt * TS2 + (size_t)khalf * 16 * 64 + lane;
-    const bf16x8 *w0_lo = a.w_lo + 4 * C * C / 8 + (size_t)mt * TS2 + (size_t)khalf * 16 * 64 + lane;
-    const bf16x8 *w2_hi = a.w_hi + 8 * C * C / 8 + (size_t)w * TS2 + lane, *w2_lo = a.w_lo + 8 * C * C / 8 + (size_t)w * TS2 + lane;
-
-    WRing<1, F8PD, NS> rq;
-    rq.fill(wq_hi, wq_lo, TS);
-    load_rows_to_planes<NS, C, TOK>(XH, XL, xg, tok0, L, tid, NT_);
-    __syncthreads();
-
-    // ---- Q projection of head w, phi, linear attention from registers ----------------------------------------
-    WRing<1, F8PD, NS> rm;
-    {
-        f32x16 q[1][TT];
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt) q[0][tt] = zero16();
-        gemm_bf16_ring<1, TT, NS, true, KB, F8PD>(q, rq, wq_hi, wq_lo, TS, XH, XL, ROWB, 0, lane);
-        rm.fill(wm_hi, wm_lo, TS);
-        const char* kvb = a.kv[s] + (size_t)b * a.kvbs;
-        const float* ksum = reinterpret_cast<const float*>(kvb + KV_FRAG_BYTES);
-        const float S = a.srclen[s];
-        const int head = w;
-        f32x16 num[TT], den[TT];
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt) {
-            num[tt] = zero16(); den[tt] = zero16();
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) q[0][tt][reg] = elu_plus_one_fast(q[0][tt][reg]);
-        }
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            const bf16x8 kvh = *reinterpret_cast<const bf16x8*>(kvb + ((size_t)((head * 2 + st) * 2 + 0) * 64 + lane) * 16);
-            const bf16x8 kvl = (NS == 3) ? *reinterpret_cast<const bf16x8*>(kvb + ((size_t)((head * 2 + st) * 2 + 1) * 64 + lane) * 16) : zero_bf8();
-            const float* kp = ksum + head * 32 + h * 16 + 8 * st;
-            bf16x8 ksh, ksl;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                __bf16 hh2, ll2;
-                split_bf16(kp[j], hh2, ll2);
-                ksh[j] = hh2;
-                ksl[j] = (NS == 3) ? ll2 : (__bf16)0.f;
-            }
-#pragma unroll
-            for (int tt = 0; tt < TT; ++tt) {
-                bf16x8 qh, ql;
-                acc_frag<NS>(q[0][tt], st, qh, ql);
-                num[tt] = mma_bf16<NS>(kvh, kvl, qh, ql, num[tt]);
-                den[tt] = mma_bf16<NS>(ksh, ksl, qh, ql, den[tt]);
-            }
-        }
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt) {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) num[tt][reg] = num[tt][reg] * rcp_fast(den[tt][reg] + 1e-6f) * S;
-            store_featrow_acc<NS>(num[tt], YH, YL, ROWB, 32 * head, 32 * tt, lane);
-        }
-    }
-    __syncthreads();
-    // ---- merge + LayerNorm 1 -> Y --------------------------------------------------------------------------
-    WRing<1, F8PD, NS> r0;
-    {
-        f32x16 m[1][TT];
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt) m[0][tt] = zero16();
-        gemm_bf16_ring<1, TT, NS, true, KB, F8PD>(m, rm, wm_hi, wm_lo, TS, YH, YL, ROWB, 0, lane);
-        r0.fill(w0_hi, w0_lo, TS2);
-        layernorm_featrow8<TT>(m, a.ln, a.ln + C, scratch, w, lane);      // its first barrier also fences the reads of Y above
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt) store_featrow_acc<NS>(m[0][tt], YH, YL, ROWB, 32 * w, 32 * tt, lane);
-    }
-    __syncthreads();
-    // ---- MLP: hidden = relu([x, msg] W0^T) in four 128-feature chunks, o += hidden_chunk W2[:, chunk]^T ------------
-    f32x16 o[1][TT];
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt) o[0][tt] = zero16();
-    for (int c = 0; c < 4; ++c) {
-        f32x16 hd[1][TT];
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt) hd[0][tt] = zero16();
-        const size_t wt = (size_t)(4 * c) * TS2;
-        gemm_bf16_ring<1, TT, NS, true, 16, F8PD>(hd, r0, w0_hi + wt, w0_lo + wt, TS2, khalf ? YH : XH, khalf ? YL : XL, ROWB, 0, lane);
-        WRing<1, F8PD, NS> r2;
-        r2.fill(w2_hi + (size_t)(8 * c) * 64, w2_lo + (size_t)(8 * c) * 64, TS2);
-        // partial sums of the msg halves -> f32 scratch [tile][tt][quad][lane] (conflict-free 16-byte slots)
-        char* part = HH;
-        if (khalf == 1) {
-#pragma unroll
-            for (int tt = 0; tt < TT; ++tt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 v = {hd[0][tt][4 * g], hd[0][tt][4 * g + 1], hd[0][tt][4 * g + 2], hd[0][tt][4 * g + 3]};
-                    *reinterpret_cast<f32x4*>(part + ((size_t)((mt * TT + tt) * 4 + g) * 64 + lane) * 16) = v;
-                }
-        }
-        __syncthreads();
-        if (khalf == 0) {
-#pragma unroll
-            for (int tt = 0; tt < TT; ++tt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(part + ((size_t)((mt * TT + tt) * 4 + g) * 64 + lane) * 16);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) hd[0][tt][4 * g + j] = fmaxf(hd[0][tt][4 * g + j] + v[j], 0.f);
-                }
-        }
-        __syncthreads();                             // partial sums consumed before the planes overwrite them
-        if (khalf == 0) {
-#pragma unroll
-            for (int tt = 0; tt < TT; ++tt) store_featrow_acc<NS>(hd[0][tt], HH, HL, HROWB, 32 * mt, 32 * tt, lane);
-        }
-        __syncthreads();
-        gemm_bf16_ring<1, TT, NS, true, 8, F8PD>(o, r2, w2_hi + (size_t)(8 * c) * 64, w2_lo + (size_t)(8 * c) * 64, TS2, HH, HL, HROWB, 0, lane);
-        if (c + 1 < 4) r0.fill(w0_hi + wt + (size_t)4 * TS2, w0_lo + wt + (size_t)4 * TS2, TS2);
-        __syncthreads();
-    }
-    layernorm_featrow8<TT>(o, a.ln + 2 * C, a.ln + 3 * C, scratch, w, lane);
-    // ---- stage LN2 output as f32 [TOK][256] over the (now dead) X / Y planes, then x + msg with whole-row stores ----
-    char* stage = smem;
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int row = 32 * tt + r;
-            const int ch = 8 * w + 2 * g + h;                    // 16-byte chunk of the f32 row
-            f32x4 v = {o[0][tt][4 * g], o[0][tt][4 * g + 1], o[0][tt][4 * g + 2], o[0][tt][4 * g + 3]};
-            *reinterpret_cast<f32x4*>(stage + row * (C * 4) + ((ch ^ (row & 15)) << 4)) = v;
-        }
-    __syncthreads();
-    float* yg = a.y[s] + (size_t)b * a.ybs[s];
-    const bool fuse = a.nkv_hi != nullptr;
-    // next layer's K|V weights of head w: K tile 4 (w >> 1) + (w & 1), V tile two further
-    WRing<2, 2, NS> rkv;
-    const bf16x8* nhi = a.nkv_hi + (size_t)(4 * (w >> 1) + (w & 1)) * TS + lane;
-    const bf16x8* nlo = a.nkv_lo + (size_t)(4 * (w >> 1) + (w & 1)) * TS + lane;
-    if (fuse) rkv.fill(nhi, nlo, 2 * TS);
-    char* KH = smem + TOK * C * 4;
-    char* KL = KH + (PL - 1) * XB;
-    for (int i = tid; i < TOK * (C / 4); i += NT_) {
-        const int row = i / (C / 4), ch = i % (C / 4);
-        f32x4 yv = {0.f, 0.f, 0.f, 0.f};
-        if (tok0 + row < L) {
-            const f32x4 mv = *reinterpret_cast<const f32x4*>(stage + row * (C * 4) + ((ch ^ (row & 15)) << 4));
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(xg + (size_t)(tok0 + row) * C + 4 * ch);
-            yv = xv + mv;
-            *reinterpret_cast<f32x4*>(yg + (size_t)(tok0 + row) * C + 4 * ch) = yv;
-        }
-        if (fuse) {
-            bf16x4 vh, vl;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                __bf16 hh, ll;
-                split_bf16(yv[j], hh, ll);
-                vh[j] = hh; vl[j] = ll;
-            }
-            const int off = plane_off(row, ch >> 1, ROWB) + 8 * (ch & 1);
-            *reinterpret_cast<bf16x4*>(KH + off) = vh;
-            if (NS == 3) *reinterpret_cast<bf16x4*>(KL + off) = vl;
-        }
-    }
-    if (fuse) {
-        __syncthreads();
-        float* out = a.npartial + ((size_t)b * (a.slabs[0] + a.slabs[1]) + (s ? a.slabs[0] : 0) + TT * lt) * KV_PART_FLOATS;
-        // one token tile at a time (the two-tile form needs 64 accumulator registers more than the 256 an 8-wave workgroup
-        // leaves per lane; the K|V fragments of one head are fetched twice instead: +64 KB of the 2.5 MB per workgroup)
-        kv_slab_from_planes<NS, 1, 1>(rkv, nhi, nlo, KH, KL, tok0, L, out, 0, lane, 2 * TS, w);
-        if (tok0 + 32 < L) {
-            rkv.fill(nhi, nlo, 2 * TS);
-            kv_slab_from_planes<NS, 1, 1>(rkv, nhi, nlo, KH + 32 * ROWB, KL + 32 * ROWB, tok0 + 32, L, out + KV_PART_FLOATS, 0, lane, 2 * TS, w);
-        }
-    }
-}
-
 template <int NS, int TT>
 __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(TT == 1 ? 2 : 1, TT == 1 ? 2 : 1) void attn_apply_bf16_kernel(AttnBArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -704,18 +446,12 @@ extern "C" int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, floa
                                         void* workspace, void* stream_) {
     if (!x3d || !x2d || !y3d || !y2d || !wpack || !workspace) return ophip_bad_arg(__func__, "null pointer");
     if (B < 1 || L3d < 1 || L2d < 1) return ophip_bad_arg(__func__, "B, L3d, L2d must be >= 1");
-    if (nsplit != 1 && nsplit != 3) return ophip_bad_arg(__func__, "nsplit must be 1 (bf16) or 3 (split bf16)");
+    if (nsplit != 1) return ophip_bad_arg(__func__, "nsplit must be 1: this is the plain-bf16 mode's layer (split-bf16: ophip_encoder_layer_x3w8)");
     if (slot != 0 && slot != 1) return ophip_bad_arg(__func__, "slot must be 0 or 1");
     if (x3d == y3d || x2d == y2d) return ophip_bad_arg(__func__, "in-place layer is not supported (cross layers read the pre-update streams)");
     hipStream_t stream = (hipStream_t)stream_;
-    // token tiles per attn_apply workgroup (see the header).  Measured at c2 (split mode): TT = 1 (32-token workgroups,
-    // two per CU, 2 waves per SIMD) 69 us per launch at B = 1 and 51 us per frame at B = 4; TT = 2 (64 tokens, one
-    // workgroup per CU, weights fetched half as often but a single wave per SIMD, so nothing covers its epilogues)
-    // 70 / 52 us.  TT = 1 is the default, OPHIP_ENC_TT=2 selects the other.  kv_reduce always works on 32-token tiles.
-    static const int tt_env = [] { const char* e = getenv("OPHIP_ENC_TT"); return e ? atoi(e) : 0; }();
-    static const int f8_env = [] { const char* e = getenv("OPHIP_ENC_F8"); return e ? atoi(e) : 0; }();
-    const bool f8 = f8_env == 1;                 // 8-wave feature-split kernel (64-token workgroups)
-    const int TT = (tt_env == 2 || f8) ? 2 : 1;
+    // 32-token workgroups, two per CU (TT = 1); kv_reduce works on 32-token tiles as well
+    constexpr int TT = 1;
     const int TOK = 32 * TT;
     const int t3 = (L3d + TOK - 1) / TOK, t2 = (L2d + TOK - 1) / TOK;
     const int s3 = (L3d + 31) / 32, s2 = (L2d + 31) / 32;
@@ -743,8 +479,7 @@ extern "C" int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, floa
             if (int rc = set_lds(kv_reduce_bf16_kernel<NS_, 32>, lds_kv, "hipFuncSetAttribute(kv_reduce_bf16)")) return rc; \
             OPHIP_LAUNCH("kv_reduce", stream, (kv_reduce_bf16_kernel<NS_, 32>), dim3(s3 + s2, B), dim3(256), lds_kv, stream, ka);  \
         }
-        if (nsplit == 3) OPHIP_KV_CASE(3)
-        else OPHIP_KV_CASE(1)
+        OPHIP_KV_CASE(1)
 #undef OPHIP_KV_CASE
         OPHIP_CHECK_LAUNCH();
     }
@@ -780,21 +515,7 @@ extern "C" int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, floa
         if (int rc = set_lds(attn_apply_bf16_kernel<NS_, TT_>, lds_at, "hipFuncSetAttribute(attn_apply_bf16)")) return rc; \
         OPHIP_LAUNCH("attn_apply", stream, (attn_apply_bf16_kernel<NS_, TT_>), dim3(t3 + t2, B), dim3(256), lds_at, stream, aa);    \
     }
-    if (f8) {
-        const size_t lds_f8 = (size_t)2 * PL * TOK * ROWB + 32768;       // X, Y planes + max(hidden planes, f32 partial sums)
-        if (lds_f8 > lds_at) lds_at = lds_f8;
-        if (nsplit == 3) {
-            if (int rc = set_lds(attn_apply_f8_kernel<3>, lds_at, "hipFuncSetAttribute(attn_apply_f8)")) return rc;
-            OPHIP_LAUNCH("attn_apply", stream, (attn_apply_f8_kernel<3>), dim3(t3 + t2, B), dim3(512), lds_at, stream, aa);
-        } else {
-            if (int rc = set_lds(attn_apply_f8_kernel<1>, lds_at, "hipFuncSetAttribute(attn_apply_f8)")) return rc;
-            OPHIP_LAUNCH("attn_apply", stream, (attn_apply_f8_kernel<1>), dim3(t3 + t2, B), dim3(512), lds_at, stream, aa);
-        }
-    }
-    else if (nsplit == 3 && TT == 2) OPHIP_AT_CASE(3, 2)
-    else if (nsplit == 3) OPHIP_AT_CASE(3, 1)
-    else if (TT == 2) OPHIP_AT_CASE(1, 2)
-    else OPHIP_AT_CASE(1, 1)
+    OPHIP_AT_CASE(1, 1)
 #undef OPHIP_AT_CASE
     OPHIP_CHECK_LAUNCH();
     return 0;

@@ -430,9 +430,8 @@ extern "C" int ophip_fine_refine_bf16(const float* feat_f, long long fs_b, long 
     a.expec_f = expec_f; a.mkq_f = mkpts_f; a.dbg_win = dbg_win; a.dbg_f3 = dbg_f3;
     a.stamps = ophip_stamp_buffer();
     hipStream_t stream = (hipStream_t)stream_;
-    // one match per 4-wave workgroup (two independent workgroups per CU) unless OPHIP_FINE_NM=2 asks for the 8-wave pairing
-    static const int nm_env = [] { const char* e = getenv("OPHIP_FINE_NM"); return e ? atoi(e) : 0; }();
-    const int NM = nm_env == 2 ? 2 : 1;
+    // one match per 4-wave workgroup, two independent workgroups per CU
+    constexpr int NM = 1;
     const int grid = (max_matches + NM - 1) / NM;
     const size_t lds = (size_t)NM * (nsplit == 3 ? (16 + 16 + 32) : (8 + 8 + 16)) * 1024;
 #define OPHIP_FINE_CASE(NS_, NM_)                                                                                               \
@@ -440,9 +439,7 @@ extern "C" int ophip_fine_refine_bf16(const float* feat_f, long long fs_b, long 
         if (int rc = set_lds(fine_refine_bf16_kernel<NS_, NM_>, lds, "hipFuncSetAttribute(fine_refine_bf16)")) return rc; \
         OPHIP_LAUNCH("fine_refine", stream, (fine_refine_bf16_kernel<NS_, NM_>), dim3(grid), dim3(NM_ * 256), lds, stream, a);  \
     }
-    if (nsplit == 3 && NM == 2) OPHIP_FINE_CASE(3, 2)
-    else if (nsplit == 3) OPHIP_FINE_CASE(3, 1)
-    else if (NM == 2) OPHIP_FINE_CASE(1, 2)
+    if (nsplit == 3) OPHIP_FINE_CASE(3, 1)
     else OPHIP_FINE_CASE(1, 1)
 #undef OPHIP_FINE_CASE
     OPHIP_CHECK_LAUNCH();

@@ -16,6 +16,8 @@ constexpr int kSlots = 16;          // frames that may be in flight between enqu
 struct Slot {
     hipEvent_t prep_done = nullptr, coarse_done = nullptr, fine_done = nullptr, ready = nullptr;
     int dev = -1;
+    int gen = 0;                     // how often the slot has been handed out: a ticket is gen * kSlots + index
+    bool recorded = false;           // `ready` has been recorded for the current generation
 };
 struct DevState {
     Slot slots[kSlots];
@@ -97,8 +99,8 @@ extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_
     int dev = 0;
     FR_HIP(hipGetDevice(&dev), "hipGetDevice");
     Slot* slot;
-    int idx;
-    hipEvent_t prev_fine = nullptr;
+    int idx, gen;
+    hipEvent_t prev_fine = nullptr, prev_ready = nullptr;
     {
         std::lock_guard<std::mutex> lk(g_mu);
         DevState& st = g_dev[dev];
@@ -106,10 +108,17 @@ extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_
         st.next = (st.next + 1) % kSlots;
         slot = &st.slots[idx];
         FR_CHECK(make_events(*slot, dev));
+        if (slot->recorded) prev_ready = slot->ready;
         auto it = st.last_fine.find(s_main);
         if (it != st.last_fine.end()) prev_fine = it->second;
-        if (st.last_fine.size() > 64) st.last_fine.clear();
-        st.last_fine[s_main] = slot->fine_done;
+    }
+    // a slot comes round again after kSlots frames: its previous frame must have left the GPU before its events are re-recorded
+    // (normally long done -- a pipeline keeps a few frames in flight --, then this returns at once)
+    if (prev_ready) FR_HIP(hipEventSynchronize(prev_ready), "hipEventSynchronize(slot reuse)");
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        slot->recorded = false;
+        gen = ++slot->gen;
     }
     auto F = [&](size_t off) { return reinterpret_cast<float*>(blob + off); };
     auto I64 = [&](size_t off) { return reinterpret_cast<long long*>(blob + off); };
@@ -185,24 +194,37 @@ extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_
                                     F(L->mkc), d->w_fine, d->n_fine, d->fine_cross_bits, d->fine_encoder_enable, 3, d->wc, d->hf / d->hc, d->fine_scale,
                                     F(L->expec), mk2d, nullptr, nullptr, s_fine));
     FR_HIP(hipEventRecord(slot->fine_done, s_fine), "hipEventRecord(fine)");
+    {                                                       // published only once it is recorded: the next frame on s_main orders behind it
+        std::lock_guard<std::mutex> lk(g_mu);
+        DevState& st = g_dev[dev];
+        if (st.last_fine.size() > 64) st.last_fine.clear();
+        st.last_fine[s_main] = slot->fine_done;
+    }
     // ---- read-back of the result block (count | b_ids | 3D points | refined 2D points) behind the fine stage ---------------------
     FR_HIP(hipStreamWaitEvent(s_copy, slot->fine_done, 0), "hipStreamWaitEvent(fine)");
     FR_HIP(hipMemcpyAsync(host_dst, blob + L->result, host_bytes, hipMemcpyDeviceToHost, s_copy), "hipMemcpyAsync(result block)");
     FR_HIP(hipEventRecord(slot->ready, s_copy), "hipEventRecord(ready)");
-    *slot_out = idx;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        slot->recorded = true;
+    }
+    *slot_out = gen * kSlots + idx;                         // ticket: ophip_frame_wait rejects nothing but knows a reused slot's frame is done
     return 0;
 }
 
-extern "C" int ophip_frame_wait(int slot) {
-    if (slot < 0 || slot >= kSlots) return ophip_bad_arg(__func__, "slot");
+extern "C" int ophip_frame_wait(int ticket) {
+    if (ticket < kSlots) return ophip_bad_arg(__func__, "not a ticket of ophip_frame_enqueue");
+    const int slot = ticket % kSlots, gen = ticket / kSlots;
     int dev = 0;
     FR_HIP(hipGetDevice(&dev), "hipGetDevice");
     hipEvent_t ev;
     {
         std::lock_guard<std::mutex> lk(g_mu);
-        ev = g_dev[dev].slots[slot].ready;
+        const Slot& s = g_dev[dev].slots[slot];
+        if (s.gen > gen) return 0;                          // the slot was handed out again: enqueue waited for this frame before that
+        if (s.gen < gen || !s.recorded) return ophip_bad_arg(__func__, "ticket of a frame that was never (completely) enqueued on this device");
+        ev = s.ready;
     }
-    if (!ev) return ophip_bad_arg(__func__, "slot was never used on this device");
     FR_HIP(hipEventSynchronize(ev), "hipEventSynchronize(frame)");
     return 0;
 }

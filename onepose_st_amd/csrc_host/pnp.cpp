@@ -6,9 +6,14 @@
 // outputs, so this is NOT a restatement of their internals ("parity unpinned"): it is the build's own estimator,
 // applied identically to the HIP path's matches and to the oracle's matches so that pose parity is checkable.
 //
-//   hypotheses : 6-point DLT on calibrated rays: the normal matrix's block structure reduces it to the smallest eigenvector
-//                of a 4x4 Schur complement (inverse iteration), projected to SO(3) by Newton polar iteration, cheirality check;
-//                four samples are solved at a time, one per lane of a 4 x double vector
+//   hypotheses : solver 1 (the pycolmap branch of ransac_PnP, metric_utils.py:155-165: COLMAP's estimator is P3P): three
+//                correspondences -> Grunert's quartic in the depth ratio s3 / s1 (coefficients by polynomial products of the two
+//                eliminated law-of-cosines equations, Ferrari + Newton polish) -> up to four poses by aligning the two point
+//                triangles, every root scored on all points like COLMAP does; works on coplanar objects (box faces, cards);
+//                solver 0 (the OpenCV branch, :188-196): 6-point DLT on calibrated rays: the normal matrix's block structure
+//                reduces it to the smallest eigenvector of a 4x4 Schur complement (inverse iteration), projected to SO(3) by
+//                Newton polar iteration, four samples at a time, one per lane of a 4 x double vector; a sample whose DLT is
+//                singular (coplanar 3D points) is solved by P3P on its first three points, the root picked by the other three
 //   scoring    : reprojection error < threshold (pixels) on a float structure-of-arrays copy (AVX2 / AVX-512 clones of
 //                one loop, hypotheses that cannot win any more dropped block by block); a candidate best is re-scored in
 //                double, which decides; at least min_iters trials (the
@@ -452,6 +457,151 @@ int dlt_pose4(const Problem& P, const int (*idx)[6], double (*pose)[12]) {
     return mask;
 }
 
+
+// ---- P3P minimal solver ---------------------------------------------------------------------------------------------------------
+// Unit bearings f_i, world points P_i, unknown depths s_i with |s_i f_i - s_j f_j| = |P_i - P_j|.  With u = s2 / s1, v = s3 / s1
+// and a, b, c = |P2 P3|, |P1 P3|, |P1 P2|, the three law-of-cosines equations give (Grunert 1841, see Haralick et al. 1994)
+//     u = N(v) / D(v),  N = (p - 1) v^2 - 2 p cos(beta) v + p + 1,  D = 2 (cos(gamma) - v cos(alpha)),  p = (a^2 - c^2) / b^2
+// and, substituted into the third equation, the quartic  D^2 + N^2 - 2 cos(gamma) N D - (c^2 / b^2) (1 - 2 cos(beta) v + v^2) D^2 = 0,
+// whose coefficients are formed here by multiplying the polynomials out (no closed-form coefficient table to get wrong).
+inline double cbrt_s(double x) { return std::cbrt(x); }
+
+// largest real root of z^3 + A z^2 + B z + C
+double cubic_largest_root(double A, double B, double C) {
+    const double a3 = A / 3.0;
+    const double P = B - A * a3, Q = 2.0 * a3 * a3 * a3 - a3 * B + C;
+    const double disc = 0.25 * Q * Q + P * P * P / 27.0;
+    double w;
+    if (disc > 0.0) {
+        const double sq = std::sqrt(disc);
+        w = cbrt_s(-0.5 * Q + sq) + cbrt_s(-0.5 * Q - sq);
+    } else {
+        const double m = 2.0 * std::sqrt(-P / 3.0);
+        double arg = m > 0.0 ? 3.0 * Q / (P * m) : 0.0;
+        arg = arg < -1.0 ? -1.0 : (arg > 1.0 ? 1.0 : arg);
+        w = m * std::cos(std::acos(arg) / 3.0);
+    }
+    double z = w - a3;
+    for (int it = 0; it < 3; ++it) {                       // Newton polish
+        const double f = ((z + A) * z + B) * z + C, df = (3.0 * z + 2.0 * A) * z + B;
+        if (std::fabs(df) < 1e-300) break;
+        z -= f / df;
+    }
+    return z;
+}
+
+// real roots of c4 x^4 + c3 x^3 + c2 x^2 + c1 x + c0 (Ferrari, each root polished on the original polynomial); returns their number
+int quartic_real_roots(const double* c, double* roots) {
+    if (!(std::fabs(c[4]) > 1e-14 * (std::fabs(c[3]) + std::fabs(c[2]) + std::fabs(c[1]) + std::fabs(c[0]) + 1e-300))) return 0;
+    const double a = c[3] / c[4], b = c[2] / c[4], cc = c[1] / c[4], d = c[0] / c[4];
+    const double a2 = a * a;
+    const double p = b - 0.375 * a2, q = cc - 0.5 * a * b + 0.125 * a2 * a, r = d - 0.25 * a * cc + 0.0625 * a2 * b - (3.0 / 256.0) * a2 * a2;
+    double y[4];
+    int n = 0;
+    const double scale = std::fabs(p) + std::sqrt(std::fabs(r)) + 1e-300;
+    if (std::fabs(q) < 1e-12 * scale * std::sqrt(scale)) {                // biquadratic
+        double disc = p * p - 4.0 * r;
+        if (disc < 0.0) { if (disc > -1e-12 * scale * scale) disc = 0.0; else return 0; }
+        const double sq = std::sqrt(disc);
+        for (const double w : {0.5 * (-p + sq), 0.5 * (-p - sq)}) {
+            if (w < 0.0) continue;
+            const double s = std::sqrt(w);
+            y[n++] = s; y[n++] = -s;
+        }
+    } else {
+        double z = cubic_largest_root(2.0 * p, p * p - 4.0 * r, -q * q);      // > 0 since q != 0
+        if (!(z > 0.0)) return 0;
+        const double s = std::sqrt(z), t1 = 0.5 * (p + z - q / s), t2 = 0.5 * (p + z + q / s);
+        const double tol = 1e-10 * (z + std::fabs(t1) + std::fabs(t2));
+        double d1 = z - 4.0 * t1, d2 = z - 4.0 * t2;
+        if (d1 > -tol) { d1 = std::sqrt(d1 > 0.0 ? d1 : 0.0); y[n++] = 0.5 * (-s + d1); y[n++] = 0.5 * (-s - d1); }
+        if (d2 > -tol) { d2 = std::sqrt(d2 > 0.0 ? d2 : 0.0); y[n++] = 0.5 * (s + d2); y[n++] = 0.5 * (s - d2); }
+    }
+    for (int i = 0; i < n; ++i) {
+        double x = y[i] - 0.25 * a;
+        for (int it = 0; it < 3; ++it) {
+            const double f = (((c[4] * x + c[3]) * x + c[2]) * x + c[1]) * x + c[0];
+            const double df = ((4.0 * c[4] * x + 3.0 * c[3]) * x + 2.0 * c[2]) * x + c[1];
+            if (std::fabs(df) < 1e-300) break;
+            x -= f / df;
+        }
+        roots[i] = x;
+    }
+    return n;
+}
+
+// right-handed orthonormal frame of a triangle: e1 along Q0 -> Q1, e3 its normal; false when the points are collinear
+bool triangle_frame(const double* Q0, const double* Q1, const double* Q2, double* E) {
+    double e1[3] = {Q1[0] - Q0[0], Q1[1] - Q0[1], Q1[2] - Q0[2]}, w[3] = {Q2[0] - Q0[0], Q2[1] - Q0[1], Q2[2] - Q0[2]};
+    const double n1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+    if (!(n1 > 1e-300)) return false;
+    for (double& v : e1) v /= n1;
+    double e3[3] = {e1[1] * w[2] - e1[2] * w[1], e1[2] * w[0] - e1[0] * w[2], e1[0] * w[1] - e1[1] * w[0]};
+    const double n3 = std::sqrt(e3[0] * e3[0] + e3[1] * e3[1] + e3[2] * e3[2]);
+    const double nw = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    if (!(n3 > 1e-9 * nw) || !(nw > 0.0)) return false;
+    for (double& v : e3) v /= n3;
+    const double e2[3] = {e3[1] * e1[2] - e3[2] * e1[1], e3[2] * e1[0] - e3[0] * e1[2], e3[0] * e1[1] - e3[1] * e1[0]};
+    for (int i = 0; i < 3; ++i) { E[i * 3] = e1[i]; E[i * 3 + 1] = e2[i]; E[i * 3 + 2] = e3[i]; }
+    return true;
+}
+
+// rays: three normalised image points (x, y) -> bearings (x, y, 1) / |.|; X: three world points.  poses[k] = [R | t] row-major.
+int p3p_poses(const double (*ray)[2], const double (*X)[3], double (*poses)[12]) {
+    double f[3][3];
+    for (int i = 0; i < 3; ++i) {
+        const double inv = 1.0 / std::sqrt(ray[i][0] * ray[i][0] + ray[i][1] * ray[i][1] + 1.0);
+        f[i][0] = ray[i][0] * inv; f[i][1] = ray[i][1] * inv; f[i][2] = inv;
+    }
+    auto dot = [](const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+    auto d2 = [](const double* a, const double* b) { return (a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]); };
+    const double ca = dot(f[1], f[2]), cb = dot(f[0], f[2]), cg = dot(f[0], f[1]);
+    const double a2 = d2(X[1], X[2]), b2 = d2(X[0], X[2]), c2 = d2(X[0], X[1]);
+    if (!(a2 > 0.0) || !(b2 > 0.0) || !(c2 > 0.0)) return 0;
+    double EP[9];
+    if (!triangle_frame(X[0], X[1], X[2], EP)) return 0;
+    const double p = (a2 - c2) / b2, k = c2 / b2;
+    // polynomials in v, lowest coefficient first
+    const double N[3] = {p + 1.0, -2.0 * p * cb, p - 1.0}, D[2] = {2.0 * cg, -2.0 * ca}, E[3] = {1.0, -2.0 * cb, 1.0};
+    const double D2[3] = {D[0] * D[0], 2.0 * D[0] * D[1], D[1] * D[1]};
+    double c[5] = {D2[0], D2[1], D2[2], 0.0, 0.0};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c[i + j] += N[i] * N[j] - k * E[i] * D2[j];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 2; ++j) c[i + j] -= 2.0 * cg * N[i] * D[j];
+    double vs[4];
+    const int nr = quartic_real_roots(c, vs);
+    int n = 0;
+    for (int ri = 0; ri < nr; ++ri) {
+        const double v = vs[ri];
+        if (!(v > 0.0) || !std::isfinite(v)) continue;
+        bool dup = false;
+        for (int rj = 0; rj < ri; ++rj) dup |= std::fabs(vs[rj] - v) < 1e-9 * (1.0 + std::fabs(v));      // a double root counted once
+        if (dup) continue;
+        const double den = D[0] + D[1] * v;
+        if (std::fabs(den) < 1e-12) continue;
+        const double u = (N[0] + (N[1] + N[2] * v) * v) / den;
+        if (!(u > 0.0)) continue;
+        const double q = 1.0 + u * u - 2.0 * u * cg;
+        if (!(q > 1e-300)) continue;
+        const double s1 = std::sqrt(c2 / q), sd[3] = {s1, u * s1, v * s1};
+        double Cc[3][3];
+        for (int i = 0; i < 3; ++i)
+            for (int d = 0; d < 3; ++d) Cc[i][d] = sd[i] * f[i][d];
+        double EC[9];
+        if (!triangle_frame(Cc[0], Cc[1], Cc[2], EC)) continue;
+        double* ps = poses[n];
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) ps[i * 4 + j] = EC[i * 3] * EP[j * 3] + EC[i * 3 + 1] * EP[j * 3 + 1] + EC[i * 3 + 2] * EP[j * 3 + 2];
+            ps[i * 4 + 3] = Cc[0][i] - (ps[i * 4] * X[0][0] + ps[i * 4 + 1] * X[0][1] + ps[i * 4 + 2] * X[0][2]);
+        }
+        bool fin = true;
+        for (int e = 0; e < 12; ++e) fin = fin && std::isfinite(ps[e]);
+        if (fin) ++n;
+    }
+    return n;
+}
+
 void rodrigues(const double* w, double* R) {
     const double th = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
     const double a = th < 1e-12 ? 1.0 - th * th / 6.0 : std::sin(th) / th;
@@ -619,10 +769,14 @@ struct Ransac {
     double K[9];
     double thr2 = 0, confidence = 0.99;
     int n = 0, min_iters = 0, max_iters = 0;
+    int solver = 0;                  // 0: 6-point DLT (OpenCV branch), 1: P3P (pycolmap branch)
     unsigned long long seed = 1;
 
+    int sample_size() const { return solver == 1 ? 3 : 6; }
+
     void setup(const double* K_, const float* pts2d, const float* pts3d, int n_, double reproj, double conf, int min_it, int max_it,
-               unsigned long long seed_) {
+               unsigned long long seed_, int solver_) {
+        solver = solver_;
         n = n_; std::memcpy(K, K_, sizeof(K));
         P.n = n; P.K = K;
         P.ray.resize(2 * (size_t)n); P.px.resize(2 * (size_t)n); P.X.resize(3 * (size_t)n);
@@ -644,7 +798,7 @@ struct Ransac {
     int full_chunks() const { return (min_iters < max_iters ? min_iters : max_iters) / CH; }
 
     int needed_for(int cnt) const {
-        const double w = (double)cnt / n, pw = std::pow(w, 6.0);
+        const double w = (double)cnt / n, pw = std::pow(w, (double)sample_size());
         if (pw > 1.0 - 1e-12) return 1;
         if (pw > 1e-12) return (int)std::ceil(std::log(1.0 - confidence) / std::log(1.0 - pw));
         return max_iters;
@@ -662,6 +816,64 @@ struct Ransac {
         int needed = best.cnt > 0 ? needed_for(best.cnt) : max_iters;
         int it = 0;
         auto wanted = [&](int i) { return i < limit && (i < floor_in_chunk || (long long)chunk * CH + i < needed); };
+        // one hypothesis: float score with early rejection against the bound; a new float best is re-scored exactly (double)
+        auto consider = [&](double* pose) {
+            float kp[12];
+            for (int c = 0; c < 4; ++c) {
+                kp[c] = (float)(K[0] * pose[c] + K[1] * pose[4 + c] + K[2] * pose[8 + c]);
+                kp[4 + c] = (float)(K[4] * pose[4 + c] + K[5] * pose[8 + c]);
+                kp[8 + c] = (float)pose[8 + c];
+            }
+            float cost_f;
+            int cnt_f;
+            if (!score_fast(F, kp, (float)thr2, best_cnt_f, best_cost_f, &cnt_f, &cost_f)) return;
+            if (cnt_f < best_cnt_f || (cnt_f == best_cnt_f && !(cost_f < best_cost_f))) return;
+            best_cnt_f = cnt_f; best_cost_f = cost_f;
+            // a new best of this chunk by the float score: its exact (double) count, cost and mask decide what is kept
+            Candidate c;
+            {                                            // exact rotation before the exact score
+                double Rm[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
+                if (polar_rotation(Rm))
+                    for (int rI = 0; rI < 3; ++rI)
+                        for (int cI = 0; cI < 3; ++cI) pose[rI * 4 + cI] = Rm[rI * 3 + cI];
+            }
+            c.cnt = count_inliers(P, pose, thr2, mask.data(), &c.cost);
+            if (c.better_than(best)) {
+                std::memcpy(c.pose, pose, sizeof(double) * 12);
+                c.mask = mask;
+                best = std::move(c);
+                needed = needed_for(best.cnt);
+            }
+        };
+        auto draw = [&](int* idx, int m) {
+            for (int k = 0; k < m;) {
+                const int c = rng.below(n);
+                bool dup = false;
+                for (int j = 0; j < k; ++j) dup |= idx[j] == c;
+                if (!dup) idx[k++] = c;
+            }
+        };
+        auto p3p_of = [&](const int* idx, double (*poses)[12]) {
+            double ray[3][2], X3[3][3];
+            for (int k = 0; k < 3; ++k) {
+                ray[k][0] = P.ray[2 * idx[k]]; ray[k][1] = P.ray[2 * idx[k] + 1];
+                for (int d = 0; d < 3; ++d) X3[k][d] = P.X[3 * idx[k] + d];
+            }
+            return p3p_poses(ray, X3, poses);
+        };
+        if (solver == 1) {
+            // P3P: a trial = one sample of three; every real root of its quartic is a hypothesis scored on all points (COLMAP's P3P
+            // estimator does the same), wrong roots die in the scorer's first block
+            while (wanted(it)) {
+                int idx[3];
+                draw(idx, 3);
+                ++it;
+                double poses[4][12];
+                const int nsol = p3p_of(idx, poses);
+                for (int k = 0; k < nsol; ++k) consider(poses[k]);
+            }
+            return it;
+        }
         while (wanted(it)) {
             // the minimal solver runs on four samples at once (drawn in trial order from this chunk's generator); the four hypotheses
             // are then looked at one by one in that order, exactly as a one-at-a-time loop would (a trial the stopping rule no longer
@@ -670,47 +882,34 @@ struct Ransac {
             int idx4[4][6];
             for (int l = 0; l < 4; ++l) {
                 if (l >= g) { std::memcpy(idx4[l], idx4[0], sizeof(idx4[0])); continue; }
-                int* idx = idx4[l];
-                for (int k = 0; k < 6;) {
-                    const int c = rng.below(n);
-                    bool dup = false;
-                    for (int j = 0; j < k; ++j) dup |= idx[j] == c;
-                    if (!dup) idx[k++] = c;
-                }
+                draw(idx4[l], 6);
             }
             double pose4[4][12];
             const int okmask = dlt_pose4(P, idx4, pose4);
             for (int l = 0; l < g; ++l) {
                 if (!wanted(it)) return it;
                 ++it;
-                if (!((okmask >> l) & 1)) continue;
-                double* pose = pose4[l];
-                float kp[12];
-                for (int c = 0; c < 4; ++c) {
-                    kp[c] = (float)(K[0] * pose[c] + K[1] * pose[4 + c] + K[2] * pose[8 + c]);
-                    kp[4 + c] = (float)(K[4] * pose[4 + c] + K[5] * pose[8 + c]);
-                    kp[8 + c] = (float)pose[8 + c];
+                if ((okmask >> l) & 1) { consider(pose4[l]); continue; }
+                // singular DLT: the six 3D points are (nearly) coplanar -- a box face, a card.  P3P on the first three, the root
+                // chosen by the reprojection error of the other three (normalised coordinates)
+                double poses[4][12];
+                const int nsol = p3p_of(idx4[l], poses);
+                int pick = -1;
+                double pick_err = 1e300;
+                for (int k = 0; k < nsol; ++k) {
+                    double err = 0.0;
+                    for (int j = 3; j < 6; ++j) {
+                        const double* x = &P.X[3 * idx4[l][j]];
+                        const double* ps = poses[k];
+                        const double zc = ps[8] * x[0] + ps[9] * x[1] + ps[10] * x[2] + ps[11];
+                        if (!(zc > 1e-12)) { err = 1e300; break; }
+                        const double du = (ps[0] * x[0] + ps[1] * x[1] + ps[2] * x[2] + ps[3]) / zc - P.ray[2 * idx4[l][j]];
+                        const double dv = (ps[4] * x[0] + ps[5] * x[1] + ps[6] * x[2] + ps[7]) / zc - P.ray[2 * idx4[l][j] + 1];
+                        err += du * du + dv * dv;
+                    }
+                    if (err < pick_err) { pick_err = err; pick = k; }
                 }
-                float cost_f;
-                int cnt_f;
-                if (!score_fast(F, kp, (float)thr2, best_cnt_f, best_cost_f, &cnt_f, &cost_f)) continue;
-                if (cnt_f < best_cnt_f || (cnt_f == best_cnt_f && !(cost_f < best_cost_f))) continue;
-                best_cnt_f = cnt_f; best_cost_f = cost_f;
-                // a new best of this chunk by the float score: its exact (double) count, cost and mask decide what is kept
-                Candidate c;
-                {                                            // exact rotation before the exact score
-                    double Rm[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
-                    if (polar_rotation(Rm))
-                        for (int rI = 0; rI < 3; ++rI)
-                            for (int cI = 0; cI < 3; ++cI) pose[rI * 4 + cI] = Rm[rI * 3 + cI];
-                }
-                c.cnt = count_inliers(P, pose, thr2, mask.data(), &c.cost);
-                if (c.better_than(best)) {
-                    std::memcpy(c.pose, pose, sizeof(double) * 12);
-                    c.mask = mask;
-                    best = std::move(c);
-                    needed = needed_for(best.cnt);
-                }
+                if (pick >= 0) consider(poses[pick]);
             }
         }
         return it;
@@ -752,19 +951,26 @@ const double kIdentPose[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
 
 }  // namespace
 
-extern "C" int oppnp_abi_version(void) { return 1; }
+extern "C" int oppnp_abi_version(void) { return 2; }
+
+// minimal solver alone (tests): rays = three normalised image points, X = three world points -> up to four poses [R | t]
+extern "C" int oppnp_p3p(const double* rays3x2, const double* X3x3, double* poses4x12) {
+    if (!rays3x2 || !X3x3 || !poses4x12) return -1;
+    return p3p_poses(reinterpret_cast<const double(*)[2]>(rays3x2), reinterpret_cast<const double(*)[3]>(X3x3),
+                     reinterpret_cast<double(*)[12]>(poses4x12));
+}
 
 extern "C" int oppnp_ransac(const double* K, const float* pts2d, const float* pts3d, int n, double reproj_err_px, double confidence,
-                            int min_iters, int max_iters, unsigned long long seed, double* pose_out, unsigned char* inlier_mask,
+                            int min_iters, int max_iters, unsigned long long seed, int solver, double* pose_out, unsigned char* inlier_mask,
                             int* n_inliers, int* iters_run) {
-    if (!K || !pose_out || (n > 0 && (!pts2d || !pts3d)) || max_iters < 1 || min_iters < 0) return -1;
+    if (!K || !pose_out || (n > 0 && (!pts2d || !pts3d)) || max_iters < 1 || min_iters < 0 || (solver != 0 && solver != 1)) return -1;
     std::memcpy(pose_out, kIdentPose, sizeof(kIdentPose));
     if (inlier_mask && n > 0) std::memset(inlier_mask, 0, (size_t)n);
     if (n_inliers) *n_inliers = 0;
     if (iters_run) *iters_run = 0;
     if (n < 6) return 1;                                  // too few correspondences: identity pose, no inliers
     Ransac R;
-    R.setup(K, pts2d, pts3d, n, reproj_err_px, confidence, min_iters, max_iters, seed);
+    R.setup(K, pts2d, pts3d, n, reproj_err_px, confidence, min_iters, max_iters, seed, solver);
     Candidate best;
     FloatBound b0;                                        // chunk 0's float best bounds every later chunk
     for (int c = 0; c < R.full_chunks(); ++c) {
@@ -877,9 +1083,9 @@ extern "C" void oppnp_pool_destroy(void* pool) { delete reinterpret_cast<Pool*>(
 
 // copies the inputs and returns a ticket (0, 1, 2, ...) at once
 extern "C" long long oppnp_pool_submit(void* pool_, const double* K, const float* pts2d, const float* pts3d, int n, double reproj_err_px,
-                                       double confidence, int min_iters, int max_iters, unsigned long long seed) {
+                                       double confidence, int min_iters, int max_iters, unsigned long long seed, int solver) {
     Pool* pool = reinterpret_cast<Pool*>(pool_);
-    if (!pool || !K || n < 0 || (n > 0 && (!pts2d || !pts3d)) || max_iters < 1 || min_iters < 0) return -1;
+    if (!pool || !K || n < 0 || (n > 0 && (!pts2d || !pts3d)) || max_iters < 1 || min_iters < 0 || (solver != 0 && solver != 1)) return -1;
     long long ticket;
     if (n < 6) {                                          // no pose: identity, recorded at once
         Result r;
@@ -892,7 +1098,7 @@ extern "C" long long oppnp_pool_submit(void* pool_, const double* K, const float
         return ticket;
     }
     auto job = std::make_shared<Job>();
-    job->R.setup(K, pts2d, pts3d, n, reproj_err_px, confidence, min_iters, max_iters, seed);
+    job->R.setup(K, pts2d, pts3d, n, reproj_err_px, confidence, min_iters, max_iters, seed, solver);
     const int nfull = job->R.full_chunks();
     job->chunk_best.resize((size_t)nfull);
     job->remaining = nfull;

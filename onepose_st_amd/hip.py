@@ -61,9 +61,6 @@ _SIGNATURES = {
     "ophip_encoder_bf16_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "ophip_encoder_bf16_wpack_bytes": (ctypes.c_size_t, []),
     "ophip_encoder_layer_bf16": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_f, ctypes.c_void_p]),
-    "ophip_encoder_x3_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
-    "ophip_encoder_x3_wpack_bytes": (ctypes.c_size_t, []),
-    "ophip_encoder_layer_x3": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_i, c_i, c_i, c_f, ctypes.c_void_p]),
     "ophip_encoder_x3w8_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "ophip_encoder_x3w8_wpack_bytes": (ctypes.c_size_t, []),
     "ophip_encoder_layer_x3w8": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_i, c_i, c_i, c_f, ctypes.c_void_p]),
@@ -81,9 +78,6 @@ _SIGNATURES = {
     "ophip_fine_bf16_wpack_bytes": (ctypes.c_size_t, [c_i]),
     "ophip_fine_refine_bf16": (c_i, [c_f, c_ll, c_ll, c_ll, c_ll, c_i, c_i, c_f, c_ll, c_ll, c_f, c_f, c_f, c_f, c_i,
                                      c_f, c_f, c_i, ctypes.c_uint, c_i, c_i, c_i, c_i, ctypes.c_float, c_f, c_f, c_f, c_f, ctypes.c_void_p]),
-    "ophip_fine_x3_wpack_bytes": (ctypes.c_size_t, [c_i]),
-    "ophip_fine_refine_x3": (c_i, [c_f, c_ll, c_ll, c_ll, c_ll, c_i, c_i, c_f, c_ll, c_ll, c_f, c_f, c_f, c_f, c_i,
-                                   c_f, c_f, c_i, ctypes.c_uint, c_i, c_i, c_i, ctypes.c_float, c_f, c_f, c_f, c_f, ctypes.c_void_p]),
     "ophip_conv_wpack_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "ophip_stem_conv7": (c_i, [c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_i, ctypes.c_void_p]),
     "ophip_conv2d_bf16": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_i, c_i, c_f,

@@ -21,6 +21,27 @@ import time
 RANK_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")
 
 
+def visible_gpu_count(environ=None, kfd_root="/sys/class/kfd/kfd/topology/nodes"):
+    """GPUs this process could use, WITHOUT bringing up the HIP runtime (``torch.cuda.device_count()`` falls back to
+    ``hipGetDeviceCount`` when its amdsmi path fails, and a parent that has initialised HIP must not fan out children on
+    this pool): the ``HIP_VISIBLE_DEVICES`` / ``ROCR_VISIBLE_DEVICES`` list when one is set, else the KFD topology nodes that
+    have SIMDs.  ``None`` when neither source is readable (the caller then lets a rank fail with its own message)."""
+    env = os.environ if environ is None else environ
+    for key in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if env.get(key, "").strip():
+            return len([t for t in env[key].split(",") if t.strip() != ""])
+    try:
+        n = 0
+        for node in os.listdir(kfd_root):
+            props = open(os.path.join(kfd_root, node, "properties")).read().split()
+            kv = dict(zip(props[0::2], props[1::2]))
+            if int(kv.get("simd_count", "0")) > 0:
+                n += 1
+        return n
+    except (OSError, ValueError):
+        return None
+
+
 def free_port() -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

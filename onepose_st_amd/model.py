@@ -28,7 +28,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import hip, host_math, packing
+from . import hip, host_math, ops, packing
 from .backbone import build_backbone
 from .backbone_hip import HipBackbone, pack_backbone
 from .config import encoder_layer_names, validate_config
@@ -116,9 +116,6 @@ class OnePosePlus_model(nn.Module):
             raise ValueError(f"hip_precision {self.precision!r}: expected 'f32', 'bf16x3' or 'bf16'")
         # backbone on the HIP convolution kernels (bf16 pipe modes only; exact-f32 mode keeps MIOpen's fp32 convolutions)
         self.hip_backbone = bool(config.get("hip_backbone", True)) and self.precision != "f32"
-        # the x3 encoder layer with eight waves per workgroup (two per SIMD, csrc/encoder_x3w8.hip: 52 against 56 us per launch at
-        # c2); OPHIP_ENC_W8=0 selects the four-wave form (csrc/encoder_x3.hip)
-        self._enc_w8 = os.environ.get("OPHIP_ENC_W8", "1") != "0"
         self._packed = None          # (key, dict of device weight blocks)
         self._packed_bb = None       # (key, backbone conv blocks)
         # fine stage (+ result read-back) on a second HIP stream: frame t's refinement then overlaps frame t + 1's input
@@ -165,14 +162,13 @@ class OnePosePlus_model(nn.Module):
         }
         if self.kpt_3d_pos_encoding is not None:
             blocks["kpt"] = packing.pack_keypoint_encoder(sd).to(device)
-        if self.precision != "f32":
+        if self.precision == "bf16":
             blocks["coarse_bf16"] = [packing.pack_coarse_layer_bf16(sd, f"loftr_coarse.layers.{i}.").to(device)
                                      for i in range(len(self.loftr_coarse.layer_names))]
-            if self.precision == "bf16x3":
-                packer = packing.pack_coarse_layer_x3w8 if self._enc_w8 else packing.pack_coarse_layer_x3
-                blocks["coarse_x3"] = [packer(sd, f"loftr_coarse.layers.{i}.").to(device) for i in range(len(self.loftr_coarse.layer_names))]
-            if self.precision == "bf16x3" and os.environ.get("OPHIP_FINE_X3"):
-                blocks["fine_x3"] = packing.pack_fine_layers_x3(sd, "loftr_fine.layers.", len(self.loftr_fine.layer_names)).to(device)
+        if self.precision == "bf16x3":
+            blocks["coarse_x3"] = [packing.pack_coarse_layer_x3w8(sd, f"loftr_coarse.layers.{i}.").to(device)
+                                   for i in range(len(self.loftr_coarse.layer_names))]
+        if self.precision != "f32":
             blocks["fine_bf16"] = packing.pack_fine_layers_bf16(sd, "loftr_fine.layers.", len(self.loftr_fine.layer_names)).to(device)
         self._packed = (key, blocks)
         return blocks
@@ -281,9 +277,8 @@ class OnePosePlus_model(nn.Module):
 
         main = torch.cuda.current_stream(dev)
         fkey = (str(dev), main.cuda_stream)
-        if (self.frame_call and self.precision == "bf16x3" and self._enc_w8 and self.overlap_fine and not _pe_applied and not want_fine_debug
+        if (self.frame_call and self.precision == "bf16x3" and self.overlap_fine and not _pe_applied and not want_fine_debug
                 and not self.debug and isinstance(self.profiler, _NullProfiler) and bool(cfg["fine_matching"]["enable"])
-                and not os.environ.get("OPHIP_ENC_V1") and not os.environ.get("OPHIP_FINE_X3")
                 and (self.kpt_3d_pos_encoding is not None or B == 1 or desc_in_d.shape[0] == B)
                 and len(self.loftr_coarse.layer_names) <= 16):
             x3d_ext = None
@@ -361,6 +356,9 @@ class OnePosePlus_model(nn.Module):
                 prep_done.record()
         if sprep is not None:
             main.wait_event(prep_done)
+            for t in (x2d, x3d, ff):                     # allocated from s_prep's pool, used on the compute / fine streams from here on
+                if t is not None:
+                    t.record_stream(main)
         # ---- a4-a6: coarse encoder ----------------------------------------------------------------
         y3d, y2d = torch.empty_like(x3d), torch.empty_like(x2d)
         z3d = torch.empty_like(x3d) if self.cache_object else x3d          # a cached encoding is read-only: ping-pong between y and z
@@ -375,10 +373,10 @@ class OnePosePlus_model(nn.Module):
                 lib_call("ophip_encoder_layer", P(x3d), P(x2d), P(y3d), P(y2d), B, N, M, P(W["coarse"][li]),
                          1 if name == "cross" else 0, P(ws), S)
                 x3d, y3d, x2d, y2d = y3d, (z3d if li == 0 else x3d), y2d, x2d
-        elif self.precision == "bf16x3" and not os.environ.get("OPHIP_ENC_V1"):
-            # 16-token tiles, one workgroup per CU, per-wave weight streams (csrc/encoder_x3.hip)
-            entry = "ophip_encoder_layer_x3w8" if self._enc_w8 else "ophip_encoder_layer_x3"
-            ws = torch.empty(getattr(hip.load(), entry.replace("layer_", "") + "_workspace_bytes")(B, N, M), device=dev, dtype=torch.uint8)
+        elif self.precision == "bf16x3":
+            # 16-token tiles, one eight-wave workgroup per CU, per-wave weight streams (csrc/encoder_x3w8.hip)
+            entry = "ophip_encoder_layer_x3w8"
+            ws = torch.empty(hip.load().ophip_encoder_x3w8_workspace_bytes(B, N, M), device=dev, dtype=torch.uint8)
             names_c = self.loftr_coarse.layer_names
             for li, name in enumerate(names_c):
                 nxt = W["coarse_x3"][li + 1] if li + 1 < len(names_c) else None
@@ -388,7 +386,7 @@ class OnePosePlus_model(nn.Module):
                          1 if name == "cross" else 0, 1 if li > 0 else 0, li & 1, P(ws, None), S)
                 x3d, y3d, x2d, y2d = y3d, (z3d if li == 0 else x3d), y2d, x2d
         else:
-            nsplit = 3 if self.precision == "bf16x3" else 1
+            nsplit = 1                                            # plain-bf16 mode
             ws = torch.empty(hip.load().ophip_encoder_bf16_workspace_bytes(B, N, M), device=dev, dtype=torch.uint8)
             names_c = self.loftr_coarse.layer_names
             for li, name in enumerate(names_c):
@@ -463,15 +461,6 @@ class OnePosePlus_model(nn.Module):
                              P(b_ids, torch.int64), P(i_ids, torch.int64), P(j_ids, torch.int64), P(count, torch.int32), max_matches,
                              P(mkc), P(W["fine"]), len(names_f), ctypes.c_uint(cross_bits), 1 if cf["enable"] else 0,
                              wc, stride, float(fine_scale), P(expec), P(mkf), P(dbg_w), P(dbg_3), S)
-                elif self.precision == "bf16x3" and ff_strides[1] == 1 and os.environ.get("OPHIP_FINE_X3"):
-                    # three matches per workgroup, weights streamed once per three (csrc/fine_x3.hip).  Opt-in: stand-alone it is 6 %
-                    # faster than the one-match kernel (267 vs 283 us at K = 2975), but a 150 KiB-LDS workgroup per CU leaves no room
-                    # for the next frame's input kernels that run beside the fine stage: 1067 vs 1119 frames/s end to end
-                    lib_call("ophip_fine_refine_x3", P(ff), *ff_strides, hf, wf,
-                             P(desc_fine_d), bstride(desc_fine_d), desc_fine_d.stride(1),
-                             P(b_ids, torch.int64), P(i_ids, torch.int64), P(j_ids, torch.int64), P(count, torch.int32), max_matches,
-                             P(mkc), P(W["fine_x3"], None), len(names_f), ctypes.c_uint(cross_bits), 1 if cf["enable"] else 0,
-                             wc, stride, float(fine_scale), P(expec), P(mkf), P(dbg_w), P(dbg_3), S)
                 else:
                     lib_call("ophip_fine_refine_bf16", P(ff), *ff_strides, hf, wf,
                              P(desc_fine_d), bstride(desc_fine_d), desc_fine_d.stride(1),
@@ -534,12 +523,10 @@ class OnePosePlus_model(nn.Module):
             L = hip.FrameLayout()
             hip.call("ophip_frame_layout", ctypes.byref(d), 1 if transpose_fine else 0, 1 if x3d_ext is not None else 0, ctypes.byref(L))
             if len(self._frame_plans) >= 8:
-                self._frame_plans.pop(next(iter(self._frame_plans)))
-            plan = self._frame_plans[pkey] = (d, L, W, pe)                 # W and the table stay alive with the pointers
-        d, L = plan[0], plan[1]
+                ops.drop_frame_plan(self._frame_plans.pop(next(iter(self._frame_plans)))[2])
+            plan = self._frame_plans[pkey] = (d, L, ops.register_frame_plan(d, L, keep_alive=(W, pe)))      # W and the table stay alive with the pointers
+        d, L, plan_id = plan
 
-        def bstride(t):
-            return 0 if t.shape[0] == 1 or t.stride(0) == 0 else t.stride(0)
         prev = self._fine_streams.get(fkey)
         if prev is not None and prev[1] is not None:                      # a stage-by-stage frame before this one: order behind its fine stage
             main.wait_event(prev[1])
@@ -552,21 +539,30 @@ class OnePosePlus_model(nn.Module):
         sprep = self._side_stream(self._prep_streams, fkey, dev) if inputs_ready else None
         scopy = self._side_stream(PendingFrame._copy_streams, (dev, main.cuda_stream), dev)
         cap = B * N
-        blob = torch.empty(L.total, dtype=torch.uint8, device=dev)
+        if sprep is not None:
+            # the input kernels write into the block on s_prep AHEAD of everything queued on the compute stream, so the block must come
+            # from s_prep's pool (the caching allocator orders reuse on the allocating stream only: a block freed on the compute stream
+            # with work still pending there could otherwise be overwritten early); the other streams that touch it are recorded, so
+            # that it goes back to the pool only after their work is done
+            with torch.cuda.stream(sprep):
+                blob = torch.empty(L.total, dtype=torch.uint8, device=dev)
+            for st in (main, sfine, scopy):
+                blob.record_stream(st)
+        else:
+            blob = torch.empty(L.total, dtype=torch.uint8, device=dev)
+            for st in (sfine, scopy):
+                blob.record_stream(st)
         nbytes = int(L.result_bytes) if host_copy else 16
         pin = PendingFrame._take_pin((cap, bool(host_copy)), nbytes)
         if transpose_fine:
             fs = (0, 0, 0, 0)                                             # filled in by the callee for its channels-last copy
         else:
             fs = (ff.stride(0), 1, ff.stride(2), ff.stride(3))
-        slot = ctypes.c_int(-1)
-        P = hip.ptr
         try:
-            hip.call("ophip_frame_enqueue", ctypes.byref(d), ctypes.byref(L), ctypes.c_void_p(blob.data_ptr()),
-                     P(fc), P(ff), fs[0], fs[1], fs[2], fs[3], P(kpts_d), bstride(kpts_d), P(desc_in_d), bstride(desc_in_d),
-                     P(desc_fine_d), bstride(desc_fine_d), desc_fine_d.stride(1), P(x3d_ext), ctypes.c_void_p(pin.data_ptr()), nbytes,
-                     ctypes.c_void_p(main.cuda_stream), ctypes.c_void_p(sprep.cuda_stream) if sprep is not None else None,
-                     ctypes.c_void_p(sfine.cuda_stream), ctypes.c_void_p(scopy.cuda_stream), ctypes.byref(slot))
+            # the whole frame through ONE custom op (torch.ops.onepose_hip.frame_enqueue -> ophip_frame_enqueue)
+            slot = torch.ops.onepose_hip.frame_enqueue(plan_id, blob, fc, ff, list(fs), kpts_d, desc_in_d, desc_fine_d, x3d_ext, pin, nbytes,
+                                                       main.cuda_stream, sprep.cuda_stream if sprep is not None else 0,
+                                                       sfine.cuda_stream, scopy.cuda_stream)
         except Exception:
             # part of the frame may be queued on the side streams already: nothing may touch the block or the pinned buffer again
             # before those streams are idle
@@ -576,7 +572,7 @@ class OnePosePlus_model(nn.Module):
         self._frame_call_pending.add(fkey)
         data["conf_matrix"] = blob[L.conf:L.conf + 4 * B * N * M].view(torch.float32).view(B, N, M)
         keep = [fc, ff, kpts_d, desc_in_d, desc_fine_d, x3d_ext, W]
-        return PendingFrame._from_block(self, data, dev, B, N, M, cap, blob, L, slot.value, pin, host_copy, keep)
+        return PendingFrame._from_block(self, data, dev, B, N, M, cap, blob, L, slot, pin, host_copy, keep)
 
 def _result_views(blob, cap):
     """(blob, count int32[1], b_ids int64[cap], mkpts3d f32[cap,3], mkpts2d f32[cap,2]) views of one byte block."""

@@ -112,50 +112,13 @@ def pack_coarse_layer_bf16(sd: dict, prefix: str) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------------------------
-# split-bf16 coarse layer as per-wave STREAMS (csrc/encoder_x3.hip): v_mfma_f32_16x16x32_bf16 fragments
+# split-bf16 coarse layer as per-wave STREAMS (csrc/encoder_x3w8.hip): v_mfma_f32_16x16x32_bf16 fragments
 #   frag(W, row0, k0)[lane = 16 q + c16][j] = W[row0 + c16][k0 + 8 q + j]      (1 KiB per plane)
 # in exactly the order wave fw consumes them, hi then lo per fragment.
 # ----------------------------------------------------------------------------------------------
-X3_MAIN_FRAGS, X3_KV_FRAGS = 512, 128         # per wave, hi and lo counted separately
-
-
-def x3_program(fw: int):
-    """-> (main, kv): lists of (matrix, row0, k0) in consumption order for wave ``fw`` (each entry = one hi + one lo fragment).
-    main: Q | merge | W0c0 | W0c1 | W2c0 | W0c2 | W2c1 | W0c3 | W2c2 | W2c3 (MLP chunk c = hidden features 128c..128c+127,
-    the chunk's first GEMM pipelined one chunk ahead of its second); kv: K|V projection of heads 2fw, 2fw+1."""
-    def gemm(mat, rows, k0, ksteps):
-        return [(mat, r0, k0 + 32 * ks) for ks in range(ksteps) for r0 in rows]
-    rows64 = [64 * fw + 16 * ft for ft in range(4)]
-    main = gemm("q", rows64, 0, 8) + gemm("m", rows64, 0, 8)
-    w0 = [gemm("w0", [128 * c + 32 * fw + 16 * ft for ft in range(2)], 0, 16) for c in range(4)]
-    w2 = [gemm("w2", rows64, 128 * c, 4) for c in range(4)]
-    main += w0[0] + w0[1] + w2[0] + w0[2] + w2[1] + w0[3] + w2[2] + w2[3]
-    kv = [(("k" if ft < 4 else "v"), 64 * fw + 16 * (ft & 3), 32 * ks) for ks in range(8) for ft in range(8)]
-    assert 2 * len(main) == X3_MAIN_FRAGS and 2 * len(kv) == X3_KV_FRAGS
-    return main, kv
-
-
 def x3_frag(w: torch.Tensor, row0: int, k0: int) -> torch.Tensor:
     """``[64 lanes][8]`` A/B-operand fragment of ``W[row0:row0+16, k0:k0+32]``."""
     return w[row0:row0 + 16, k0:k0 + 32].reshape(16, 4, 8).permute(1, 0, 2).reshape(64, 8)
-
-
-def pack_coarse_layer_x3(sd: dict, prefix: str) -> torch.Tensor:
-    """uint8 block ``[main streams: 4 waves x 512 KiB][K|V streams: 4 x 128 KiB][norm1.w norm1.b norm2.w norm2.b f32]`` for
-    ``ophip_encoder_layer_x3``."""
-    mats = {"q": sd[prefix + "q_proj.weight"], "k": sd[prefix + "k_proj.weight"], "v": sd[prefix + "v_proj.weight"],
-            "m": sd[prefix + "merge.weight"], "w0": sd[prefix + "mlp.0.weight"], "w2": sd[prefix + "mlp.2.weight"]}
-    mats = {k: v.detach().to(torch.float32).cpu().contiguous() for k, v in mats.items()}
-    if tuple(mats["q"].shape) != (256, 256) or tuple(mats["w0"].shape) != (512, 512) or tuple(mats["w2"].shape) != (256, 512):
-        raise ValueError("coarse encoder kernels are specialised for d_model = 256")
-    progs = [x3_program(fw) for fw in range(4)]
-    frags = [x3_frag(mats[m], r0, k0) for sel in (0, 1) for fw in range(4) for (m, r0, k0) in progs[fw][sel]]
-    flat = torch.stack(frags)                                     # [n][64][8] f32
-    hi = flat.to(torch.bfloat16)
-    lo = (flat - hi.float()).to(torch.bfloat16)
-    out = _bytes(torch.stack([hi, lo], 1), torch.cat(_ln(sd, prefix)))
-    assert out.numel() == 4 * (X3_MAIN_FRAGS + X3_KV_FRAGS) * 1024 + 16 * 256
-    return out
 
 
 def pack_fine_layers_bf16(sd: dict, prefix: str, n_layers: int) -> torch.Tensor:
@@ -205,50 +168,6 @@ def pack_coarse_layer_x3w8(sd: dict, prefix: str) -> torch.Tensor:
     lo = (flat - hi.float()).to(torch.bfloat16)
     out = _bytes(torch.stack([hi, lo], 1), torch.cat(_ln(sd, prefix)))
     assert out.numel() == 8 * (256 + 64) * 1024 + 16 * 256
-    return out
-
-
-X3_FINE_LAYER_FRAGS = 160        # per wave and layer, hi and lo counted separately
-
-
-def x3_fine_program(fw: int):
-    """(matrix, row0, k0) entries of ONE fine layer (d_model 128) in the order wave ``fw`` of csrc/fine_x3.hip consumes them:
-    K|V of heads 2fw, 2fw+1 | Q | merge | W0 chunk 0 | W2 chunk 0 | W0 chunk 1 | W2 chunk 1 (hidden chunk c = features 128c..)."""
-    rows = [32 * fw + 16 * ft for ft in range(2)]
-    prog = [(("k" if ft < 2 else "v"), 32 * fw + 16 * (ft & 1), 32 * ks) for ks in range(4) for ft in range(4)]
-    prog += [("q", r0, 32 * ks) for ks in range(4) for r0 in rows]
-    prog += [("m", r0, 32 * ks) for ks in range(4) for r0 in rows]
-    for c in range(2):
-        prog += [("w0", 128 * c + r0, 32 * ks) for ks in range(8) for r0 in rows]
-        prog += [("w2", r0, 128 * c + 32 * ks) for ks in range(4) for r0 in rows]
-    assert 2 * len(prog) == X3_FINE_LAYER_FRAGS
-    return prog
-
-
-def pack_fine_layers_x3(sd: dict, prefix: str, n_layers: int) -> torch.Tensor:
-    """uint8 block ``[streams: 4 waves x (n_layers x 160 KiB)][ln: n_layers x (norm1.w norm1.b norm2.w norm2.b) f32]`` for
-    ``ophip_fine_refine_x3`` (``prefix`` like ``"loftr_fine.layers."``); a wave's stream runs through all layers."""
-    frags = []
-    lns = []
-    per_layer = []
-    for i in range(n_layers):
-        p = f"{prefix}{i}."
-        mats = {"q": sd[p + "q_proj.weight"], "k": sd[p + "k_proj.weight"], "v": sd[p + "v_proj.weight"],
-                "m": sd[p + "merge.weight"], "w0": sd[p + "mlp.0.weight"], "w2": sd[p + "mlp.2.weight"]}
-        mats = {k: v.detach().to(torch.float32).cpu().contiguous() for k, v in mats.items()}
-        if tuple(mats["q"].shape) != (128, 128) or tuple(mats["w0"].shape) != (256, 256) or tuple(mats["w2"].shape) != (128, 256):
-            raise ValueError("fine encoder kernel is specialised for d_model = 128")
-        per_layer.append(mats)
-        lns.append(torch.cat(_ln(sd, p)))
-    for fw in range(4):
-        prog = x3_fine_program(fw)
-        for mats in per_layer:
-            frags += [x3_frag(mats[m], r0, k0) for (m, r0, k0) in prog]
-    flat = torch.stack(frags)
-    hi = flat.to(torch.bfloat16)
-    lo = (flat - hi.float()).to(torch.bfloat16)
-    out = _bytes(torch.stack([hi, lo], 1), torch.cat(lns))
-    assert out.numel() == n_layers * (4 * X3_FINE_LAYER_FRAGS * 1024 + 16 * 128)
     return out
 
 

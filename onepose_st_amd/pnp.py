@@ -33,19 +33,21 @@ def load():
         lib = ctypes.CDLL(path)
         lib.oppnp_ransac.restype = ctypes.c_int
         lib.oppnp_ransac.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_double,
-                                     ctypes.c_int, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_int, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+        lib.oppnp_p3p.restype = ctypes.c_int
+        lib.oppnp_p3p.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         lib.oppnp_pool_create.restype = ctypes.c_void_p
         lib.oppnp_pool_create.argtypes = [ctypes.c_int]
         lib.oppnp_pool_destroy.argtypes = [ctypes.c_void_p]
         lib.oppnp_pool_submit.restype = ctypes.c_longlong
         lib.oppnp_pool_submit.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double,
-                                          ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_ulonglong]
+                                          ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_int]
         lib.oppnp_pool_wait_all.restype = ctypes.c_longlong
         lib.oppnp_pool_wait_all.argtypes = [ctypes.c_void_p]
         lib.oppnp_pool_result.restype = ctypes.c_int
         lib.oppnp_pool_result.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
-        if lib.oppnp_abi_version() != 1:
+        if lib.oppnp_abi_version() != 2:
             raise RuntimeError("libonepose_pnp.so ABI version mismatch")
         _lib = lib
     return _lib
@@ -58,19 +60,41 @@ POLICY = {
 }
 
 
+SOLVER = {"dlt6": 0, "p3p": 1}
+
+
+def minimal_solver(use_pycolmap_ransac: bool, solver=None) -> int:
+    """pycolmap's ``absolute_pose_estimation`` samples three correspondences (P3P) and scores every root; the OpenCV branch keeps
+    the build's 6-point DLT (with a P3P fallback on coplanar samples).  ``solver``: "p3p" / "dlt6" overrides."""
+    if solver is None:
+        return SOLVER["p3p" if use_pycolmap_ransac else "dlt6"]
+    return SOLVER[solver]
+
+
+def p3p(rays, X):
+    """The minimal solver alone: ``rays [3, 2]`` normalised image points, ``X [3, 3]`` world points -> list of ``[3, 4]`` poses."""
+    lib = load()
+    r = np.ascontiguousarray(rays, dtype=np.float64).reshape(3, 2)
+    x = np.ascontiguousarray(X, dtype=np.float64).reshape(3, 3)
+    out = np.zeros((4, 12), dtype=np.float64)
+    n = lib.oppnp_p3p(r.ctypes.data, x.ctypes.data, out.ctypes.data)
+    return [out[i].reshape(3, 4).copy() for i in range(max(n, 0))]
+
+
 def trial_policy(use_pycolmap_ransac: bool, min_iters=None, max_iters=None) -> tuple:
     pol = POLICY["reference" if use_pycolmap_ransac else "adaptive"]
     return (pol["min_iters"] if min_iters is None else int(min_iters), pol["max_iters"] if max_iters is None else int(max_iters))
 
 
 def ransac_PnP(K, pts_2d, pts_3d, scale=1, pnp_reprojection_error=5, img_hw=None, use_pycolmap_ransac=False,
-               confidence=0.99, min_iters=None, max_iters=None, seed=1):
+               confidence=0.99, min_iters=None, max_iters=None, seed=1, solver=None):
     """-> ``(pose [3,4], pose_homo [4,4], inliers [k] int64)`` like the reference.  ``scale`` multiplies the 3D points
     for the solve and divides the translation afterwards (the reference's OpenCV branch, ``metric_utils.py:186,200``).
     ``use_pycolmap_ransac`` selects the trial policy of the reference's branch: ``True`` (what ``inference.py:181-189``
     passes) runs at least 10 000 trials like ``pycolmap.absolute_pose_estimation(min_num_trials=10000, max_num_trials=1e6)``,
     ``False`` stops adaptively at the confidence within 10 000 trials like ``cv2.solvePnPRansac``; ``min_iters`` /
-    ``max_iters`` override either.  The estimator itself is the build's own (pose parity vs pycolmap / OpenCV is unpinned);
+    ``max_iters`` override either.  The minimal solver follows the branch too (:func:`minimal_solver`: P3P / 6-point DLT).
+    The estimator itself is the build's own (pose parity vs pycolmap / OpenCV is unpinned);
     ``img_hw`` is accepted for signature compatibility."""
     lib = load()
     min_iters, max_iters = trial_policy(bool(use_pycolmap_ransac), min_iters, max_iters)
@@ -84,7 +108,7 @@ def ransac_PnP(K, pts_2d, pts_3d, scale=1, pnp_reprojection_error=5, img_hw=None
     mask = np.zeros(max(n, 1), dtype=np.uint8)
     n_in, iters = ctypes.c_int(0), ctypes.c_int(0)
     rc = lib.oppnp_ransac(K.ctypes.data, p2.ctypes.data, p3.ctypes.data, n, float(pnp_reprojection_error), float(confidence),
-                          int(min_iters), int(max_iters), int(seed), pose.ctypes.data, mask.ctypes.data,
+                          int(min_iters), int(max_iters), int(seed), minimal_solver(bool(use_pycolmap_ransac), solver), pose.ctypes.data, mask.ctypes.data,
                           ctypes.byref(n_in), ctypes.byref(iters))
     if rc < 0:
         raise ValueError("oppnp_ransac: invalid arguments")
@@ -97,13 +121,15 @@ def ransac_PnP(K, pts_2d, pts_3d, scale=1, pnp_reprojection_error=5, img_hw=None
 class PnPPool:
     """Library-owned worker threads: ``submit`` copies the matches and returns a ticket immediately."""
 
-    def __init__(self, K, threads=3, pnp_reprojection_error=7, confidence=0.99, min_iters=None, max_iters=None, seed=1, policy="reference"):
+    def __init__(self, K, threads=3, pnp_reprojection_error=7, confidence=0.99, min_iters=None, max_iters=None, seed=1, policy="reference",
+                 solver=None):
         """``policy``: "reference" = the pycolmap branch's trial floor (what the reference's inference loop runs), "adaptive" = the
         OpenCV branch; a frame's unconditional trials are split over all pool threads (same pose for any thread count)."""
         self._lib = load()
         min_iters, max_iters = trial_policy(policy == "reference", min_iters, max_iters)
         self._K = np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(3, 3))
-        self._args = (float(pnp_reprojection_error), float(confidence), int(min_iters), int(max_iters), int(seed))
+        self._args = (float(pnp_reprojection_error), float(confidence), int(min_iters), int(max_iters), int(seed),
+                      minimal_solver(policy == "reference", solver))
         self._pool = ctypes.c_void_p(self._lib.oppnp_pool_create(int(threads)))
 
     def submit(self, pts_2d, pts_3d) -> int:

@@ -115,12 +115,12 @@ def test_encoder_layer(sd, dev, cross, B, L3, L2):
                  hip.ptr(ws), hip.stream_handle())
 
 
-@pytest.mark.parametrize("nsplit,rtol,atol", [(3, 3e-4, 1e-4), (1, 5e-2, 5e-2)])
+@pytest.mark.parametrize("nsplit,rtol,atol", [(1, 5e-2, 5e-2)])
 @pytest.mark.parametrize("cross", [0, 1])
 @pytest.mark.parametrize("B,L3,L2", [(1, 64, 32), (2, 70, 45), (1, 1000, 1200)])
 def test_encoder_layer_bf16(sd, dev, nsplit, rtol, atol, cross, B, L3, L2):
-    """bf16 matrix pipe: split-bf16 (nsplit 3) must track the f32 oracle to ~1e-4; plain bf16 (nsplit 1) is only
-    sanity-checked here (8-bit mantissas: ~1e-2 relative)."""
+    """plain-bf16 mode's layer (csrc/encoder_bf16.hip): sanity-checked against the f32 oracle (8-bit mantissas: ~1e-2
+    relative); the split-bf16 layer is ophip_encoder_layer_x3w8 (next test) and nsplit = 3 is refused here."""
     g = torch.Generator().manual_seed(2)
     x3, x2 = torch.randn(B, L3, 256, generator=g), torch.randn(B, L2, 256, generator=g)
     p = "loftr_coarse.layers.2."
@@ -140,17 +140,19 @@ def test_encoder_layer_bf16(sd, dev, nsplit, rtol, atol, cross, B, L3, L2):
     print(f"nsplit={nsplit} cross={cross} B={B} L=({L3},{L2}): max abs err 3D {e3:.3e} 2D {e2:.3e}")
     close(y3, r3, rtol=rtol, atol=atol, msg="3D stream")
     close(y2, r2, rtol=rtol, atol=atol, msg="2D stream")
+    with pytest.raises(ValueError):
+        hip.call("ophip_encoder_layer_bf16", hip.ptr(d3), hip.ptr(d2), hip.ptr(y3), hip.ptr(y2), B, L3, L2, hip.ptr(w, None), None, 3, cross, 0, 0,
+                 hip.ptr(ws, None), hip.stream_handle())
 
 
-X3_KERNELS = {"x3": ("ophip_encoder_layer_x3", "ophip_encoder_x3_wpack_bytes", "ophip_encoder_x3_workspace_bytes", "pack_coarse_layer_x3"),
-              "x3w8": ("ophip_encoder_layer_x3w8", "ophip_encoder_x3w8_wpack_bytes", "ophip_encoder_x3w8_workspace_bytes", "pack_coarse_layer_x3w8")}
+X3_KERNELS = {"x3w8": ("ophip_encoder_layer_x3w8", "ophip_encoder_x3w8_wpack_bytes", "ophip_encoder_x3w8_workspace_bytes", "pack_coarse_layer_x3w8")}
 
 
-@pytest.mark.parametrize("kern", ["x3", "x3w8"])
+@pytest.mark.parametrize("kern", ["x3w8"])
 @pytest.mark.parametrize("cross", [0, 1])
 @pytest.mark.parametrize("B,L3,L2", [(1, 64, 32), (2, 70, 45), (1, 1000, 1200), (3, 49, 97)])
 def test_encoder_layer_x3(sd, dev, cross, B, L3, L2, kern):
-    """split-bf16 layer on 16-token tiles / per-wave weight streams (csrc/encoder_x3.hip): tracks the f32 oracle to ~1e-4
+    """split-bf16 layer on 16-token tiles / per-wave weight streams (csrc/encoder_x3w8.hip, the default): tracks the f32 oracle to ~1e-4
     at ragged sizes (tokens not a multiple of 48, several frames)."""
     g = torch.Generator().manual_seed(2)
     x3, x2 = torch.randn(B, L3, 256, generator=g), torch.randn(B, L2, 256, generator=g)
@@ -220,7 +222,7 @@ def test_encoder_layer_writes_the_similarity_fragments(sd, dev, B, N, hc, wc):
     assert torch.equal(ref[0], got[0]) and all(torch.equal(a, b) for a, b in zip(ref[1], got[1])) and torch.equal(ref[2], got[2])
 
 
-@pytest.mark.parametrize("kern", ["x3", "x3w8"])
+@pytest.mark.parametrize("kern", ["x3w8"])
 @pytest.mark.parametrize("B,L3,L2", [(1, 100, 75), (2, 333, 260)])
 def test_encoder_x3_chain_with_fused_kv_tail(sd, dev, B, L3, L2, kern):
     """three chained layers (self, cross, self): layers 1.. take their K|V slabs from the previous launch's fused tail
@@ -361,11 +363,9 @@ def test_coarse_match_empty(dev):
     close(conf, orc.dual_softmax_confidence(f3, f2, 0.08), atol=1e-7)
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16", "x3"])
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16"])
 @pytest.mark.parametrize("channels_last", [False, True])
 def test_fine_refine_vs_oracle(sd, cfg, dev, channels_last, mode):
-    if mode == "x3" and not channels_last:
-        pytest.skip("ophip_fine_refine_x3 takes the channels-last map (the model always hands it one)")
     B, N, hc, wc = 2, 90, 6, 7
     hf, wf = hc * 4, wc * 4
     g = torch.Generator().manual_seed(7)
@@ -399,11 +399,6 @@ def test_fine_refine_vs_oracle(sd, cfg, dev, channels_last, mode):
         w = torch.cat([packing.pack_fine_layer(sd, f"loftr_fine.layers.{i}.") for i in range(2)]).to(dev)
         hip.call("ophip_fine_refine", *head, hip.ptr(w), 2, ctypes.c_uint(2), 1, *tail)
         rt, at = RTOL, ATOL
-    elif mode == "x3":                           # three matches per workgroup: K = 37 leaves a single match in the last one
-        w = packing.pack_fine_layers_x3(sd, "loftr_fine.layers.", 2).to(dev)
-        assert w.numel() == hip.load().ophip_fine_x3_wpack_bytes(2)
-        hip.call("ophip_fine_refine_x3", *head, hip.ptr(w, None), 2, ctypes.c_uint(2), 1, *tail)
-        rt, at = 5e-4, 2e-4
     else:
         w = packing.pack_fine_layers_bf16(sd, "loftr_fine.layers.", 2).to(dev)
         assert w.numel() == hip.load().ophip_fine_bf16_wpack_bytes(2)
@@ -809,26 +804,63 @@ def test_object_cache_is_bit_identical(sd, cfg, dev):
         assert torch.equal(a[k], b[k]), k
 
 
-def test_custom_ops_match_the_c_abi(sd, dev):
-    """torch.ops.onepose_hip.* (onepose_st_amd/ops.py) forward to the same C symbols: one encoder layer and the coarse-matching
-    stage through the ops equal the direct calls bit for bit"""
+def test_custom_ops_match_the_c_abi(sd, cfg, dev):
+    """torch.ops.onepose_hip.* (onepose_st_amd/ops.py) forward to the same C symbols the model runs by default: the eight-wave
+    encoder layer (plain and fragment-writing form), coarse matching and the fused fine stage through the ops equal the direct
+    C-ABI calls bit for bit"""
     from onepose_st_amd import ops  # noqa: F401  (registers the library)
     g = torch.Generator().manual_seed(3)
-    B, L3, L2 = 1, 130, 96
+    B, L3, hc, wc = 1, 130, 8, 12
+    L2 = hc * wc
     x3, x2 = torch.randn(B, L3, 256, generator=g).to(dev), torch.randn(B, L2, 256, generator=g).to(dev)
-    w = packing.pack_coarse_layer_x3(sd, "loftr_coarse.layers.0.").to(dev)
-    ws = torch.empty(hip.load().ophip_encoder_x3_workspace_bytes(B, L3, L2), dtype=torch.uint8, device=dev)
+    w = packing.pack_coarse_layer_x3w8(sd, "loftr_coarse.layers.0.").to(dev)
+    ws = torch.empty(hip.load().ophip_encoder_x3w8_workspace_bytes(B, L3, L2), dtype=torch.uint8, device=dev)
     y3, y2 = torch.empty_like(x3), torch.empty_like(x2)
-    torch.ops.onepose_hip.encoder_layer_x3(x3, x2, y3, y2, w, None, False, False, 0, ws)
+    torch.ops.onepose_hip.encoder_layer_x3w8(x3, x2, y3, y2, w, None, False, False, 0, ws)
     z3, z2 = torch.empty_like(x3), torch.empty_like(x2)
-    hip.call("ophip_encoder_layer_x3", hip.ptr(x3), hip.ptr(x2), hip.ptr(z3), hip.ptr(z2), B, L3, L2, hip.ptr(w, None), None, 0, 0, 0,
+    hip.call("ophip_encoder_layer_x3w8", hip.ptr(x3), hip.ptr(x2), hip.ptr(z3), hip.ptr(z2), B, L3, L2, hip.ptr(w, None), None, 0, 0, 0,
              hip.ptr(ws, None), hip.stream_handle())
     assert torch.equal(y3, z3) and torch.equal(y2, z2)
+    # the fragment-writing form: same rows, and coarse matching fed from the planes gives the same matches
+    cws = torch.empty(hip.load().ophip_coarse_workspace_floats(B, L3, L2), device=dev)
+    f3, f2 = torch.empty_like(x3), torch.empty_like(x2)
+    torch.ops.onepose_hip.encoder_layer_x3w8_frag(x3, x2, f3, f2, w, None, False, False, 0, ws, cws)
+    assert torch.equal(f3, z3) and torch.equal(f2, z2)
     kp = torch.randn(B, L3, 3, generator=g).to(dev)
-    f2 = y2.clone()
-    f2[0, :40] = y3[0, :40]                                   # plant matches
-    conf, b_ids, i_ids, j_ids, mconf, mk3, mkc, count = torch.ops.onepose_hip.coarse_match(y3, f2, kp, 12, 0.08, 0.1, 0, 8.0, 3)
+    q2 = y2.clone()
+    q2[0, 30:70] = y3[0, :40]                                   # plant matches away from the top / left border
+    conf, b_ids, i_ids, j_ids, mconf, mk3, mkc, count = torch.ops.onepose_hip.coarse_match(y3, q2, kp, wc, 0.08, 0.1, 0, 8.0, 3)
     K = int(count.item())
     assert K >= 30 and conf.shape == (B, L3, L2) and torch.all(i_ids[:K][1:] > i_ids[:K][:-1])
+    ref = _coarse_match(dev, y3.cpu(), q2.cpu(), kp.cpu(), wc, border=0, nsplit=3)
+    assert torch.equal(conf, ref[0]) and torch.equal(i_ids[:K], ref[1][1]) and torch.equal(j_ids[:K], ref[1][2]) and torch.equal(mconf[:K], ref[2])
+    # fused fine stage: gather + 2 fine layers + correlation + soft-argmax
+    hf, wf = 4 * hc, 4 * wc
+    ff = torch.randn(B, 128, hf, wf, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    dd = torch.randn(B, 128, L3, generator=g).to(dev)
+    wf_ = packing.pack_fine_layers_bf16(sd, "loftr_fine.layers.", 2).to(dev)
+    expec, mkf = torch.ops.onepose_hip.fine_refine_bf16(ff, dd, b_ids, i_ids, j_ids, count, mkc, wf_, 2, 2, True, 3, wc, 4, 4.0)
+    e2, m2 = torch.full_like(expec, float("nan")), torch.full_like(mkf, float("nan"))
+    cap = b_ids.numel()
+    hip.call("ophip_fine_refine_bf16", hip.ptr(ff), ff.stride(0), ff.stride(1), ff.stride(2), ff.stride(3), hf, wf, hip.ptr(dd), dd.stride(0), dd.stride(1),
+             hip.ptr(b_ids, torch.int64), hip.ptr(i_ids, torch.int64), hip.ptr(j_ids, torch.int64), hip.ptr(count, torch.int32), cap, hip.ptr(mkc),
+             hip.ptr(wf_, None), 2, ctypes.c_uint(2), 1, 3, wc, 4, 4.0, hip.ptr(e2), hip.ptr(m2), None, None, hip.stream_handle())
+    assert torch.equal(expec[:K], e2[:K]) and torch.equal(mkf[:K], m2[:K]) and torch.isfinite(mkf[:K]).all()
     with pytest.raises(ValueError):
-        torch.ops.onepose_hip.encoder_layer_x3(x3, x2, y3, y2, w, None, False, False, 0, ws[:64])
+        torch.ops.onepose_hip.encoder_layer_x3w8(x3, x2, y3, y2, w, None, False, False, 0, ws[:64])
+    with pytest.raises((ValueError, RuntimeError, NotImplementedError)):          # no CPU implementation behind the ops
+        torch.ops.onepose_hip.encoder_layer_x3w8(x3.cpu(), x2.cpu(), y3.cpu(), y2.cpu(), w.cpu(), None, False, False, 0, ws.cpu())
+
+
+def test_model_default_path_dispatches_through_the_frame_op(sd, cfg, dev):
+    """OnePosePlus_model's default (bf16x3) forward goes through torch.ops.onepose_hip.frame_enqueue: one custom-op call per frame"""
+    from onepose_st_amd import ops
+    m = _model(sd, cfg, dev, "bf16x3")
+    inp = make_synthetic_inputs(sd, n_points=300, image_hw=(64, 96), n_plant=90, seed=4, config=cfg)
+    n_plans, n_calls = len(ops._frame_plans), ops.CALLS["frame_enqueue"]
+    for _ in range(3):
+        data = {k: inp[k].to(dev) for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db")}
+        m.forward_features(data, inp["feat_c"].to(dev), inp["feat_f"].to(dev), inp["image_hw"])
+        assert data["i_ids"].numel() > 20
+    assert len(ops._frame_plans) == n_plans + 1               # one plan per (model, input shape), registered once
+    assert ops.CALLS["frame_enqueue"] == n_calls + 3           # one op call per frame

@@ -1,5 +1,5 @@
-"""Index arithmetic of csrc/encoder_x3.hip on a lane-level emulation of v_mfma_f32_16x16x32_bf16, in exact arithmetic:
-the per-wave weight streams of packing.x3_program, both operand orientations, the swizzled planes and quad stores, the
+"""Index arithmetic of csrc/encoder_x3w8.hip on a lane-level emulation of v_mfma_f32_16x16x32_bf16, in exact arithmetic:
+the per-wave weight streams of packing.x3w8_program (eight waves, wave fw = head fw), both operand orientations, the swizzled planes and quad stores, the
 MLP chunk order, and the accumulator-as-operand chain  K|V tail -> slab -> kv_sum fragments -> attention."""
 import numpy as np
 import torch
@@ -62,67 +62,58 @@ def test_stream_gemm_weights_as_a_and_quad_store_roundtrip():
     px.load_rows(x)
     out = np.zeros((48, 256))
     dst = E.Plane(48, 512)
-    for fw in range(4):
-        main, _ = packing.x3_program(fw)
-        acc = gemm_stage(main[:32], mats, px, 4, 8, True)                 # Q stage = first 32 entries
-        for ft in range(4):
+    for fw in range(8):
+        main, _ = packing.x3w8_program(fw)
+        acc = gemm_stage(main[:16], mats, px, 2, 8, True)                 # Q stage = first 16 entries (32 fragments hi + lo)
+        for ft in range(2):
             for tt in range(NTT):
                 for l in range(64):
-                    f0 = 64 * fw + 16 * ft + 4 * Q[l]
+                    f0 = 32 * fw + 16 * ft + 4 * Q[l]
                     out[16 * tt + C16[l], f0:f0 + 4] = acc[ft][tt][l]
                     store_quad(dst, acc[ft][tt][l], tt, l, f0)
     ref = x @ mats["q"].T
     np.testing.assert_allclose(out, ref, atol=1e-9)
     back = np.stack([np.concatenate([dst.read16(E.plane_off(row, ch, 512)) for ch in range(32)]) for row in range(48)])
     np.testing.assert_allclose(back, ref, atol=1e-9)
-    # merge stage = entries 32..63 of the same stream
-    acc = gemm_stage(packing.x3_program(2)[0][32:64], mats, px, 4, 8, True)
-    np.testing.assert_allclose(acc[1][2][:, 0], (x @ mats["m"].T)[32 + C16, 128 + 16 + 4 * Q], atol=1e-9)
+    # merge stage = entries 16..31 of the same stream
+    acc = gemm_stage(packing.x3w8_program(5)[0][16:32], mats, px, 2, 8, True)
+    np.testing.assert_allclose(acc[1][2][:, 0], (x @ mats["m"].T)[32 + C16, 32 * 5 + 16 + 4 * Q], atol=1e-9)
 
 
 def test_mlp_chunk_order_of_the_stream():
-    """W0c0 | W0c1 | W2c0 | W0c2 | W2c1 | W0c3 | W2c2 | W2c3 with x-half / msg-half k-steps and 128-wide hidden planes"""
+    """W0c0 | W2c0 | W0c1 | W2c1: 256-wide hidden chunks through ONE hidden buffer, x-half then msg-half k-steps"""
     mats = mats_random(2)
     g = np.random.default_rng(3)
     x, msg = g.normal(size=(48, 256)), g.normal(size=(48, 256))
     px, py = E.Plane(48, 512), E.Plane(48, 512)
     px.load_rows(x), py.load_rows(msg)
-    order = [("w0", 0), ("w0", 1), ("w2", 0), ("w0", 2), ("w2", 1), ("w0", 3), ("w2", 2), ("w2", 3)]
     hidden_ref = np.maximum(np.concatenate([x, msg], 1) @ mats["w0"].T, 0.0)
     out_ref = hidden_ref @ mats["w2"].T
-    hbuf = [E.Plane(48, 256), E.Plane(48, 256)]
-    streams = [packing.x3_program(fw)[0][64:] for fw in range(4)]
-    pos = [0] * 4
-    o = [[[np.zeros((64, 4)) for _ in range(NTT)] for _ in range(4)] for _ in range(4)]
-    hid = {}
-    for kind, c in order:
-        for fw in range(4):
-            if kind == "w0":
-                prog = streams[fw][pos[fw]:pos[fw] + 32]
-                a = gemm_stage(prog[:16], mats, px, 2, 8, True)
-                b = gemm_stage(prog[16:], mats, py, 2, 8, True)
-                hid[(c, fw)] = [[a[ft][tt] + b[ft][tt] for tt in range(NTT)] for ft in range(2)]
-                pos[fw] += 32
-            else:
-                prog = streams[fw][pos[fw]:pos[fw] + 16]
-                a = gemm_stage(prog, mats, hbuf[c & 1], 4, 4, True)
-                for ft in range(4):
-                    for tt in range(NTT):
-                        o[fw][ft][tt] += a[ft][tt]
-                pos[fw] += 16
-        if kind == "w0":                               # the chunk's relu + store happens before its W2 (buffer c & 1)
-            for fw in range(4):
-                for ft in range(2):
-                    for tt in range(NTT):
-                        for l in range(64):
-                            store_quad(hbuf[c & 1], np.maximum(hid[(c, fw)][ft][tt][l], 0), tt, l, 32 * fw + 16 * ft + 4 * Q[l])
-    assert pos == [192] * 4
+    streams = [packing.x3w8_program(fw)[0][32:] for fw in range(8)]
+    o = [[[np.zeros((64, 4)) for _ in range(NTT)] for _ in range(2)] for _ in range(8)]
+    for c in range(2):
+        hbuf = E.Plane(48, 512)
+        pos = 48 * c
+        for fw in range(8):
+            prog = streams[fw][pos:pos + 32]
+            a = gemm_stage(prog[:16], mats, px, 2, 8, True)
+            b = gemm_stage(prog[16:], mats, py, 2, 8, True)
+            for ft in range(2):
+                for tt in range(NTT):
+                    for l in range(64):
+                        store_quad(hbuf, np.maximum(a[ft][tt][l] + b[ft][tt][l], 0), tt, l, 32 * fw + 16 * ft + 4 * Q[l])
+        for fw in range(8):
+            a = gemm_stage(streams[fw][pos + 32:pos + 48], mats, hbuf, 2, 8, True)
+            for ft in range(2):
+                for tt in range(NTT):
+                    o[fw][ft][tt] += a[ft][tt]
+    assert all(len(st) == 96 for st in streams)
     out = np.zeros((48, 256))
-    for fw in range(4):
-        for ft in range(4):
+    for fw in range(8):
+        for ft in range(2):
             for tt in range(NTT):
                 for l in range(64):
-                    f0 = 64 * fw + 16 * ft + 4 * Q[l]
+                    f0 = 32 * fw + 16 * ft + 4 * Q[l]
                     out[16 * tt + C16[l], f0:f0 + 4] = o[fw][ft][tt][l]
     np.testing.assert_allclose(out, out_ref, atol=1e-7)
 
@@ -138,67 +129,65 @@ def test_kv_tail_slab_kv_sum_attention_chain():
     Kf, Vf = phi(y @ mats["k"].T), y @ mats["v"].T     # [tok][256]
     blk = np.full((8, 2, 64, 8), np.nan)               # kv_sum fragments [head][vt][lane][j]  (hi plane only: exact)
     ksum = np.zeros((8, 32))
-    for fw in range(4):
-        _, kvp = packing.x3_program(fw)
-        kk = gemm_stage(kvp, mats, py, 8, 8, False)    # D[token 4q + r][feature c16]
-        for ft in range(4):
+    for fw in range(8):                                # wave fw = head fw: ft 0, 1 = K tiles, ft 2, 3 = V tiles
+        _, kvp = packing.x3w8_program(fw)
+        kk = gemm_stage(kvp, mats, py, 4, 8, False)    # D[token 4q + r][feature c16]
+        for ft in range(2):
             for tt in range(NTT):
                 kk[ft][tt] = phi(kk[ft][tt])
-        np.testing.assert_allclose(kk[5][1][:, 2], Vf[16 + 4 * Q + 2, 64 * fw + 16 + C16], atol=1e-9)
+        np.testing.assert_allclose(kk[3][1][:, 2], Vf[16 + 4 * Q + 2, 32 * fw + 16 + C16], atol=1e-9)
         z = np.zeros((64, 4))
-        for hh in range(2):
-            head = 2 * fw + hh
-            for dt in range(2):
-                for vt in range(2):
-                    a0 = np.concatenate([kk[2 * hh + dt][0], kk[2 * hh + dt][1]], 1)
-                    a1 = np.concatenate([kk[2 * hh + dt][2], z], 1)
-                    b0 = np.concatenate([kk[4 + 2 * hh + vt][0], kk[4 + 2 * hh + vt][1]], 1)
-                    b1 = np.concatenate([kk[4 + 2 * hh + vt][2], z], 1)
-                    kvt = mfma16(a1, b1, mfma16(a0, b0, np.zeros((64, 4))))
-                    # slab [head][dt][vt][lane][r]  ->  kv_sum: fragment element j = 4 dt + r of [head][vt][lane]
-                    blk[head, vt, :, 4 * dt:4 * dt + 4] = kvt
-                s = sum(kk[2 * hh + dt][tt].sum(1) for tt in range(NTT))          # per lane: its 12 tokens
-                tot = np.array([s[(L64 & 15) == c].sum() for c in range(16)])     # + the xor-16 / xor-32 butterflies
-                ksum[head, 16 * dt:16 * dt + 16] = tot
+        head = fw
+        for dt in range(2):
+            for vt in range(2):
+                a0 = np.concatenate([kk[dt][0], kk[dt][1]], 1)
+                a1 = np.concatenate([kk[dt][2], z], 1)
+                b0 = np.concatenate([kk[2 + vt][0], kk[2 + vt][1]], 1)
+                b1 = np.concatenate([kk[2 + vt][2], z], 1)
+                kvt = mfma16(a1, b1, mfma16(a0, b0, np.zeros((64, 4))))
+                # slab [head][dt][vt][lane][r]  ->  kv_sum: fragment element j = 4 dt + r of [head][vt][lane]
+                blk[head, vt, :, 4 * dt:4 * dt + 4] = kvt
+            s = sum(kk[dt][tt].sum(1) for tt in range(NTT))                   # per lane: its 12 tokens
+            tot = np.array([s[(L64 & 15) == c].sum() for c in range(16)])     # + the permlane sums over q
+            ksum[head, 16 * dt:16 * dt + 16] = tot
     KV = np.stack([Kf[:, 32 * h:32 * h + 32].T @ Vf[:, 32 * h:32 * h + 32] for h in range(8)])
     np.testing.assert_allclose(ksum, Kf.sum(0).reshape(8, 32), atol=1e-9)
     # attention on the query tile: phi(Q) accumulators (D[feature][token]) as the B operand
     Qf = phi(xq @ mats["q"].T)
     msg = np.zeros((48, 256))
-    for fw in range(4):
-        main, _ = packing.x3_program(fw)
-        qa = gemm_stage(main[:32], mats, pq, 4, 8, True)
-        for hh in range(2):
-            head = 2 * fw + hh
-            for tt in range(NTT):
-                p0, p1 = phi(qa[2 * hh][tt]), phi(qa[2 * hh + 1][tt])
-                den_l = np.array([p0[l] @ ksum[head, 4 * Q[l]:4 * Q[l] + 4] + p1[l] @ ksum[head, 16 + 4 * Q[l]:20 + 4 * Q[l]] for l in range(64)])
-                den = np.array([den_l[(L64 & 15) == C16[l]].sum() for l in range(64)])
-                qfrag = np.concatenate([p0, p1], 1)
-                for vt in range(2):
-                    num = mfma16(blk[head, vt], qfrag, np.zeros((64, 4)))
-                    for l in range(64):
-                        f0 = 64 * fw + 32 * hh + 16 * vt + 4 * Q[l]
-                        msg[16 * tt + C16[l], f0:f0 + 4] = num[l] / den[l]
+    for fw in range(8):
+        main, _ = packing.x3w8_program(fw)
+        qa = gemm_stage(main[:16], mats, pq, 2, 8, True)
+        head = fw
+        for tt in range(NTT):
+            p0, p1 = phi(qa[0][tt]), phi(qa[1][tt])
+            den_l = np.array([p0[l] @ ksum[head, 4 * Q[l]:4 * Q[l] + 4] + p1[l] @ ksum[head, 16 + 4 * Q[l]:20 + 4 * Q[l]] for l in range(64)])
+            den = np.array([den_l[(L64 & 15) == C16[l]].sum() for l in range(64)])
+            qfrag = np.concatenate([p0, p1], 1)
+            for vt in range(2):
+                num = mfma16(blk[head, vt], qfrag, np.zeros((64, 4)))
+                for l in range(64):
+                    f0 = 32 * fw + 16 * vt + 4 * Q[l]
+                    msg[16 * tt + C16[l], f0:f0 + 4] = num[l] / den[l]
     ref = np.concatenate([(Qf[:, 32 * h:32 * h + 32] @ KV[h]) / (Qf[:, 32 * h:32 * h + 32] @ Kf.sum(0)[32 * h:32 * h + 32])[:, None] for h in range(8)], 1)
     np.testing.assert_allclose(msg, ref, rtol=1e-9, atol=1e-9)
 
 
-def test_x3_block_layout(sd):
+def test_x3w8_block_layout(sd):
     p = "loftr_coarse.layers.1."
-    blk = packing.pack_coarse_layer_x3(sd, p)
-    assert blk.dtype == torch.uint8 and blk.numel() == 4 * 640 * 1024 + 16 * 256
-    fr = blk[:4 * 640 * 1024].view(torch.bfloat16).float().view(-1, 2, 64, 8)          # [entry][plane][lane][j]
-    main, kv = packing.x3_program(3)
-    e = 3 * 256 + 70                                   # wave 3, entry 70 of its main stream
+    blk = packing.pack_coarse_layer_x3w8(sd, p)
+    assert blk.dtype == torch.uint8 and blk.numel() == 8 * 320 * 1024 + 16 * 256
+    fr = blk[:8 * 320 * 1024].view(torch.bfloat16).float().view(-1, 2, 64, 8)          # [entry][plane][lane][j]
+    main, kv = packing.x3w8_program(3)
+    e = 3 * 128 + 70                                   # wave 3, entry 70 of its main stream (128 entries = 256 fragments per wave)
     m, r0, k0 = main[70]
     w = {"q": "q_proj", "m": "merge", "w0": "mlp.0", "w2": "mlp.2"}[m]
     want = packing.x3_frag(sd[p + w + ".weight"].float(), r0, k0)
     assert torch.equal(fr[e, 0], want.to(torch.bfloat16).float())
     np.testing.assert_allclose((fr[e, 0] + fr[e, 1]).numpy(), want.numpy(), rtol=2 ** -15, atol=1e-9)
-    e = 4 * 256 + 1 * 64 + 9                           # K|V streams follow the four main streams
-    m, r0, k0 = packing.x3_program(1)[1][9]
+    e = 8 * 128 + 1 * 32 + 9                           # K|V streams follow the eight main streams (32 entries per wave)
+    m, r0, k0 = packing.x3w8_program(1)[1][9]
     want = packing.x3_frag(sd[p + ("k_proj" if m == "k" else "v_proj") + ".weight"].float(), r0, k0)
     assert torch.equal(fr[e, 0], want.to(torch.bfloat16).float())
-    ln = blk[4 * 640 * 1024:].view(torch.float32)
+    ln = blk[8 * 320 * 1024:].view(torch.float32)
     assert torch.equal(ln[:256], sd[p + "norm1.weight"]) and torch.equal(ln[768:], sd[p + "norm2.bias"])

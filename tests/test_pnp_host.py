@@ -91,3 +91,91 @@ def test_trial_policy_follows_the_reference_branches():
     pa, _, ia = ransac_PnP(K, uv, X, pnp_reprojection_error=7)
     pr, _, ir = ransac_PnP(K, uv, X, pnp_reprojection_error=7, use_pycolmap_ransac=True, min_iters=2000)
     assert np.abs(pa[:, :3] - pr[:, :3]).max() < 1e-4 and abs(len(ia) - len(ir)) <= 2      # more trials, the same pose to refinement accuracy
+
+
+def _pose(rng, ang=None):
+    ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+    ang = rng.uniform(0.1, 2.5) if ang is None else ang
+    Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    return np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx, np.array([0.05 * rng.normal(), 0.05 * rng.normal(), 0.45])
+
+
+def test_p3p_minimal_solver_contains_the_planted_pose():
+    """Grunert quartic + triangle alignment: on exact data one of the (at most four) roots is the planted pose; every returned
+    pose is a rotation that reprojects its three points exactly"""
+    from onepose_st_amd.pnp import p3p
+    rng = np.random.default_rng(0)
+    hit, total_roots, sharp = 0, 0, 0
+    for trial in range(500):
+        R, t = _pose(rng)
+        X = (rng.random((3, 3)) - 0.5) * 0.2
+        pc = X @ R.T + t
+        rays = pc[:, :2] / pc[:, 2:]
+        sols = p3p(rays, X)
+        assert len(sols) <= 4
+        total_roots += len(sols)
+        for ps in sols:
+            Rs, ts = ps[:, :3], ps[:, 3]
+            assert np.abs(Rs @ Rs.T - np.eye(3)).max() < 1e-9 and abs(np.linalg.det(Rs) - 1) < 1e-9
+            q = X @ Rs.T + ts
+            # (a root next to a double root of the quartic is only as sharp as the square root of the rounding: still far below a pixel)
+            assert np.abs(q[:, :2] / q[:, 2:] - rays).max() < 1e-4 and (q[:, 2] > 0).all()
+            sharp += np.abs(q[:, :2] / q[:, 2:] - rays).max() < 1e-9
+        if sols and min(np.abs(ps[:, :3] - R).max() + np.abs(ps[:, 3] - t).max() for ps in sols) < 1e-6:
+            hit += 1
+    assert hit >= 490, hit                   # a handful of samples sit on a double root of the quartic (lost to rounding: RANSAC draws another)
+    assert 500 <= total_roots <= 2000 and sharp >= 0.97 * total_roots
+    assert p3p(np.zeros((3, 2)), np.array([[0, 0, 0], [1, 1, 1], [2, 2, 2.0]])) == []          # collinear points: no pose
+
+
+def _planar_scene(n, seed, noise_px=0.0, outlier_frac=0.0):
+    """every 3D point on ONE face of a box (z = const in the object frame): what a 6-point DLT cannot solve"""
+    rng = np.random.default_rng(seed)
+    X = np.concatenate([(rng.random((n, 2)) - 0.5) * np.array([0.2, 0.14]), np.full((n, 1), 0.05)], 1)
+    R, t = _pose(rng, ang=0.6)
+    K = np.array([[1216.0, 0, 320.0], [0, 1216.0, 240.0], [0, 0, 1]])
+    pc = X @ R.T + t
+    uv = (pc[:, :2] / pc[:, 2:]) * 1216.0 + np.array([320.0, 240.0]) + noise_px * rng.normal(size=(n, 2))
+    n_out = int(outlier_frac * n)
+    if n_out:
+        uv[:n_out] = rng.random((n_out, 2)) * np.array([640.0, 480.0])
+    return K, uv.astype(np.float32), X.astype(np.float32), R, t, n_out
+
+
+@pytest.mark.parametrize("pycolmap_branch", [True, False])
+def test_coplanar_scene_recovers_the_planted_pose(pycolmap_branch):
+    """box faces / cards are what OnePose tracks: the P3P branch (and the DLT branch through its P3P fallback) must solve them"""
+    K, uv, X, R, t, n_out = _planar_scene(1500, 21, noise_px=0.4, outlier_frac=0.25)
+    kw = dict(min_iters=1000) if pycolmap_branch else {}
+    pose, _, inl = ransac_PnP(K, uv, X, pnp_reprojection_error=7, use_pycolmap_ransac=pycolmap_branch, **kw)
+    assert _rot_err(pose[:, :3], R) < 0.1 and np.linalg.norm(pose[:, 3] - t) / np.linalg.norm(t) < 3e-3
+    assert len(inl) >= 0.95 * (1500 - n_out) and (inl >= n_out).mean() > 0.97
+    pose2, _, inl2 = ransac_PnP(K, uv, X, pnp_reprojection_error=7, use_pycolmap_ransac=pycolmap_branch, **kw)
+    assert np.array_equal(pose, pose2) and np.array_equal(inl, inl2)                       # deterministic
+
+
+def test_p3p_branch_on_a_general_scene_and_pool_thread_independence():
+    K, uv, X, R, t, n_out = _scene(2000, 31, noise_px=0.5, outlier_frac=0.3)
+    pose, _, inl = ransac_PnP(K, uv, X, pnp_reprojection_error=7, use_pycolmap_ransac=True, min_iters=1500)
+    assert _rot_err(pose[:, :3], R) < 0.05 and np.linalg.norm(pose[:, 3] - t) / np.linalg.norm(t) < 2e-3
+    for threads in (1, 4):
+        pool = PnPPool(K, threads=threads, pnp_reprojection_error=7, policy="reference", min_iters=1500)
+        tk = pool.submit(uv, X)
+        pool.wait_all()
+        p2, n_in, rc = pool.result(tk)
+        assert rc == 0 and np.array_equal(p2, pose) and n_in == len(inl)
+        pool.close()
+
+
+def test_reference_policy_cost_is_reported():
+    """ms per 10 000 trials of the pycolmap-branch policy (P3P, every root scored) at the matcher's match count"""
+    import time
+    K, uv, X, R, t, _ = _scene(3000, 41, noise_px=0.5, outlier_frac=0.05)
+    t0 = time.perf_counter()
+    pose, _, inl = ransac_PnP(K, uv, X, pnp_reprojection_error=7, use_pycolmap_ransac=True)
+    ms = 1e3 * (time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    ransac_PnP(K, uv, X, pnp_reprojection_error=7, use_pycolmap_ransac=True, solver="dlt6")
+    ms6 = 1e3 * (time.perf_counter() - t0)
+    print(f"10 000 trials at 3 000 correspondences, single thread: P3P {ms:.1f} ms, 6-point DLT {ms6:.1f} ms")
+    assert _rot_err(pose[:, :3], R) < 0.05 and len(inl) > 2700 and ms < 2000

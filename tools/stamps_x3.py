@@ -1,4 +1,4 @@
-"""Diagnostic: per-phase cycle stamps and launch time of the x3 encoder layer kernel at c2 (or --tokens N).  Not part of the product."""
+"""Diagnostic: per-phase cycle stamps and launch time of the eight-wave x3 encoder layer kernel (csrc/encoder_x3w8.hip, the shipped default) at c2 (or --tokens N).  Not part of the product."""
 import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -11,10 +11,9 @@ L3, L2 = 7000, 4800
 g = torch.Generator().manual_seed(0)
 x3, x2 = torch.randn(B, L3, 256, generator=g).to(dev), torch.randn(B, L2, 256, generator=g).to(dev)
 y3, y2 = torch.empty_like(x3), torch.empty_like(x2)
-W8 = os.environ.get("OPHIP_ENC_W8", "1") != "0"
-ENTRY = "ophip_encoder_layer_x3w8" if W8 else "ophip_encoder_layer_x3"
-w = (packing.pack_coarse_layer_x3w8 if W8 else packing.pack_coarse_layer_x3)(sd, "loftr_coarse.layers.0.").to(dev)
-ws = torch.empty(getattr(hip.load(), ENTRY.replace("layer_", "") + "_workspace_bytes")(B, L3, L2), dtype=torch.uint8, device=dev)
+ENTRY = "ophip_encoder_layer_x3w8"
+w = packing.pack_coarse_layer_x3w8(sd, "loftr_coarse.layers.0.").to(dev)
+ws = torch.empty(hip.load().ophip_encoder_x3w8_workspace_bytes(B, L3, L2), dtype=torch.uint8, device=dev)
 fuse = not os.environ.get("NOFUSE")
 def run():
     hip.call(ENTRY, hip.ptr(x3), hip.ptr(x2), hip.ptr(y3), hip.ptr(y2), B, L3, L2, hip.ptr(w, None),
@@ -30,13 +29,8 @@ nwg = B * ((L3 + 47) // 48 + (L2 + 47) // 48)
 buf = torch.zeros(nwg * 32, dtype=torch.int64, device=dev)
 hip.call("ophip_debug_stamps", ctypes.c_void_p(buf.data_ptr())); run(); torch.cuda.synchronize(); hip.call("ophip_debug_stamps", None)
 s = buf.view(-1, 32)[:nwg].cpu().numpy().astype(np.int64)
-names8 = ["start", "rows in + ring fill + stage + sync", "Q gemm", "attention + msg store + sync", "merge gemm", "LN1 + store + sync",
-          "W0c0 + hidden store + sync", "W2c0", "W0c1 + sync + hidden store + sync", "W2c1", "LN2 + residual + store", "K|V tail"]
-names = ["start", "ring fill + KV/Ksum loads + X stage + sync", "Q gemm", "attention + msg store + sync", "merge gemm", "LN1 moments + sync",
-         "W0c0 x-half (+LN1 normalise) + sync", "W0c0 msg-half", "W0c1 (+store c0) + sync", "W2c0 + W0c2 (+store c1) + sync",
-         "W2c1 + W0c3 (+store c2) + sync", "W2c2 (+store c3) + sync", "W2c3", "LN2 + residual + store", "K|V tail"]
-if W8:
-    names = names8
+names = ["start", "rows in + ring fill + stage + sync", "Q gemm", "attention + msg store + sync", "merge gemm", "LN1 + store + sync",
+         "W0c0 + hidden store + sync", "W2c0", "W0c1 + sync + hidden store + sync", "W2c1", "LN2 + residual + store", "K|V tail"]
 last = len(names) - 1
 d = s[:, last] - s[:, 0]
 print("workgroups", nwg, "WG cycles p10/p50/p90", np.percentile(d, 10), np.median(d), np.percentile(d, 90))

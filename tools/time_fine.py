@@ -21,10 +21,8 @@ head = (hip.ptr(ff), hf * wf * 128, 1, wf * 128, 128, hf, wf, hip.ptr(desc), des
         hip.ptr(b_ids, torch.int64), hip.ptr(i_ids, torch.int64), hip.ptr(j_ids, torch.int64), hip.ptr(cnt, torch.int32), cap, hip.ptr(mkc))
 tail = (wc, 4, 4.0, hip.ptr(expec), hip.ptr(mkf), None, None, hip.stream_handle())
 w1 = packing.pack_fine_layers_bf16(sd, "loftr_fine.layers.", 2).to(dev)
-w3 = packing.pack_fine_layers_x3(sd, "loftr_fine.layers.", 2).to(dev)
 def v1(): hip.call("ophip_fine_refine_bf16", *head, hip.ptr(w1, None), 2, ctypes.c_uint(2), 1, 3, *tail)
-def v3(): hip.call("ophip_fine_refine_x3", *head, hip.ptr(w3, None), 2, ctypes.c_uint(2), 1, *tail)
-for name, fn in (("fine_refine_bf16 (1 match / workgroup)", v1), ("fine_refine_x3 (3 matches / workgroup)", v3)):
+for name, fn in (("fine_refine_bf16 (1 match / workgroup)", v1),):
     for _ in range(3): fn()
     torch.cuda.synchronize(); hip.timing_select("fine_refine")
     for _ in range(20): fn()
