@@ -361,16 +361,22 @@ def main():
         pnp_ceiling = rate * world
 
     # HBM bytes and matrix-pipe busy cycles per launch of the roofline kernel: from the committed counter passes (separate
-    # rocprofv3 --pmc runs, tools/run_profile_r02.sh), not live
-    traffic, mfma_busy = None, None
+    # rocprofv3 --pmc runs, tools/run_profile_r03.sh), not live -- and quoted ONLY when those passes ran on the build that is
+    # running now (the pmc file records ophip_build_stamp): a kernel change without a re-profile prints null, never a stale number
+    traffic, mfma_busy, pmc_note = None, None, None
+    stem = {"bf16x3": "enc_x3w8_kernel<false>", "bf16": "attn_apply_bf16_kernel<1", "f32": "attn_apply_kernel"}[args.precision]
     try:
-        pmc = json.load(open(os.path.join(REPO, "profiles", "r02_pmc.json")))["kernels"]
-        stem = {"bf16x3": "enc_x3w8_kernel<false>" if os.environ.get("OPHIP_ENC_W8", "1") != "0" else "enc_x3_kernel<false>", "bf16": "attn_apply_bf16_kernel<1", "f32": "attn_apply_kernel"}[args.precision]
-        hits = [v for k, v in pmc.items() if k.startswith(stem)]
-        if hits and B == 1 and args.workload == "c2":
-            traffic = hits[0]["hbm_bytes_per_launch"]
-            mfma_busy = hits[0].get("SQ_VALU_MFMA_BUSY_CYCLES_median")
-    except (OSError, KeyError, ValueError):
+        pmc_path = sorted(p for p in os.listdir(os.path.join(REPO, "profiles")) if p.endswith("_pmc.json"))[-1]
+        pmc_all = json.load(open(os.path.join(REPO, "profiles", pmc_path)))
+        if pmc_all.get("library_build_stamp") != hip.build_stamp():
+            pmc_note = f"profiles/{pmc_path} was taken on build {pmc_all.get('library_build_stamp')}, this is {hip.build_stamp()}: not quoted"
+        else:
+            hits = [v for k, v in pmc_all["kernels"].items() if k.startswith(stem)]
+            if hits and B == 1 and args.workload == "c2":
+                traffic = hits[0]["hbm_bytes_per_launch"]
+                mfma_busy = hits[0].get("SQ_VALU_MFMA_BUSY_CYCLES_median")
+                pmc_note = f"profiles/{pmc_path} (build {hip.build_stamp()})"
+    except (OSError, KeyError, ValueError, IndexError):
         pass
 
     frames_total = world * args.steps * B
@@ -418,7 +424,7 @@ def main():
             "host_bound": (pnp_ceiling < (frames_total / dt_matcher if dt_matcher else value)) if pnp_ceiling else None,
         },
         "roofline": {
-            "kernel": {"bf16x3": ("enc_x3w8_kernel<false>" if os.environ.get("OPHIP_ENC_W8", "1") != "0" else "enc_x3_kernel<false>") + " (attn_apply)", "bf16": "attn_apply_bf16_kernel<1, 1>", "f32": "attn_apply_kernel"}[args.precision]
+            "kernel": {"bf16x3": "enc_x3w8_kernel<false> (attn_apply)", "bf16": "attn_apply_bf16_kernel<1, 1>", "f32": "attn_apply_kernel"}[args.precision]
                       + " (fused Q-proj + linear attention + merge + MLP + 2 LayerNorms" + (" + next layer's K/V reduce)" if args.precision != "f32" else ")"),
             "bound": "mfma",
             "achieved": achieved,
@@ -427,9 +433,11 @@ def main():
             "frac": achieved / MFMA_PEAK_TFLOPS[args.precision],
             "mfma_issue_frac": achieved * (3.0 if args.precision == "bf16x3" else 1.0) / MFMA_PEAK_TFLOPS[args.precision],
             "traffic": traffic,
+            "counters_from": pmc_note,
+            "library_build_stamp": hip.build_stamp(),
             # SQ_VALU_MFMA_BUSY_CYCLES of the committed counter pass over (1024 SIMDs x this run's launch time x the 2.4 GHz the
-            # 2.5 PFLOP/s peak is quoted at): the matrix pipe's busy share at PEAK clock; the chip holds ~1.75 GHz in this kernel
-            # (in-kernel s_memtime), where the pipe is busy 46 % of the cycles
+            # 2.5 PFLOP/s peak is quoted at): the matrix pipe's busy share at PEAK clock.  The clock the chip really holds in this
+            # kernel is the in-kernel s_memtime / s_memrealtime ratio in profiles/r03_stamps_enc_x3w8.txt
             "mfma_busy_frac_at_peak_clock": (mfma_busy / (1024.0 * avg_ms * 1e-3 * 2.4e9)) if (mfma_busy and launches) else None,
             "launches": launches,
             "launches_sampled_every": time_every,

@@ -22,6 +22,9 @@ extern "C" {
 #endif
 
 int ophip_abi_version(void);
+/* host string: 16 hex digits of the sha256 over the sources this library was built from (profiles/*_pmc.json record it;
+ * bench.py quotes committed counter values only when they were taken on the running build) */
+const char* ophip_build_stamp(void);
 const char* ophip_last_error(void);
 /* host query: CU count, LDS bytes per block, gcn arch name of the current device */
 int ophip_device_info(int* cu_count, int* lds_per_block, char* arch, int arch_len);

@@ -109,6 +109,10 @@ extern "C" int ophip_debug_stamps(void* device_buffer) { g_stamps = reinterpret_
 
 extern "C" int ophip_abi_version(void) { return 1; }
 
+#include "build/src_hash.h"
+// 16 hex digits of the sha256 over the library's sources (csrc/Makefile): which build produced a measurement
+extern "C" const char* ophip_build_stamp(void) { return OPHIP_SRC_HASH; }
+
 extern "C" const char* ophip_last_error(void) { return g_err; }
 
 extern "C" int ophip_device_info(int* cu_count, int* lds_per_block, char* arch, int arch_len) {

@@ -147,6 +147,7 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
     wsk.open(tail ? a.wkv + (size_t)fwu * KV_FRAGS * 64 : a.wmain, tail ? KV_FRAGS : 0, lane);
     Ring ring;
     OPHIP_STAMP(a.stamps, wg, 0);
+    OPHIP_STAMP_REAL(a.stamps, wg, 30);
 
     // activation rows: 48 x 256 f32, (row, 8-feature chunk) items over 512 threads
     constexpr int ITEMS = TOK * (C / 8) / 512;       // 3
@@ -370,6 +371,7 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
         kv_tail(ring, wsk, XH, XL, tok0, L, slab, fw, lane);
     }
     OPHIP_STAMP(a.stamps, wg, 11);
+    OPHIP_STAMP_REAL(a.stamps, wg, 31);
 }
 
 struct KvSumArgs {
@@ -378,33 +380,42 @@ struct KvSumArgs {
     int tiles[2];
 };
 
-constexpr int KVS_G = 16;
+constexpr int KVS_G = 64;          // tile groups per workgroup: a thread sums tiles g, g + 64, g + 128, ... (<= 3 at c2: all its loads in flight at once)
+constexpr int KVS_L = 16;          // lanes per group: one workgroup reduces 64 consecutive floats (16 x f32x4) of the 8448 of a slab
 
-// identical in function to kv_sum_x3_kernel of encoder_x3.hip (same slab and fragment formats)
+// Sum of a stream's K|V partial slabs in a FIXED order (no float atomics: bit-reproducible) -> KV as (hi, lo) bf16 A-operand
+// fragments + Ksum f32.  Latency-bound: 264 workgroups (every CU busy) whose threads each issue all their loads at once, instead of
+// 66 workgroups looping over the tiles (5.4 -> ~2 us per launch at c2).
 __global__ __launch_bounds__(1024) void kv_sum_w8_kernel(KvSumArgs a) {
-    __shared__ f32x4 red[KVS_G][64];
-    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    __shared__ f32x4 red[KVS_G][KVS_L];
+    const int o = threadIdx.x & (KVS_L - 1), g = threadIdx.x / KVS_L;
     const int s = blockIdx.y & 1, b = blockIdx.y >> 1;
     const int ttot = a.tiles[0] + a.tiles[1];
     const int t0 = s ? a.tiles[0] : 0, nt = a.tiles[s];
-    const int e = (blockIdx.x * 64 + o) * 4;
+    const int e = (blockIdx.x * KVS_L + o) * 4;
     const float* p = a.partial + ((size_t)b * ttot + t0) * KV_PART_FLOATS + e;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     int t = g;
-    for (; t + 3 * KVS_G < nt; t += 4 * KVS_G) {
+    for (; t + 2 * KVS_G < nt; t += 3 * KVS_G) {
         const f32x4 u0 = *reinterpret_cast<const f32x4*>(p + (size_t)t * KV_PART_FLOATS);
         const f32x4 u1 = *reinterpret_cast<const f32x4*>(p + (size_t)(t + KVS_G) * KV_PART_FLOATS);
         const f32x4 u2 = *reinterpret_cast<const f32x4*>(p + (size_t)(t + 2 * KVS_G) * KV_PART_FLOATS);
-        const f32x4 u3 = *reinterpret_cast<const f32x4*>(p + (size_t)(t + 3 * KVS_G) * KV_PART_FLOATS);
-        acc = (((acc + u0) + u1) + u2) + u3;
+        acc = ((acc + u0) + u1) + u2;
     }
     for (; t < nt; t += KVS_G) acc += *reinterpret_cast<const f32x4*>(p + (size_t)t * KV_PART_FLOATS);
     red[g][o] = acc;
     __syncthreads();
+    if (g < 8) {                                   // 64 -> 8 partial sums, each over groups g, g + 8, ... in that order
+        f32x4 tot = red[g][o];
+#pragma unroll
+        for (int k = 1; k < KVS_G / 8; ++k) tot += red[g + 8 * k][o];
+        red[g][o] = tot;
+    }
+    __syncthreads();
     if (g == 0) {
         f32x4 tot = red[0][o];
 #pragma unroll
-        for (int k = 1; k < KVS_G; ++k) tot += red[k][o];
+        for (int k = 1; k < 8; ++k) tot += red[k][o];
         char* blk = a.kv + ((size_t)b * 2 + s) * KV_BLOCK_BYTES;
         if (e < NH * 1024) {
             const int ln = (e >> 2) & 63, vt = (e >> 8) & 1, dt = (e >> 9) & 1, head = e >> 10;
@@ -479,7 +490,8 @@ int layer_x3w8(const float* x3d, const float* x2d, float* y3d, float* y2d, int B
     }
     KvSumArgs sa;
     sa.partial = partial; sa.kv = kv; sa.tiles[0] = t3; sa.tiles[1] = t2;
-    OPHIP_LAUNCH("kv_sum", stream, kv_sum_w8_kernel, dim3(KV_PART_FLOATS / 256, 2 * B), dim3(1024), 0, stream, sa);
+    static_assert(KV_PART_FLOATS % (4 * KVS_L) == 0, "a slab is a whole number of 64-float chunks");
+    OPHIP_LAUNCH("kv_sum", stream, kv_sum_w8_kernel, dim3(KV_PART_FLOATS / (4 * KVS_L), 2 * B), dim3(KVS_G * KVS_L), 0, stream, sa);
     OPHIP_CHECK_LAUNCH();
     aa.kv[0] = kv + (is_cross ? KV_BLOCK_BYTES : 0);
     aa.kv[1] = kv + (is_cross ? 0 : KV_BLOCK_BYTES);

@@ -398,6 +398,405 @@ __global__ __launch_bounds__(NM * 256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_refi
     OPHIP_STAMP(p.stamps, blockIdx.x, 31);
 }
 
+// a copy of v the compiler cannot see through: what is computed from it stays where it is used instead of joining the caller's
+// loop invariants (and their live ranges)
+__device__ __forceinline__ int opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// LayerNorm over the 128 features of the tokens of BOTH matches of a pair workgroup (wave ft holds features 32 ft .. 32 ft + 31
+// of tokens 0 .. 63 as two D[feature][token] accumulators).  Two-pass; `scratch` = [2][4][64] floats of its own.  2 barriers.
+__device__ __forceinline__ void layernorm_pair(f32x16 (&m)[1][2], const float* __restrict__ gamma, const float* __restrict__ beta,
+                                               float* scratch, int ft, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        float s = 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) s += m[0][tt][reg];
+        s += __shfl_xor(s, 32, 64);
+        if (h == 0) scratch[ft * 64 + 32 * tt + r] = s;
+    }
+    __syncthreads();
+    float mean[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int tok = 32 * tt + r;
+        mean[tt] = ((scratch[tok] + scratch[64 + tok]) + (scratch[128 + tok] + scratch[192 + tok])) * (1.0f / CF);
+        float q = 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const float d = m[0][tt][reg] - mean[tt];
+            q += d * d;
+        }
+        q += __shfl_xor(q, 32, 64);
+        if (h == 0) scratch[256 + ft * 64 + tok] = q;
+    }
+    __syncthreads();
+    f32x4 gv[4], bv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int f0 = 32 * ft + 8 * g + 4 * h;
+        gv[g] = *reinterpret_cast<const f32x4*>(gamma + f0);
+        bv[g] = *reinterpret_cast<const f32x4*>(beta + f0);
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int tok = 32 * tt + r;
+        const float var = ((scratch[256 + tok] + scratch[320 + tok]) + (scratch[384 + tok] + scratch[448 + tok])) * (1.0f / CF);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[0][tt][4 * g + j] = (m[0][tt][4 * g + j] - mean[tt]) * rstd * gv[g][j] + bv[g][j];
+    }
+}
+
+// TWO matches per 4-wave workgroup, sharing every weight fragment: wave ft owns feature tile ft of BOTH matches (token tiles
+// tt = 0, 1 of 64-row planes), so a fragment pulled from L2 feeds two matrix instructions and the layers' 1.3 MB of (hi, lo)
+// weights cross the L2 -> CU path once per two matches (one-match workgroups: 3.9 GB of L2 reads per frame at K = 2 975, which is
+// what bounded the stage, profiles/r03_fine_*).  LDS stays at 66 KiB per workgroup -- two workgroups per CU as before -- because the
+// hidden planes OVERLAY the X and Y planes: relu(hidden) is held in registers until every wave is done reading [x, msg], then
+// written over them; the residual stream lives in f32 registers, the next layer's X planes are rewritten from it.
+//   LDS map: [X hi | X lo] 32 KiB, [Y hi | Y lo] 32 KiB (= hidden planes 64 KiB; f32 staging image in the Y half), 2 KiB LayerNorm scratch
+template <int NS>
+__global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_pair_kernel(FineBArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PL = NS == 3 ? 2 : 1;
+    constexpr int TOK = 64, NT_ = 256;
+    constexpr int XB = TOK * ROWB, HB = TOK * HROWB;   // per plane: 16 KiB, 32 KiB
+    // (the same 66 KiB map in plain-bf16 mode, whose lo planes stay unused: the f32 staging image needs its 32 KiB either way)
+    char* XH = smem;
+    char* XL = smem + XB;
+    char* YH = smem + 2 * XB;
+    char* YL = YH + XB;
+    char* HH = smem;                                    // overlays X and Y
+    char* HL = HH + HB;
+    char* stage = YH;                                   // f32 [64][128] = 32 KiB: the Y half, while Y is idle
+    float* scratch = reinterpret_cast<float*>(smem + 4 * XB);
+    static_assert(PL == 1 || PL == 2, "one or two planes");
+    const int k0 = 2 * blockIdx.x;
+    const int total = *p.count;
+    if (k0 >= total) return;
+    const int tid = threadIdx.x, lane = tid & 63, ft = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    OPHIP_STAMP(p.stamps, blockIdx.x, 0);
+
+    const int nl = p.enc_enable ? p.nlayers : 0;
+    constexpr size_t LAYER_BYTES = (size_t)2 * W_ELEMS * 2 + 4 * CF * 4;
+    constexpr int OQ = 0, OKV = CF * CF / 8, OM = 3 * CF * CF / 8, O0 = 4 * CF * CF / 8, O2 = 8 * CF * CF / 8;
+    WRing<1, 2, NS> rq;
+    WRing<2, 2, NS> rkv;
+    if (nl > 0) {
+        const bf16x8* w_hi = reinterpret_cast<const bf16x8*>(p.wpack);
+        const bf16x8* w_lo = w_hi + W_ELEMS / 8;
+        rq.fill(w_hi + OQ + (size_t)ft * TS + lane, w_lo + OQ + (size_t)ft * TS + lane, TS);
+        rkv.fill(w_hi + OKV + (size_t)(2 * ft) * TS + lane, w_lo + OKV + (size_t)(2 * ft) * TS + lane, TS);
+    }
+
+    // ---- gather both matches into the f32 staging image (all loads issued before the first LDS write) -------------------
+    const bool live1 = k0 + 1 < total;
+    const int b0 = (int)p.b_ids[k0], i30 = (int)p.i_ids[k0], j0 = (int)p.j_ids[k0];
+    const int b1 = live1 ? (int)p.b_ids[k0 + 1] : 0, i31 = live1 ? (int)p.i_ids[k0 + 1] : 0, j1 = live1 ? (int)p.j_ids[k0 + 1] : 0;
+    const int cy0 = p.stride * (j0 / p.wc), cx0 = p.stride * (j0 % p.wc);
+    const int cy1 = p.stride * (j1 / p.wc), cx1 = p.stride * (j1 % p.wc);
+#define PLIVE(mi) ((mi) ? live1 : true)
+#define PB(mi) ((mi) ? b1 : b0)
+#define PI3(mi) ((mi) ? i31 : i30)
+#define PCY(mi) ((mi) ? cy1 : cy0)
+#define PCX(mi) ((mi) ? cx1 : cx0)
+    if (p.fs_c == 1) {
+        constexpr int NQ = 2 * WIN * (CF / 4), PER = (NQ + NT_ - 1) / NT_;
+        f32x4 v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = tid + NT_ * u;
+            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (e < NQ) {
+                const int mi = e / (WIN * (CF / 4)), e2 = e % (WIN * (CF / 4)), rr = e2 >> 5, c4 = e2 & 31;
+                const int y = PCY(mi) + rr / 5 - 2, x = PCX(mi) + rr % 5 - 2;
+                if (PLIVE(mi) && y >= 0 && y < p.hf && x >= 0 && x < p.wf)
+                    v[u] = *reinterpret_cast<const f32x4*>(p.feat_f + (size_t)PB(mi) * p.fs_b + (size_t)y * p.fs_y + (size_t)x * p.fs_x + 4 * c4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = tid + NT_ * u;
+            if (e < NQ) {
+                const int mi = e / (WIN * (CF / 4)), e2 = e % (WIN * (CF / 4)), rr = e2 >> 5, c4 = e2 & 31;
+                *reinterpret_cast<f32x4*>(stage + stage_off(32 * mi + rr, c4)) = v[u];
+            }
+        }
+    } else {
+        constexpr int RUNS = 2 * CF * 5, PER = (RUNS + NT_ - 1) / NT_;
+        float v[PER][5];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int q = tid + NT_ * u;
+            const int mi = q / (CF * 5), q2 = q % (CF * 5), c = q2 / 5, ky = q2 % 5;
+            const bool ok = q < RUNS && PLIVE(mi);
+            const int y = PCY(mi) + ky - 2;
+            const bool yin = ok && y >= 0 && y < p.hf;
+            const float* src = p.feat_f + (size_t)PB(mi) * p.fs_b + (size_t)c * p.fs_c + (size_t)(yin ? y : 0) * p.fs_y;
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) {
+                const int x = PCX(mi) + kx - 2;
+                v[u][kx] = (yin && x >= 0 && x < p.wf) ? src[(size_t)x * p.fs_x] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int q = tid + NT_ * u;
+            if (q < RUNS) {
+                const int mi = q / (CF * 5), q2 = q % (CF * 5), c = q2 / 5, ky = q2 % 5;
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx)
+                    *reinterpret_cast<float*>(stage + stage_off(32 * mi + ky * 5 + kx, c >> 2) + 4 * (c & 3)) = v[u][kx];
+            }
+        }
+    }
+    {                                   // the 3D fine descriptor (row 25) of both matches: 2 x 128 values = one per thread
+        const int mi = tid >> 7, c = tid & 127;
+        const float v = PLIVE(mi) ? p.desc_f[(size_t)PB(mi) * p.ds_b + (size_t)c * p.ds_c + PI3(mi)] : 0.f;
+        *reinterpret_cast<float*>(stage + stage_off(32 * mi + TOK3D, c >> 2) + 4 * (c & 3)) = v;
+    }
+    for (int e = tid; e < 2 * 6 * CF; e += NT_) {       // padding rows 26..31
+        const int mi = e / (6 * CF), e2 = e % (6 * CF), rr = 26 + (e2 >> 7), c = e2 & 127;
+        *reinterpret_cast<float*>(stage + stage_off(32 * mi + rr, c >> 2) + 4 * (c & 3)) = 0.f;
+    }
+#undef PLIVE
+#undef PB
+#undef PI3
+#undef PCY
+#undef PCX
+    __syncthreads();
+    OPHIP_STAMP(p.stamps, blockIdx.x, 1);
+    // residual stream in registers, D[feature][token] layout: this wave's 32 features of the 32 tokens of each match
+    f32x16 xres[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stage + stage_off(32 * tt + r, 8 * ft + 2 * g + h));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xres[tt][4 * g + j] = v[j];
+        }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) store_featrow_acc<NS>(xres[tt], XH, XL, ROWB, 32 * ft, 32 * tt, lane);      // X region: disjoint from the staging image
+    __syncthreads();
+
+    const bf16x8 zeros = zero_bf8();
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+
+    for (int l = 0; l < nl; ++l) {
+        const char* wl = p.wpack + (size_t)l * LAYER_BYTES;
+        const bf16x8* w_hi = reinterpret_cast<const bf16x8*>(wl);
+        const bf16x8* w_lo = w_hi + W_ELEMS / 8;
+        const float* ln = reinterpret_cast<const float*>(wl + (size_t)2 * W_ELEMS * 2);
+        const bool cross = (p.cross_bits >> l) & 1u;
+
+        // ---- phase 1: Q (D[feature][token]) of both matches from X with shared weight fragments; K, V (D[token][feature]) one
+        //      match at a time (their accumulators + the attention block's tiles of two matches at once do not fit 256 registers:
+        //      87 spilled; the K|V fifth of the weights is therefore read once per match, the other four fifths once per pair) ----
+        // (per-lane weight pointers are formed from an opaque copy of the lane index phase by phase: as loop invariants of the layer loop
+        //  they would all stay live across the whole layer)
+        f32x16 q[1][2] = {{zero16(), zero16()}};
+        {
+            const int ln_ = opaque(lane);
+            gemm_bf16_ring<1, 2, NS, true, KB, 2>(q, rq, w_hi + OQ + (size_t)ft * TS + ln_, w_lo + OQ + (size_t)ft * TS + ln_, TS, XH, XL, ROWB, 0, lane);
+        }
+        OPHIP_STAMP(p.stamps, blockIdx.x, 2 + 8 * l);
+        // ---- KV / Ksum of the two source sets and phi(Q) KV per match, all in registers -----------------------------------
+        const bool is3d = r == TOK3D;                 // on the token (lane) axis of D[feature][token] tiles
+        const bool use_w = cross ? is3d : !is3d;      // this token attends to the window set (else: the 3D token)
+        auto f_kw = [&](int reg, float v) { return acc_row(reg, h) < WIN ? elu_plus_one_fast(v) : 0.f; };
+        auto f_k3 = [&](int reg, float v) { return acc_row(reg, h) == TOK3D ? elu_plus_one_fast(v) : 0.f; };
+        auto f_vs = [&](int reg, float v) {
+            const int row = acc_row(reg, h);
+            return row < WIN ? v * 0.04f : (row == TOK3D ? v : 0.f);
+        };
+        const auto block_diag = [&](f32x16& t) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                if ((acc_row(reg, h) >> 4) != (r >> 4)) t[reg] = 0.f;
+        };
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            f32x16 kv_[2][1] = {{zero16()}, {zero16()}};
+            const int lk_ = opaque(lane);
+            gemm_bf16_ring<2, 1, NS, false, KB, 2>(kv_, rkv, w_hi + OKV + (size_t)(2 * ft) * TS + lk_, w_lo + OKV + (size_t)(2 * ft) * TS + lk_, TS,
+                                                   XH + 32 * tt * ROWB, XL + 32 * tt * ROWB, ROWB, 0, lane);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) q[0][tt][reg] = elu_plus_one_fast(q[0][tt][reg]);
+            f32x16 num = zero16(), den = zero16();
+            {
+                f32x16 kvw = zero16(), ksw = zero16();
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    bf16x8 wh, wl2, vh, vl;
+                    acc_frag_map<NS>(kv_[0][0], st, f_kw, wh, wl2);
+                    acc_frag_map<NS>(kv_[1][0], st, f_vs, vh, vl);
+                    kvw = mma_bf16<NS>(wh, wl2, vh, vl, kvw);
+                    ksw = mma_bf16<NS>(wh, wl2, ones, zeros, ksw);
+                }
+                block_diag(kvw);
+                block_diag(ksw);
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    bf16x8 qh, ql, ah, al;
+                    acc_frag<NS>(q[0][tt], st, qh, ql);
+                    const bf16x8 qwh = select_frag(use_w, qh, zeros), qwl = select_frag(use_w, ql, zeros);
+                    acc_frag<NS>(kvw, st, ah, al); num = mma_bf16<NS>(ah, al, qwh, qwl, num);
+                    acc_frag<NS>(ksw, st, ah, al); den = mma_bf16<NS>(ah, al, qwh, qwl, den);
+                }
+            }
+            {
+                f32x16 kv3 = zero16(), ks3 = zero16();
+                bf16x8 th, tl, vh, vl;
+                acc_frag_map<NS>(kv_[0][0], 1, f_k3, th, tl);
+                acc_frag_map<NS>(kv_[1][0], 1, f_vs, vh, vl);
+                kv3 = mma_bf16<NS>(th, tl, vh, vl, kv3);
+                ks3 = mma_bf16<NS>(th, tl, ones, zeros, ks3);
+                block_diag(kv3);
+                block_diag(ks3);
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    bf16x8 qh, ql, ah, al;
+                    acc_frag<NS>(q[0][tt], st, qh, ql);
+                    const bf16x8 q3h = select_frag(!use_w, qh, zeros), q3l = select_frag(!use_w, ql, zeros);
+                    acc_frag<NS>(kv3, st, ah, al); num = mma_bf16<NS>(ah, al, q3h, q3l, num);
+                    acc_frag<NS>(ks3, st, ah, al); den = mma_bf16<NS>(ah, al, q3h, q3l, den);
+                }
+            }
+            const float S = use_w ? 25.0f : 1.0f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) num[reg] = num[reg] * rcp_fast(den[reg] + 1e-6f) * S;
+            store_featrow_acc<NS>(num, YH, YL, ROWB, 32 * ft, 32 * tt, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tt == 0) rkv.fill(w_hi + OKV + (size_t)(2 * ft) * TS + lk_, w_lo + OKV + (size_t)(2 * ft) * TS + lk_, TS);      // the second match's K|V weights
+        }
+        WRing<1, 2, NS> rm;                      // merge weights travel under the barrier
+        const int lm_ = opaque(lane);
+        rm.fill(w_hi + OM + (size_t)ft * TS + lm_, w_lo + OM + (size_t)ft * TS + lm_, TS);
+        __syncthreads();
+        OPHIP_STAMP(p.stamps, blockIdx.x, 3 + 8 * l);
+        // ---- phase 2: merge + LN1 -> Y -----------------------------------------------------------------
+        WRing<2, 2, NS> r0;                      // MLP-up weights (hidden tiles 2 ft, 2 ft + 1)
+        {
+            f32x16 m[1][2] = {{zero16(), zero16()}};
+            gemm_bf16_ring<1, 2, NS, true, KB, 2>(m, rm, w_hi + OM + (size_t)ft * TS + lm_, w_lo + OM + (size_t)ft * TS + lm_, TS, YH, YL, ROWB, 0, lane);
+            const int l0_ = opaque(lane);
+            r0.fill(w_hi + O0 + (size_t)(2 * ft) * TS2 + l0_, w_lo + O0 + (size_t)(2 * ft) * TS2 + l0_, TS2);
+            OPHIP_STAMP(p.stamps, blockIdx.x, 4 + 8 * l);
+            layernorm_pair(m, ln, ln + CF, scratch, ft, lane);           // its first barrier also fences the reads of Y above
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) store_featrow_acc<NS>(m[0][tt], YH, YL, ROWB, 32 * ft, 32 * tt, lane);
+        }
+        __syncthreads();
+        OPHIP_STAMP(p.stamps, blockIdx.x, 5 + 8 * l);
+        // ---- phase 3: hidden = relu([x, msg] W0^T), kept in registers until every wave has read X and Y, then written OVER them ----
+        WRing<1, 2, NS> r2;
+        {
+            f32x16 hd[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
+            const int l0_ = opaque(lane);
+            gemm_bf16_ring_cat<2, 2, NS, KB2, 2>(hd, r0, w_hi + O0 + (size_t)(2 * ft) * TS2 + l0_, w_lo + O0 + (size_t)(2 * ft) * TS2 + l0_, TS2,
+                                                 XH, XL, YH, YL, ROWB, lane);
+            r2.fill(w_hi + O2 + (size_t)ft * TS2 + l0_, w_lo + O2 + (size_t)ft * TS2 + l0_, TS2);
+            OPHIP_STAMP(p.stamps, blockIdx.x, 6 + 8 * l);
+            __syncthreads();                         // X and Y are dead from here to the end of the layer
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) hd[t][tt][reg] = fmaxf(hd[t][tt][reg], 0.f);
+                    store_featrow_acc<NS>(hd[t][tt], HH, HL, HROWB, 64 * ft + 32 * t, 32 * tt, lane);
+                }
+        }
+        __syncthreads();
+        OPHIP_STAMP(p.stamps, blockIdx.x, 7 + 8 * l);
+        // ---- phase 4: o = hidden W2^T, LN2, residual ------------------------------------------------------
+        f32x16 o[1][2] = {{zero16(), zero16()}};
+        {
+            const int l2_ = opaque(lane);
+            gemm_bf16_ring<1, 2, NS, true, KB2, 2>(o, r2, w_hi + O2 + (size_t)ft * TS2 + l2_, w_lo + O2 + (size_t)ft * TS2 + l2_, TS2, HH, HL, HROWB, 0, lane);
+        }
+        OPHIP_STAMP(p.stamps, blockIdx.x, 8 + 8 * l);
+        if (l + 1 < nl) {                        // next layer's first weights travel during LN2 and the plane rewrite
+            const bf16x8* n_hi = reinterpret_cast<const bf16x8*>(wl + LAYER_BYTES);
+            const bf16x8* n_lo = n_hi + W_ELEMS / 8;
+            const int ln_ = opaque(lane);
+            rq.fill(n_hi + OQ + (size_t)ft * TS + ln_, n_lo + OQ + (size_t)ft * TS + ln_, TS);
+            rkv.fill(n_hi + OKV + (size_t)(2 * ft) * TS + ln_, n_lo + OKV + (size_t)(2 * ft) * TS + ln_, TS);
+        }
+        layernorm_pair(o, ln + 2 * CF, ln + 3 * CF, scratch, ft, lane);  // its first barrier: every wave is done reading the hidden planes
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) xres[tt][reg] += o[0][tt][reg];
+            if (l + 1 < nl) store_featrow_acc<NS>(xres[tt], XH, XL, ROWB, 32 * ft, 32 * tt, lane);
+        }
+        __syncthreads();
+        OPHIP_STAMP(p.stamps, blockIdx.x, 9 + 8 * l);
+    }
+
+    // ---- final f32 features to the staging image (Y half: idle), then correlation -> softmax -> expectation -------------------
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = {xres[tt][4 * g], xres[tt][4 * g + 1], xres[tt][4 * g + 2], xres[tt][4 * g + 3]};
+            *reinterpret_cast<f32x4*>(stage + stage_off(32 * tt + r, 8 * ft + 2 * g + h)) = v;
+        }
+    __syncthreads();
+    if (p.dbg_win) {
+        for (int mi = 0; mi < 2; ++mi) {
+            const int k = k0 + mi;
+            if (k >= total) break;
+            for (int e = tid; e < WIN * CF; e += NT_) {
+                const int rr = e >> 7, c = e & 127;
+                p.dbg_win[(size_t)k * WIN * CF + e] = *reinterpret_cast<const float*>(stage + stage_off(32 * mi + rr, c >> 2) + 4 * (c & 3));
+            }
+            if (tid < CF) p.dbg_f3[(size_t)k * CF + tid] = *reinterpret_cast<const float*>(stage + stage_off(32 * mi + TOK3D, tid >> 2) + 4 * (tid & 3));
+        }
+    }
+    if (ft < 2 && k0 + ft < total) {             // wave 0 finishes match k0, wave 1 match k0 + 1
+        const int k = k0 + ft, base = 32 * ft;
+        float t = -INFINITY;
+        if (lane < WIN) {
+            float dot = 0.f;
+            for (int c4 = 0; c4 < CF / 4; ++c4) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(stage + stage_off(base + TOK3D, c4));
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(stage + stage_off(base + lane, c4));
+                dot += a[0] * bq[0];
+                dot += a[1] * bq[1];
+                dot += a[2] * bq[2];
+                dot += a[3] * bq[3];
+            }
+            t = dot * 0.08838834764831845f;              // 1 / sqrt(128)
+        }
+        const float m = wave_max(t);
+        const float e = lane < WIN ? expf(t - m) : 0.f;
+        const float sum = wave_sum(e);
+        const float pr = e / sum;
+        const float gx = (float)(lane % 5 - 2) * 0.5f, gy = (float)(lane / 5 - 2) * 0.5f;
+        const float ex = wave_sum(pr * gx), ey = wave_sum(pr * gy);
+        const float ex2 = wave_sum(pr * gx * gx), ey2 = wave_sum(pr * gy * gy);
+        if (lane == 0) {
+            const float vx = ex2 - ex * ex, vy = ey2 - ey * ey;
+            const float sd = sqrtf(fmaxf(vx, 1e-10f)) + sqrtf(fmaxf(vy, 1e-10f));
+            p.expec_f[3 * k] = ex; p.expec_f[3 * k + 1] = ey; p.expec_f[3 * k + 2] = sd;
+            p.mkq_f[2 * k] = p.mkq_c[2 * k] + ex * p.fine_scale;
+            p.mkq_f[2 * k + 1] = p.mkq_c[2 * k + 1] + ey * p.fine_scale;
+        }
+    }
+    OPHIP_STAMP(p.stamps, blockIdx.x, 31);
+}
+
 template <typename K>
 int set_lds(K kernel, size_t bytes, const char* what) {
     return ophip_lds_attr(reinterpret_cast<const void*>(kernel), bytes, what);
@@ -430,7 +829,21 @@ extern "C" int ophip_fine_refine_bf16(const float* feat_f, long long fs_b, long 
     a.expec_f = expec_f; a.mkq_f = mkpts_f; a.dbg_win = dbg_win; a.dbg_f3 = dbg_f3;
     a.stamps = ophip_stamp_buffer();
     hipStream_t stream = (hipStream_t)stream_;
-    // one match per 4-wave workgroup, two independent workgroups per CU
+    // two matches per 4-wave workgroup sharing every weight fragment (fine_pair_kernel); OPHIP_FINE_PAIR=0: one match per workgroup
+    static const bool pair = [] { const char* e = getenv("OPHIP_FINE_PAIR"); return !(e && e[0] == '0'); }();
+    if (pair) {
+        const int gridp = (max_matches + 1) / 2;
+        const size_t ldsp = (size_t)64 * 1024 + 2048;
+        if (nsplit == 3) {
+            if (int rc = set_lds(fine_pair_kernel<3>, ldsp, "hipFuncSetAttribute(fine_pair)")) return rc;
+            OPHIP_LAUNCH("fine_refine", stream, (fine_pair_kernel<3>), dim3(gridp), dim3(256), ldsp, stream, a);
+        } else {
+            if (int rc = set_lds(fine_pair_kernel<1>, ldsp, "hipFuncSetAttribute(fine_pair)")) return rc;
+            OPHIP_LAUNCH("fine_refine", stream, (fine_pair_kernel<1>), dim3(gridp), dim3(256), ldsp, stream, a);
+        }
+        OPHIP_CHECK_LAUNCH();
+        return 0;
+    }
     constexpr int NM = 1;
     const int grid = (max_matches + NM - 1) / NM;
     const size_t lds = (size_t)NM * (nsplit == 3 ? (16 + 16 + 32) : (8 + 8 + 16)) * 1024;

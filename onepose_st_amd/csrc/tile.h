@@ -174,3 +174,9 @@ extern "C" unsigned long long* ophip_stamp_buffer(void);
     do {                                                                                  \
         if ((buf) && threadIdx.x == 0) (buf)[(size_t)(wg) * 32 + (slot)] = __builtin_readcyclecounter(); \
     } while (0)
+// the constant 100 MHz counter (s_memrealtime) beside a cycle stamp: delta(s_memtime) / delta(s_memrealtime) x 100 MHz is the
+// clock the chip holds inside the kernel (MI355X_MICROARCH.md, "DVFS give-back" item 6)
+#define OPHIP_STAMP_REAL(buf, wg, slot)                                                   \
+    do {                                                                                  \
+        if ((buf) && threadIdx.x == 0) (buf)[(size_t)(wg) * 32 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)

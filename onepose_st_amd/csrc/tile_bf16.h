@@ -115,9 +115,14 @@ __device__ __forceinline__ void gemm_bf16_ring(f32x16 (&acc)[NT][TT], WRing<NT, 
     // runs under the MFMAs of k-block kb even with a single wave on the SIMD
     bf16x8 x_hi[2][TT], x_lo[2][TT];
     auto read_x = [&](int kb, int set) {
+        // The swizzled offsets are loop invariants of the caller's layer loop: hoisted out of it, the offsets of every k-block of every
+        // GEMM stage stay live across the whole layer (~100 registers in the fine kernels; 87-187 spilled in the two-match form).
+        // An opaque copy of the lane's row keeps each offset next to its read: 3 vector-ALU instructions per read, beside 3-12 MFMAs.
+        int rr = r;
+        asm volatile("" : "+v"(rr));
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) {
-            const int off = plane_off(32 * tt + r, chunk0 + 2 * kb + h, rowb, swz);
+            const int off = plane_off(32 * tt + rr, chunk0 + 2 * kb + h, rowb, swz);
             x_hi[set][tt] = *reinterpret_cast<const bf16x8*>(act_hi + off);
             x_lo[set][tt] = (NS == 3) ? *reinterpret_cast<const bf16x8*>(act_lo + off) : zero_bf8();
         }
@@ -162,9 +167,11 @@ __device__ __forceinline__ void gemm_bf16_ring_cat(f32x16 (&acc)[NT][TT], WRing<
         const char* s_hi = second ? b_hi : a_hi;
         const char* s_lo = second ? b_lo : a_lo;
         const int kk = second ? kb - KBLOCKS / 2 : kb;
+        int rr = r;                              // (see gemm_bf16_ring: keeps the offset out of the caller's loop-invariant set)
+        asm volatile("" : "+v"(rr));
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) {
-            const int off = plane_off(32 * tt + r, 2 * kk + h, rowb);
+            const int off = plane_off(32 * tt + rr, 2 * kk + h, rowb);
             x_hi[set][tt] = *reinterpret_cast<const bf16x8*>(s_hi + off);
             x_lo[set][tt] = (NS == 3) ? *reinterpret_cast<const bf16x8*>(s_lo + off) : zero_bf8();
         }

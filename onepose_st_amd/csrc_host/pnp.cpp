@@ -765,7 +765,9 @@ struct Candidate {
 
 struct Ransac {
     Problem P;
-    FastPoints F;
+    FastPoints F;                    // float copy in the caller's order: what chunk 0 scores
+    FastPoints G;                    // the same points, those chunk 0's best pose rejects FIRST: what every later chunk scores
+    bool reordered = false;
     double K[9];
     double thr2 = 0, confidence = 0.99;
     int n = 0, min_iters = 0, max_iters = 0;
@@ -797,6 +799,14 @@ struct Ransac {
     }
     int full_chunks() const { return (min_iters < max_iters ? min_iters : max_iters) / CH; }
 
+    // The scorer drops a hypothesis as soon as it can no longer beat the best one, and a hypothesis that is about as good as the
+    // best can only be dropped once it has met the outliers (its count can then no longer exceed the best's and the cost decides).
+    // Scored in the caller's order that takes most of the list; with the points chunk 0's best pose rejects moved to the front it
+    // takes a block or two.  The order of evaluation does not change a hypothesis' count or (up to float rounding of the screening
+    // sum) its cost, and it is a function of the data only (chunk 0 always runs first, alone): results stay independent of the
+    // thread count.
+    void reorder_after_chunk0(const Candidate& c0);
+
     int needed_for(int cnt) const {
         const double w = (double)cnt / n, pw = std::pow(w, (double)sample_size());
         if (pw > 1.0 - 1e-12) return 1;
@@ -810,6 +820,7 @@ struct Ransac {
     // (fixed by the data, so the result does not depend on scheduling), out: this chunk's best float score
     int run_chunk(int chunk, int limit, int floor_in_chunk, Candidate& best, FloatBound& bound) const {
         Rng rng(seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(chunk + 1));
+        const FastPoints& FS = (chunk > 0 && reordered) ? G : F;
         std::vector<unsigned char> mask((size_t)n);
         int& best_cnt_f = bound.cnt;
         float& best_cost_f = bound.cost;
@@ -826,7 +837,7 @@ struct Ransac {
             }
             float cost_f;
             int cnt_f;
-            if (!score_fast(F, kp, (float)thr2, best_cnt_f, best_cost_f, &cnt_f, &cost_f)) return;
+            if (!score_fast(FS, kp, (float)thr2, best_cnt_f, best_cost_f, &cnt_f, &cost_f)) return;
             if (cnt_f < best_cnt_f || (cnt_f == best_cnt_f && !(cost_f < best_cost_f))) return;
             best_cnt_f = cnt_f; best_cost_f = cost_f;
             // a new best of this chunk by the float score: its exact (double) count, cost and mask decide what is kept
@@ -947,6 +958,19 @@ struct Ransac {
     }
 };
 
+void Ransac::reorder_after_chunk0(const Candidate& c0) {
+    if (c0.cnt <= 0 || (int)c0.mask.size() != n || c0.cnt == n) return;
+    G.n = n; G.x.resize(n); G.y.resize(n); G.z.resize(n); G.u.resize(n); G.v.resize(n);
+    int k = 0;
+    for (int pass = 0; pass < 2; ++pass)                  // the rejected points first, both groups in their original order
+        for (int i = 0; i < n; ++i)
+            if ((c0.mask[i] != 0) == (pass == 1)) {
+                G.x[k] = F.x[i]; G.y[k] = F.y[i]; G.z[k] = F.z[i]; G.u[k] = F.u[i]; G.v[k] = F.v[i];
+                ++k;
+            }
+    reordered = true;
+}
+
 const double kIdentPose[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
 
 }  // namespace
@@ -977,6 +1001,7 @@ extern "C" int oppnp_ransac(const double* K, const float* pts2d, const float* pt
         Candidate local;
         FloatBound b = b0;
         R.run_chunk(c, CH, CH, local, c == 0 ? b0 : b);
+        if (c == 0) R.reorder_after_chunk0(local);
         if (local.better_than(best)) best = std::move(local);
     }
     R.run_tail(best, b0, iters_run);
@@ -1051,6 +1076,7 @@ struct Pool {
             if (task.second < 0) { finish_job(job); continue; }
             if (task.second == 0) {                  // chunk 0 first, alone: its float best then bounds the others, which start now
                 job.R.run_chunk(0, CH, CH, job.chunk_best[0], job.b0);
+                job.R.reorder_after_chunk0(job.chunk_best[0]);          // before any other chunk of this job exists
                 const int nfull = (int)job.chunk_best.size();
                 if (nfull > 1) {
                     {

@@ -40,6 +40,7 @@ class FrameLayout(ctypes.Structure):
 
 _SIGNATURES = {
     "ophip_abi_version": (c_i, []),
+    "ophip_build_stamp": (ctypes.c_char_p, []),
     "ophip_last_error": (ctypes.c_char_p, []),
     "ophip_device_info": (c_i, [ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.c_char_p, c_i]),
     "ophip_timing_select": (c_i, [ctypes.c_char_p]),
@@ -140,6 +141,11 @@ def stream_handle():
 def call(name: str, *args):
     rc = getattr(load(), name)(*args)
     _check(rc, name)
+
+
+def build_stamp() -> str:
+    """16 hex digits identifying the sources ``libonepose_hip.so`` was built from (``ophip_build_stamp``)."""
+    return load().ophip_build_stamp().decode()
 
 
 def device_info() -> dict:

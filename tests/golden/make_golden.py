@@ -237,6 +237,38 @@ def main():
     print("case full-forward: K =", int(g["K"][0]), {k: tuple(data[k].shape) for k in ("expec_f", "mkpts_query_f")})
     np.savez_compressed(os.path.join(HERE, "full_forward_empty.npz"), **g)
 
+    # ---- case D: full forward incl. backbone WITH matches: the reference's own backbone runs on a synthetic image and a forward
+    #      hook adds the planted feature maps to its two outputs (a random image alone matches nothing) --------------------------------
+    gi = torch.Generator().manual_seed(6)
+    inp = make_synthetic_inputs(sd, n_points=500, image_hw=(128, 160), n_plant=180, seed=7, config=cfg)
+    img = torch.rand(1, 1, 128, 160, generator=gi)
+    data = {"query_image": img, "keypoints3d": inp["keypoints3d"], "descriptors3d_db": inp["descriptors3d_db"],
+            "descriptors3d_coarse_db": inp["descriptors3d_coarse_db"]}
+    feats = []
+
+    def plant(m, i, o):
+        feats.extend(t.detach().clone() for t in o)
+        return [o[0] + inp["feat_c"], o[1] + inp["feat_f"]]
+    h = model.backbone.register_forward_hook(plant)
+    with torch.no_grad():
+        model(data)
+    h.remove()
+    conf = data["conf_matrix"]
+    g = {"image_cs": checksum(img), "feat_c_cs": checksum(feats[0]), "feat_f_cs": checksum(feats[1]),
+         "delta_c_cs": checksum(inp["feat_c"]), "delta_f_cs": checksum(inp["feat_f"]),
+         "conf_cs": checksum(conf), "conf_rowmax": conf.max(dim=2)[0][0].numpy(), "conf_colmax": conf.max(dim=1)[0][0].numpy(),
+         "planted_i": inp["planted_i"].numpy().astype(np.int32), "planted_j": inp["planted_j"].numpy().astype(np.int32),
+         "pose_gt": inp["pose_gt"].numpy(), "K": inp["K"].numpy()}
+    for k in ("b_ids", "i_ids", "j_ids", "m_bids"):
+        g[k] = data[k].numpy().astype(np.int32)
+    for k in ("mconf", "mkpts_3d_db", "mkpts_query_c", "expec_f", "mkpts_query_f"):
+        g[k] = data[k].numpy().astype(np.float32)
+    mc = g["mconf"]
+    print("case full-forward planted: K =", len(g["i_ids"]), "planted =", len(g["planted_i"]),
+          "min |mconf - thr| =", float(np.abs(mc - 0.1).min()) if len(mc) else None,
+          "row maxima within 1e-3 of thr:", int((np.abs(g["conf_rowmax"] - 0.1) < 1e-3).sum()))
+    np.savez_compressed(os.path.join(HERE, "full_forward_planted.npz"), **g)
+
 
 if __name__ == "__main__":
     main()

@@ -355,6 +355,57 @@ def test_coarse_match_tie_and_border_semantics(dev):
     assert torch.equal(mkc.cpu(), ref["mkpts_query_c"])
 
 
+def test_fine_pair_kernel_is_bit_identical_to_the_one_match_kernel(sd, dev):
+    """fine_pair_kernel (two matches per workgroup, shared weight fragments, hidden planes overlaid on X / Y) runs the same arithmetic
+    per match as the one-match kernel it replaces: outputs bit for bit, at an odd match count (the last workgroup holds one match),
+    NCHW and channels-last maps, both bf16 modes.  The one-match kernel stays reachable through OPHIP_FINE_PAIR=0 for this test."""
+    import subprocess, sys, json, tempfile
+    code = r'''
+import ctypes, os, sys, torch, hashlib, json
+sys.path.insert(0, os.getcwd())
+from onepose_st_amd import hip, packing
+from onepose_st_amd.config import default_config
+from onepose_st_amd.synthetic import make_synthetic_state_dict
+sd = make_synthetic_state_dict(0, default_config()); dev = torch.device("cuda:0"); hip.load()
+B, N, hc, wc, K, cap = 2, 500, 12, 14, 301, 320
+hf, wf = 4 * hc, 4 * wc
+g = torch.Generator().manual_seed(11)
+feat = torch.randn(B, 128, hf, wf, generator=g).to(dev)
+desc = torch.randn(B, 128, N, generator=g).to(dev)
+b_ids = torch.sort(torch.randint(0, B, (cap,), generator=g))[0].to(dev)
+i_ids = torch.randint(0, N, (cap,), generator=g).to(dev)
+j_ids = torch.randint(0, hc * wc, (cap,), generator=g).to(dev)
+j_ids[:4] = torch.tensor([0, wc - 1, (hc - 1) * wc, hc * wc - 1])
+mkc = (torch.stack([j_ids % wc, j_ids // wc], 1) * 8.0).float().contiguous()
+cnt = torch.tensor([K], dtype=torch.int32, device=dev)
+w = packing.pack_fine_layers_bf16(sd, "loftr_fine.layers.", 2).to(dev)
+out = {}
+for cl in (False, True):
+    ff = feat.contiguous(memory_format=torch.channels_last) if cl else feat
+    for ns in (3, 1):
+        expec = torch.full((cap, 3), float("nan"), device=dev); mkf = torch.full((cap, 2), float("nan"), device=dev)
+        dw, d3 = torch.zeros(cap, 25, 128, device=dev), torch.zeros(cap, 128, device=dev)
+        hip.call("ophip_fine_refine_bf16", hip.ptr(ff), ff.stride(0), ff.stride(1), ff.stride(2), ff.stride(3), hf, wf, hip.ptr(desc), desc.stride(0), desc.stride(1),
+                 hip.ptr(b_ids, torch.int64), hip.ptr(i_ids, torch.int64), hip.ptr(j_ids, torch.int64), hip.ptr(cnt, torch.int32), cap, hip.ptr(mkc),
+                 hip.ptr(w, None), 2, ctypes.c_uint(2), 1, ns, wc, 4, 4.0, hip.ptr(expec), hip.ptr(mkf), hip.ptr(dw), hip.ptr(d3), hip.stream_handle())
+        torch.cuda.synchronize()
+        assert torch.isfinite(expec[:K]).all() and torch.isnan(expec[K:]).all()
+        h = hashlib.sha256()
+        for t in (expec[:K], mkf[:K], dw[:K], d3[:K]):
+            h.update(t.cpu().numpy().tobytes())
+        out[f"cl{int(cl)}_ns{ns}"] = h.hexdigest()
+print(json.dumps(out))
+'''
+    res = {}
+    for pair in ("1", "0"):
+        env = dict(os.environ, OPHIP_FINE_PAIR=pair)
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                           cwd=os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+        assert p.returncode == 0, p.stderr[-3000:]
+        res[pair] = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res["1"] == res["0"], (res["1"], res["0"])
+
+
 def test_coarse_match_empty(dev):
     g = torch.Generator().manual_seed(6)
     f3, f2 = torch.randn(1, 50, 256, generator=g), torch.randn(1, 48, 256, generator=g)
@@ -425,21 +476,38 @@ def _run_features(model, inp, dev, **kw):
     return data
 
 
-def _check_against(data, want, precision="f32", thr=0.1):
-    """Indices bit-exact wherever that is well defined: a match whose confidence sits within 1e-4 of the (strict) threshold may
-    fall on either side of it in another arithmetic ("hard parts"); such borderline matches -- and only those --
-    are set aside, reported, and everything else must agree exactly."""
+# matches set aside at the confidence threshold, per test label: printed by conftest.pytest_terminal_summary as ONE line
+# ("borderline_set_aside: {...}") so that the use of the hatch below is visible in a `pytest -q` tail
+BORDERLINE = {}
+# half-width of the window around the (strict) threshold inside which a match may fall on either side in another arithmetic,
+# relative to the threshold: exact-f32 mode has no window at all; split-bf16 confidences measure <= 4e-5 relative off the oracle's
+# (printed by every full-size test), the window is 5x that
+BORDER_WINDOW = {"f32": 0.0, "bf16x3": 2e-4}
+
+
+def _check_against(data, want, precision="f32", thr=0.1, label=None, want_rowmax=None):
+    """Indices bit-exact wherever that is well defined: a match whose confidence sits within BORDER_WINDOW of the (strict) threshold
+    may fall on either side of it in another arithmetic ("hard parts"); such borderline matches -- and only
+    those -- are set aside, COUNTED (returned and recorded under `label`), and everything else must agree exactly.  Exact-f32 mode
+    has no window: any difference fails.  `want_rowmax` (the oracle's / reference's row maxima of conf_matrix) lets the check also
+    require that the other side's value of a set-aside row lies inside the window."""
     rt, at, rt_conf = TOL[precision]
+    win = BORDER_WINDOW.get(precision, 0.0) * thr
     got_bi = torch.stack([data["b_ids"], data["i_ids"]], 1).cpu().numpy()
     want_bi = np.stack([np.asarray(want["b_ids"]), np.asarray(want["i_ids"])], 1)
     gk = {(int(b), int(i)): k for k, (b, i) in enumerate(got_bi)}
     wk = {(int(b), int(i)): k for k, (b, i) in enumerate(want_bi)}
     border = sorted(set(gk) ^ set(wk))
+    if label is not None:
+        BORDERLINE[label] = len(border)
     if border:
+        assert win > 0.0, f"[{precision}] exact mode: match sets differ at {border}"
         gm, wm = data["mconf"].cpu().numpy(), np.asarray(want["mconf"])
         for key in border:
             c = gm[gk[key]] if key in gk else wm[wk[key]]
-            assert abs(float(c) - thr) < 1e-4 * 10 * thr, f"match {key} differs with confidence {c}: not a threshold case"
+            assert abs(float(c) - thr) < win, f"match {key} differs with confidence {c}: not a threshold case (window {win:.1e})"
+            if want_rowmax is not None and key[0] == 0:
+                assert abs(float(np.asarray(want_rowmax)[key[1]]) - thr) < win, f"match {key}: the reference's row maximum is not a threshold case"
         assert len(border) <= max(1, len(wk) // 1000)
         print(f"[{precision}] {len(border)} borderline match(es) at the confidence threshold set aside: {border}")
         gsel = np.array([k for key, k in sorted(gk.items()) if key in wk], dtype=np.int64)
@@ -460,9 +528,10 @@ def _check_against(data, want, precision="f32", thr=0.1):
     err_px = float(np.abs(data["mkpts_query_f"].cpu().numpy() - np.asarray(want["mkpts_query_f"])).max()) if len(want["mconf"]) else 0.0
     err_conf = float(np.abs(data["mconf"].cpu().numpy() / np.asarray(want["mconf"]) - 1).max()) if len(want["mconf"]) else 0.0
     print(f"[{precision}] K={len(want['mconf'])}: max |mkpts_query_f err| = {err_px:.2e} px, max mconf rel err = {err_conf:.2e}")
+    return len(border)
 
 
-def _pose_parity(data, ref_mk3d, ref_mkf, inp, label):
+def _pose_parity(data, ref_mk3d, ref_mkf, inp, label, n_set_aside=0):
     """north_star: pose R|t within 1e-4 relative.  The same deterministic host PnP (onepose_st_amd.pnp) is applied to the
     HIP path's matches and to the reference / oracle matches (the reference's pycolmap / OpenCV solvers are not
     available: pose parity is pinned to equal inputs -> equal estimator)."""
@@ -476,21 +545,23 @@ def _pose_parity(data, ref_mk3d, ref_mkf, inp, label):
     print(f"[{label}] pose parity: max |dR| = {dR:.2e}, |dt|/|t| = {dt:.2e}; vs planted pose: {ang:.3f} deg, "
           f"{np.linalg.norm(pose_g[:, 3] - gt[:, 3]) * 1000:.2f} mm; inliers {len(inl_g)}/{len(inl_r)}")
     assert dR < 1e-4 and dt < 1e-4
-    assert abs(len(inl_g) - len(inl_r)) <= 2 and ang < 0.5 and np.linalg.norm(pose_g[:, 3] - gt[:, 3]) < 5e-3      # (a threshold-borderline match may differ)
+    assert abs(len(inl_g) - len(inl_r)) <= n_set_aside and ang < 0.5 and np.linalg.norm(pose_g[:, 3] - gt[:, 3]) < 5e-3      # (only a set-aside threshold match may differ)
 
 
 def test_c1_against_reference_golden(model, sd, cfg, dev, golden_dir):
     g = np.load(os.path.join(golden_dir, "c1_feature_boundary.npz"))
     inp = make_synthetic_inputs(sd, n_points=1000, image_hw=(240, 320), n_plant=600, seed=1, config=cfg)
     data = _run_features(model, inp, dev)
-    _check_against(data, g, model.precision)
+    n_sa = _check_against(data, g, model.precision, label=f"c1_{model.precision}", want_rowmax=g["conf_rowmax"])
+    if model.precision == "f32":
+        assert n_sa == 0                                   # exact mode against the reference golden: no hatch
     conf = data["conf_matrix"]
     assert conf.shape == (1, 1000, 1200) and conf.dtype == torch.float32
     rt_conf = TOL[model.precision][2]
     np.testing.assert_allclose(conf.max(dim=2)[0][0].cpu().numpy(), g["conf_rowmax"], rtol=rt_conf, atol=1e-6)
     np.testing.assert_allclose(conf.max(dim=1)[0][0].cpu().numpy(), g["conf_colmax"], rtol=rt_conf, atol=1e-6)
     assert data["bs"] == 1 and tuple(data["q_hw_c"]) == (30, 40) and tuple(data["q_hw_f"]) == (120, 160) and data["W"] == 5
-    _pose_parity(data, g["mkpts_3d_db"], g["mkpts_query_f"], inp, f"c1 {model.precision} vs reference golden")
+    _pose_parity(data, g["mkpts_3d_db"], g["mkpts_query_f"], inp, f"c1 {model.precision} vs reference golden", n_sa)
 
 
 def test_b2_ragged_against_reference_golden(model, sd, cfg, dev, golden_dir):
@@ -500,7 +571,7 @@ def test_b2_ragged_against_reference_golden(model, sd, cfg, dev, golden_dir):
     both = {k: torch.cat([i0[k], i1[k]], 0) for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db", "feat_c", "feat_f")}
     both["image_hw"] = i0["image_hw"]
     data = _run_features(model, both, dev)
-    _check_against(data, g, model.precision)
+    _check_against(data, g, model.precision, label=f"b2_{model.precision}")
     # shared object block passed as an expand() (stride-0 batch) gives the same answer
     exp = dict(both)
     for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db"):
@@ -525,6 +596,32 @@ def test_full_forward_with_backbone_empty_path(model, sd, cfg, dev, golden_dir):
     np.testing.assert_allclose(data["conf_matrix"].max(dim=2)[0][0].cpu().numpy(), g["conf_rowmax"], rtol=5e-2, atol=1e-6)
 
 
+def test_full_forward_with_backbone_planted_against_reference_golden(model, sd, cfg, dev, golden_dir):
+    """Backbone + K > 0 against the REFERENCE: its own backbone ran on this synthetic image and a forward hook added the planted
+    feature maps to the backbone's two outputs (tests/golden/make_golden.py, case D: 180 matches, every confidence > 0.05 away from
+    the threshold).  Here: the HIP convolution backbone (exact-f32 mode: MIOpen fp32) -> + the same maps -> rows a1-a11."""
+    g = np.load(os.path.join(golden_dir, "full_forward_planted.npz"))
+    img = torch.rand(1, 1, 128, 160, generator=torch.Generator().manual_seed(6))
+    inp = make_synthetic_inputs(sd, n_points=500, image_hw=(128, 160), n_plant=180, seed=7, config=cfg)
+    data = {k: inp[k].to(dev) for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db")}
+    data.update({"bs": 1, "q_hw_i": torch.Size((128, 160))})
+    if model.hip_backbone:
+        fc, ff = model.backbone_features(img.to(dev))                 # channels-last memory, positional encoding already added (linear)
+        fc.add_(inp["feat_c"].to(dev)), ff.add_(inp["feat_f"].to(dev))
+        model.enqueue_features(data, fc, ff, _pe_applied=True).finish()
+    else:
+        with torch.no_grad():
+            fc, ff = model.backbone(img.to(dev))
+        model.forward_features(data, fc + inp["feat_c"].to(dev), ff + inp["feat_f"].to(dev))
+    assert len(g["i_ids"]) == 180
+    n_sa = _check_against(data, g, model.precision, label=f"full_forward_{model.precision}", want_rowmax=g["conf_rowmax"])
+    assert n_sa == 0                                                   # every reference confidence is >= 0.05 away from the threshold
+    rt = {"f32": 1e-3, "bf16x3": 2e-3}[model.precision]                # 22 convolution layers in front of the path
+    np.testing.assert_allclose(data["conf_matrix"].max(dim=2)[0][0].cpu().numpy(), g["conf_rowmax"], rtol=rt, atol=1e-6)
+    np.testing.assert_allclose(data["conf_matrix"].max(dim=1)[0][0].cpu().numpy(), g["conf_colmax"], rtol=rt, atol=1e-6)
+    _pose_parity(data, g["mkpts_3d_db"], g["mkpts_query_f"], inp, f"full forward {model.precision} vs reference golden")
+
+
 def test_c2_full_size_against_oracle_and_properties(model, sd, cfg, dev):
     """BASELINE config c2 (7000 x 4800): indices bit-exact against the oracle, plus size-independent properties
     of the result checked on the device: mutual-nearest, threshold, border, ordering, planted recall."""
@@ -535,9 +632,10 @@ def test_c2_full_size_against_oracle_and_properties(model, sd, cfg, dev):
         ref = orc.forward_from_features(sd, cfg, inp, inp["feat_c"], inp["feat_f"], inp["image_hw"])
     K = len(ref["i_ids"])
     assert K > 2000
-    _check_against(data, {k: ref[k].numpy() for k in ("b_ids", "i_ids", "j_ids", "m_bids", "mconf", "mkpts_3d_db", "mkpts_query_c",
-                                                      "mkpts_query_f", "expec_f")}, model.precision)
-    _pose_parity(data, ref["mkpts_3d_db"].numpy(), ref["mkpts_query_f"].numpy(), inp, f"c2 {model.precision} vs oracle")
+    n_sa = _check_against(data, {k: ref[k].numpy() for k in ("b_ids", "i_ids", "j_ids", "m_bids", "mconf", "mkpts_3d_db", "mkpts_query_c",
+                                                             "mkpts_query_f", "expec_f")}, model.precision, label=f"c2_{model.precision}",
+                          want_rowmax=ref["conf_matrix"].max(dim=2)[0][0].numpy())
+    _pose_parity(data, ref["mkpts_3d_db"].numpy(), ref["mkpts_query_f"].numpy(), inp, f"c2 {model.precision} vs oracle", n_sa)
     conf, i, j = data["conf_matrix"][0], data["i_ids"], data["j_ids"]
     v = conf[i, j]
     assert torch.equal(v, data["mconf"])
@@ -587,9 +685,10 @@ def test_c4_large_object_against_oracle(sd, cfg, dev):
     with torch.no_grad():
         ref = orc.forward_from_features(sd, cfg, inp, inp["feat_c"], inp["feat_f"], inp["image_hw"])
     assert len(ref["i_ids"]) > 4000 and data["conf_matrix"].shape == (1, 15000, 19200)
-    _check_against(data, {k: ref[k].numpy() for k in ("b_ids", "i_ids", "j_ids", "m_bids", "mconf", "mkpts_3d_db", "mkpts_query_c",
-                                                      "mkpts_query_f", "expec_f")}, "bf16x3")
-    _pose_parity(data, ref["mkpts_3d_db"].numpy(), ref["mkpts_query_f"].numpy(), inp, "c4 bf16x3 vs oracle")
+    n_sa = _check_against(data, {k: ref[k].numpy() for k in ("b_ids", "i_ids", "j_ids", "m_bids", "mconf", "mkpts_3d_db", "mkpts_query_c",
+                                                             "mkpts_query_f", "expec_f")}, "bf16x3", label="c4_bf16x3",
+                          want_rowmax=ref["conf_matrix"].max(dim=2)[0][0].numpy())
+    _pose_parity(data, ref["mkpts_3d_db"].numpy(), ref["mkpts_query_f"].numpy(), inp, "c4 bf16x3 vs oracle", n_sa)
     conf, i, j = data["conf_matrix"][0], data["i_ids"], data["j_ids"]
     v = conf[i, j]
     assert torch.equal(v, data["mconf"]) and torch.equal(v, conf.max(dim=1)[0][i]) and torch.equal(v, conf.max(dim=0)[0][j])

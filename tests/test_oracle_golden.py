@@ -97,6 +97,26 @@ def test_oracle_full_forward_empty_matches(sd, cfg, golden_dir):
         assert tuple(out[k].shape) == tuple(g[k + "_shape"]), k
 
 
+def test_oracle_full_forward_planted_matches(sd, cfg, golden_dir):
+    """Backbone + K > 0: the reference ran its own backbone on a synthetic image and a forward hook added the planted feature
+    maps to the backbone's outputs (make_golden.py case D); the oracle does the same sum."""
+    g = np.load(os.path.join(golden_dir, "full_forward_planted.npz"))
+    img = torch.rand(1, 1, 128, 160, generator=torch.Generator().manual_seed(6))
+    np.testing.assert_allclose(cs(img), g["image_cs"], rtol=1e-12)
+    inp = make_synthetic_inputs(sd, n_points=500, image_hw=(128, 160), n_plant=180, seed=7, config=cfg)
+    np.testing.assert_allclose(cs(inp["feat_c"]), g["delta_c_cs"], rtol=1e-9)
+    with torch.no_grad():
+        fc, ff = orc.backbone_8_2(sd, img)
+        close_cs(cs(fc), g["feat_c_cs"], rtol=1e-4)
+        out = orc.forward_from_features(sd, cfg, inp, fc + inp["feat_c"], ff + inp["feat_f"], (128, 160))
+    assert len(g["i_ids"]) >= 150
+    for k in ("b_ids", "i_ids", "j_ids"):
+        np.testing.assert_array_equal(out[k].numpy(), g[k])
+    np.testing.assert_allclose(out["conf_matrix"].max(dim=2)[0][0].numpy(), g["conf_rowmax"], rtol=1e-4, atol=1e-7)
+    for k in ("mconf", "mkpts_query_f"):
+        np.testing.assert_allclose(out[k].numpy(), g[k], rtol=1e-4, atol=2e-5, err_msg=k)
+
+
 def test_position_table_quirk():
     """div_term = exp(-(0,2,4,...)) because of the floor division (row a1)."""
     pe = orc.position_table(256)[0]

@@ -5,7 +5,10 @@ usage: python tools/pmc_summary.py <dir of the FETCH_SIZE pass> <dir of the WRIT
 
 The optional matrix-pipe pass (`--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE`) adds, per kernel,
 the MFMA-busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 (the counter
-sums the 8 XCDs; MI355X_MICROARCH.md "DVFS give-back"), and the clock that implies with the kernel-trace duration.
+sums the 8 XCDs; MI355X_MICROARCH.md "DVFS give-back").  No clock is derived from it: GRBM_GUI_ACTIVE / 8 / duration reads high on
+dispatches shorter than ~0.3 ms (the guide says so; round 2's `clock_ghz` field printed 6 GHz for small kernels) -- the ONE clock
+this project quotes for a kernel is the in-kernel s_memtime / s_memrealtime ratio of tools/stamps_x3.py (profiles/r03_stamps_*).
+The output also records the build stamp of the library the passes ran on (ophip_build_stamp) and its ABI version.
 
 Each pass is `rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -d <dir> -- python bench.py ...` (counters in
 their own runs, never with --stats/--sys-trace).  HBM bytes per launch follow /opt/skills/guides/MI355X_MICROARCH.md:
@@ -76,16 +79,23 @@ def main():
                 "SQ_WAVE_CYCLES_median": statistics.median(mf["SQ_WAVE_CYCLES"].get(k, [0])),
                 "mfma_busy_frac": busy / (1024.0 * cyc) if cyc else None,
                 "duration_us_under_pmc": dur.get(k, 0) / 1e3,
-                "clock_ghz": cyc / dur[k] if dur.get(k) else None,
             })
+    try:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        from onepose_st_amd import hip
+        stamp, abi = hip.build_stamp(), int(hip.load().ophip_abi_version())
+    except Exception as e:          # the summary is still written; bench.py then refuses to quote it
+        stamp, abi = f"unknown ({e})", None
     json.dump({
         "command": command,
+        "library_build_stamp": stamp,
+        "ophip_abi_version": abi,
         "correction": "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (MI355X_MICROARCH.md HBM: on gfx950 FETCH_SIZE "
                       "reports 1/2 of a wide 16 B/lane coalesced read; WRITE_SIZE is exact)",
         "kernels": kernels,
     }, open(out, "w"), indent=1)
     for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:14]:
-        extra = f"  mfma busy {v['mfma_busy_frac']:.3f}, {v['duration_us_under_pmc']:.1f} us, {v['clock_ghz']:.2f} GHz" if v.get("mfma_busy_frac") is not None else ""
+        extra = f"  mfma busy {v['mfma_busy_frac']:.3f}, {v['duration_us_under_pmc']:.1f} us" if v.get("mfma_busy_frac") is not None else ""
         print(f"{k:60s} {v['hbm_bytes_per_launch'] / 1e6:10.2f} MB/launch  x{v['launches']}{extra}")
 
 

@@ -20,17 +20,21 @@ hip.call("ophip_debug_stamps", ctypes.c_void_p(buf.data_ptr()))
 data = dict(d); m.forward_features(data, fc, ff, inp["image_hw"])
 torch.cuda.synchronize()
 hip.call("ophip_debug_stamps", None)
-K = data["i_ids"].numel(); nwg = K
+K = data["i_ids"].numel()
+PAIR = __import__("os").environ.get("OPHIP_FINE_PAIR", "1") != "0"
+nwg = (K + 1) // 2 if PAIR else K
 s = buf.view(-1, 32)[:nwg].cpu().numpy().astype(np.int64)
 names = {0: "start", 1: "gather", 31: "end"}
 for l in range(2):
-    for i, n in enumerate(["qkv gemm", "attention+sync", "merge gemm", "LN1+sync", "mlp0 gemm", "H store+sync", "mlp2 gemm", "LN2+X+sync"]):
+    for i, n in enumerate(["q gemm (both matches)" if PAIR else "qkv gemm", "2 x (kv gemm + attention) + sync" if PAIR else "attention+sync", "merge gemm", "LN1+sync", "mlp0 gemm",
+                           "sync + H store + sync" if PAIR else "H store+sync", "mlp2 gemm", "LN2+X+sync"]):
         names[2 + 8 * l + i] = f"L{l} {n}"
 order = sorted(names)
 prev = s[:, 0]
+print("library build", hip.build_stamp(), "| two matches per workgroup" if PAIR else "| one match per workgroup")
 print("workgroups", nwg, "total cycles median", np.median(s[:, 31] - s[:, 0]), " (s_memtime ticks = shader cycles)")
 for k in order[1:]:
-    print(f"{names[k]:22s} {np.median(s[:, k] - prev):10.0f}")
+    print(f"{names[k]:34s} {np.median(s[:, k] - prev):10.0f}")
     prev = s[:, k]
 first, last = s[:, 0].min(), s[:, 31].max()
 print("kernel span (cycles)", last - first, " mean WG duration", (s[:, 31] - s[:, 0]).mean())
