@@ -319,7 +319,19 @@ def main():
 
     # side measurements first (the other PnP policy, the matcher alone), the contract's region last with the kernel timing on
     other = {"reference": "adaptive", "adaptive": "reference"}[args.pnp_policy]
-    dt_other = dt_matcher = dt_cached = None
+    dt_other = dt_matcher = dt_cached = dt_lazy = None
+    if not args.main_region_only and args.precision != "f32":
+        # the mode in which conf_matrix is not requested, reported beside the headline (which stays eager: the reference
+        # writes the matrix every frame).  config["hip_conf_matrix"] = "lazy": nothing N x M is stored, match lists bit-identical
+        cfg_lazy = dict(cfg)
+        cfg_lazy["hip_conf_matrix"] = "lazy"
+        model_lazy = OnePosePlus_model(cfg_lazy).eval()
+        model_lazy.load_state_dict(sd, strict=True)
+        model_lazy.to(dev)
+        model_eager, model = model, model_lazy
+        dt_lazy = timed_region(pools.get(args.pnp_policy))
+        model = model_eager
+        del model_lazy
     if not args.main_region_only:
         dt_other = timed_region(pools[other]) if pools else None
         dt_matcher = timed_region(None)
@@ -392,9 +404,10 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "setup_steps_untimed": setup_steps + (1 if args.main_region_only else 4) * args.warmup,      # settle blocks before the W warm-up steps + the warm-ups of the side regions
+        "setup_steps_untimed": setup_steps + (1 if args.main_region_only else (5 if args.precision != "f32" else 4)) * args.warmup,      # settle blocks before the W warm-up steps + the warm-ups of the side regions
         "ms_per_step": dt / args.steps * 1e3,
         "value_matcher_only": (frames_total / dt_matcher) if dt_matcher else None,
+        "value_lazy_conf": (frames_total / dt_lazy) if dt_lazy else None,          # conf_matrix not materialised (hip_conf_matrix = "lazy"), same PnP policy as `value`
         "value_matcher_only_object_cached": (frames_total / dt_cached) if dt_cached else None,
         ("value_pnp_" + other): (frames_total / dt_other) if dt_other else None,
         "higher_is_better": True,

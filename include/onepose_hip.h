@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 int ophip_abi_version(void);
-/* host string: 16 hex digits of the sha256 over the sources this library was built from (profiles/*_pmc.json record it;
+/* host string: 16 hex digits of the sha256 over the sources this library was built from (the profiles/ pmc summaries record it;
  * bench.py quotes committed counter values only when they were taken on the running build) */
 const char* ophip_build_stamp(void);
 const char* ophip_last_error(void);
@@ -106,7 +106,15 @@ int ophip_encoder_layer_x3w8(const float* x3d, const float* x2d, float* y3d, flo
  * m_bids (int64, = b_ids) and gt_mask (one byte per match, mconf == 0) are the two remaining keys of the reference's
  * coarse_matches dict (coarse_matching.py:228-240); either may be NULL.
  * temperature is passed as double so that (float)(temperature + 1e-4) matches the reference's scalar.
- * nsplit selects the arithmetic of the similarity GEMM: 0 exact f32 MFMA, 1 bf16, 3 split-bf16. */
+ * nsplit selects the arithmetic of the similarity GEMM: 0 exact f32 MFMA, 1 bf16, 3 split-bf16.
+ *
+ * LAZY conf_matrix ("may be produced lazily"; the inference callers read only the match lists, inference.py:179-180):
+ * conf == NULL in a bf16 mode.  Nothing N x M is stored: a first pass over the similarity tiles leaves the softmax statistics, a
+ * second one recomputes every tile, forms the confidences with conf_matrix's own expression (bit-identical values) and keeps per
+ * (row, column tile) the best candidate above the threshold and the column maxima -- what the selection consumes.  Indices and
+ * mconf are bit-identical to the eager form.  `count` must then point at TWO ints: count[1] is set to 1 when a row's maximum is
+ * tied exactly between columns and the first of them fails the mutual test (resolving that needs the stored row): the caller
+ * re-runs the frame with a conf buffer.  count[1] = 0 otherwise. */
 size_t ophip_coarse_workspace_floats(int B, int N, int M);
 /* bf16 modes: the similarity kernel reads its operands as (hi, lo) bf16 MFMA fragments that a first kernel derives from
  * feat3d / feat2d.  A producer that writes them itself (ophip_encoder_layer_x3w8_frag) gets their place inside the workspace
@@ -175,6 +183,7 @@ int ophip_fine_refine_bf16(const float* feat_f, long long fs_b, long long fs_c, 
  *   entry point (for callers that mix it with stage-by-stage calls and want attn_apply never to share the chip with it). */
 typedef struct ophip_frame_desc {
     int B, N, M, hc, wc, hf, wf, cf;             /* cf: channels of the fine map (128) */
+    int lazy_conf;                                /* 1: conf_matrix is not materialised (layout.conf = 0; result block int32 @4 = "re-run eagerly" flag) */
     int n_coarse; unsigned coarse_cross_bits;     /* bit li set: coarse layer li is a "cross" layer */
     int n_fine; unsigned fine_cross_bits; int fine_encoder_enable;
     int border_rm;
@@ -188,6 +197,7 @@ typedef struct ophip_frame_desc {
 typedef struct ophip_frame_layout_t {
     size_t total, result_bytes;
     size_t x2d, ffcl, x3d, y3d, y2d, z3d, stats, enc_ws, conf, cws, result, i_ids, j_ids, m_bids, gt_mask, mconf, mkc, expec;
+    size_t feat3d_out, feat2d_out;                /* the encoder's final rows [B][N][256] / [B][M][256] (inputs of coarse matching) */
 } ophip_frame_layout_t;
 int ophip_frame_layout(const ophip_frame_desc* desc, int transpose_fine, int external_x3d, ophip_frame_layout_t* layout);
 int ophip_frame_enqueue(const ophip_frame_desc* desc, const ophip_frame_layout_t* layout, void* block,

@@ -255,12 +255,20 @@ __global__ __launch_bounds__(256) void frag_planes_kernel(FragArgs p) {
 struct SimFragArgs {
     const char* a;               // fragment planes of feat3d / 16 (see frag_planes_kernel)
     const char* b;               // fragment planes of feat2d / 16
-    float* conf;                 // [B][N][M]
+    float* conf;                 // [B][N][M]   (MODE 0 only)
     float* rowpart;              // [B][ntc][N][2] (max, sum exp)
     float* colpart;              // [B][ntr][M][2]
     int N, M, ntr, ntc;
     float temp;
     unsigned long long* stamps;
+    // MODE 2 (candidates of the lazy form): merged statistics in, per-(row, column tile) best candidates and column maxima out
+    const float* rowstat;        // [B][N][2] (max, sum exp)
+    const float* colstat;        // [B][M][2]
+    const float* rowlog;         // [B][N] logf(sum exp)
+    const float* collog;         // [B][M]
+    float* rowbest;              // [B][ntc][N][3] (value, j as float bits, tie count as float bits)
+    unsigned* colmax_bits;       // [B][M]
+    float thr, logthr_lo;        // strict threshold; logf(thr) - 1e-3: conservative prefilter on the exponent (saves the exponential)
 };
 
 // XCD-aware tile of this block: label x = blockIdx.x % 8 owns row tiles [r0, r1) (sizes differ by at most one) and walks
@@ -318,7 +326,13 @@ constexpr int FRAG_CHUNK_BYTES = 16384;                              // one k-st
 constexpr size_t SIM_FRAG_STAGE = (size_t)TM * FLD * sizeof(float);  // 67 584
 constexpr size_t SIM_FRAG_LDS = SIM_FRAG_STAGE + 4 * 128 * sizeof(float) + 64;
 
-template <int NS>
+// MODE 0: the scaled S tile goes to the conf buffer and into the (max, sum exp) partials (the eager form: conf_kernel follows);
+// MODE 1: partials only, nothing stored (first pass of the lazy form: conf_matrix is not materialised);
+// MODE 2: second pass of the lazy form: the tile is recomputed, turned into confidences with the merged statistics -- the very
+//         expression of conf_kernel, so every value is bit-identical to the eager form's -- and only what select_kernel consumes
+//         leaves the chip: per (row, column tile) the best candidate above the threshold (value, lowest j, tie count) and the
+//         column maxima.  Reference callers read only the match lists (inference.py:179-180): 134 MB store + 269 MB pass saved.
+template <int NS, int MODE>
 __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_frag_kernel(SimFragArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int ti, tj;
@@ -402,6 +416,67 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_frag_kerne
                 St[(64 * wr + 32 * x + acc_row(reg, h)) * FLD + 64 * wc + 32 * y + r] = sv;
                 vmax = fmaxf(vmax, sv);
             }
+    if (MODE == 2) {
+        unsigned long long* bestk = reinterpret_cast<unsigned long long*>(smem + SIM_FRAG_STAGE);     // [128] (value bits << 32) | ~j : max = best value, lowest j
+        int* tiecnt = reinterpret_cast<int*>(bestk + 128);                                             // [128]
+        if (tid < 128) { bestk[tid] = 0ull; tiecnt[tid] = 0; }
+        __syncthreads();
+        const int c4 = tid & 31, rg = tid >> 5;
+        const float* cst = p.colstat + (size_t)b * p.M * 2;
+        const float* rst = p.rowstat + (size_t)b * p.N * 2;
+        const float* clg = p.collog + (size_t)b * p.M;
+        const float* rlg = p.rowlog + (size_t)b * p.N;
+        unsigned* cb = p.colmax_bits + (size_t)b * p.M;
+        float cmv[4], clv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = min(j0 + 4 * c4 + e, p.M - 1);
+            cmv[e] = cst[2 * j]; clv[e] = clg[j];
+        }
+        // conf = exp(((s - M_c) - log E_c) + ((s - M_r) - log E_r)): conf_kernel<.., FAST>'s expression, term for term
+        auto sweep = [&](bool count_ties) {
+            bool any = false;
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int row = rg + 8 * it, gi = i0 + row;
+                if (gi >= p.N) continue;
+                const float rm = rst[2 * gi], rl = rlg[gi];
+                const f32x4 v = *reinterpret_cast<const f32x4*>(St + row * FLD + 4 * c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int gj = j0 + 4 * c4 + e;
+                    const float t = ((v[e] - cmv[e]) - clv[e]) + ((v[e] - rm) - rl);
+                    if (t > p.logthr_lo && gj < p.M) {
+                        const float c = __expf(t);
+                        if (c > p.thr) {
+                            any = true;
+                            const unsigned long long key = ((unsigned long long)__float_as_uint(c) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)gj);
+                            if (!count_ties) {
+                                atomicMax(bestk + row, key);
+                                atomicMax(cb + gj, __float_as_uint(c));
+                            } else if ((unsigned)(bestk[row] >> 32) == __float_as_uint(c)) {
+                                atomicAdd(tiecnt + row, 1);
+                            }
+                        }
+                    }
+                }
+            }
+            return any;
+        };
+        const bool any = sweep(false);
+        __syncthreads();
+        if (any) sweep(true);                        // candidates are a few per frame and tile: the second look costs nothing
+        __syncthreads();
+        if (tid < 128 && i0 + tid < p.N) {
+            const unsigned long long key = bestk[tid];
+            float* o = p.rowbest + (((size_t)b * p.ntc + tj) * p.N + i0 + tid) * 3;
+            o[0] = key ? __uint_as_float((unsigned)(key >> 32)) : -1.f;
+            o[1] = __int_as_float(key ? (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) : 0x7fffffff);
+            o[2] = __int_as_float(tiecnt[tid]);
+        }
+        OPHIP_STAMP(p.stamps, wg, 4);
+        return;
+    }
     const float mw = wave_max_dpp(vmax);
     if (lane == 0) { wmx[wave] = mw; slow[wave] = 0; }
     __syncthreads();
@@ -423,7 +498,7 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_frag_kerne
             const int row = rg + 8 * it;
             const int gi = i0 + row, gj = j0 + 4 * c4;
             const f32x4 v = *reinterpret_cast<const f32x4*>(St + row * FLD + 4 * c4);
-            if (gi < p.N && gj < p.M) {
+            if (MODE == 0 && gi < p.N && gj < p.M) {
                 if (vec) {
                     *reinterpret_cast<f32x4*>(conf + (size_t)gi * p.M + gj) = v;
                 } else {
@@ -466,7 +541,7 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_frag_kerne
             o[0] = m; o[1] = ctot;
         }
     } else {
-        SimArgs q{nullptr, nullptr, p.conf, p.rowpart, p.colpart, p.N, p.M, p.ntr, p.ntc, p.temp, nullptr};
+        SimArgs q{nullptr, nullptr, nullptr, p.rowpart, p.colpart, p.N, p.M, p.ntr, p.ntc, p.temp, nullptr};
         tile_stats_lds<true, FLD>(q, St, tid, i0, j0, b);
     }
     OPHIP_STAMP(p.stamps, wg, 4);
@@ -478,6 +553,8 @@ struct CombineArgs {
     float *rowstat, *colstat;     // [B][N][2], [B][M][2]
     unsigned* colmax_bits;        // [B][M], cleared here for the conf pass's atomicMax
     int N, M, ntr, ntc;
+    float *rowlog, *collog;       // optional [B][N], [B][M]: logf(sum exp) for the lazy form's candidate pass (NULL: not written)
+    int* lazy_flag;               // optional: count[1], cleared here (select_kernel sets it on an exact row tie it cannot resolve without conf)
 };
 
 // 8 lanes per row / column: lane q merges partials q, q+8, ... in order, then the 8 are merged by an xor
@@ -487,6 +564,7 @@ __global__ __launch_bounds__(256) void stat_combine_kernel(CombineArgs p) {
     const bool is_row = gid < p.N;
     const int idx = is_row ? gid : gid - p.N;
     const bool live = gid < p.N + p.M;
+    if (p.lazy_flag && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *p.lazy_flag = 0;
     const int np = is_row ? p.ntc : p.ntr, len = is_row ? p.N : p.M;
     const float* part = is_row ? p.rowpart : p.colpart;
     float m = -INFINITY, e = 0.f;
@@ -507,6 +585,8 @@ __global__ __launch_bounds__(256) void stat_combine_kernel(CombineArgs p) {
         float* o = (is_row ? p.rowstat : p.colstat) + ((size_t)b * len + idx) * 2;
         o[0] = m; o[1] = e;
         if (!is_row) p.colmax_bits[(size_t)b * p.M + idx] = 0u;
+        float* lg = is_row ? p.rowlog : p.collog;
+        if (lg) lg[(size_t)b * len + idx] = logf(e);
     }
 }
 
@@ -715,7 +795,7 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs p) {
     if (tid == 0) base_s = 0;
     __syncthreads();
     for (int b = 0; b < p.B; ++b) {
-        const float* conf = p.conf + (size_t)b * p.N * p.M;
+        const float* conf = p.conf ? p.conf + (size_t)b * p.N * p.M : nullptr;
         const float* cmx = p.colmax + (size_t)b * p.M;
         const float* kpb = p.kpts + (size_t)b * p.kpts_bs;
         for (int ib = 0; ib < p.N; ib += 1024 * SEL_IT) {
@@ -756,9 +836,13 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs p) {
                     o = inside(j[it]) && vv == cm[it];
                     if (!o && c[it] > 1) {
                         // exact tie of the row maximum: the reference takes the first j whose mask is true
-                        const float* row = conf + (size_t)i * p.M;
-                        for (int jj = j[it] + 1; jj < p.M; ++jj)
-                            if (row[jj] == vv && inside(jj) && vv == cmx[jj]) { j[it] = jj; o = true; break; }
+                        if (p.conf) {
+                            const float* row = conf + (size_t)i * p.M;
+                            for (int jj = j[it] + 1; jj < p.M; ++jj)
+                                if (row[jj] == vv && inside(jj) && vv == cmx[jj]) { j[it] = jj; o = true; break; }
+                        } else {
+                            p.count[1] = 1;          // lazy form: the other tied columns were never stored -> the caller re-runs this frame eagerly
+                        }
                     }
                 }
                 ok[it] = o;
@@ -802,32 +886,44 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs p) {
             __syncthreads();
         }
     }
-    if (tid == 0 && blockIdx.x == 0) *p.count = base_s;
+    if (tid == 0 && blockIdx.x == 0) *p.count = base_s;          // (count[1], the lazy form's "needs the eager form" flag, is cleared by the caller's memset / stat pass)
 }
 
 inline int conf_nspan(int M) { return (M + 3071) / 3072; }
 inline int conf_spanw(int M) { const int ns = conf_nspan(M); return (((M + ns - 1) / ns) + 3) / 4 * 4; }
 
+// workspace map (floats), shared by the sizing helper, coarse_impl and the fragment-plane accessor
+struct CoarseWs {
+    size_t rowpart, colpart, rowstat, colstat, rowbest, colmax, rowlog, collog, planes, total;
+    int nspan_cap;                                   // row-best records per row: conf_kernel's spans or (lazy form) the column tiles
+};
+CoarseWs coarse_ws(int B, int N, int M) {
+    const size_t ntr = (N + TM - 1) / TM, ntc = (M + TN - 1) / TN;
+    CoarseWs w;
+    w.nspan_cap = (int)(ntc > (size_t)conf_nspan(M) ? ntc : (size_t)conf_nspan(M));
+    size_t f = 0;
+    w.rowpart = f; f += (size_t)B * ntc * N * 2;
+    w.colpart = f; f += (size_t)B * ntr * M * 2;
+    w.rowstat = f; f += (size_t)B * N * 2;
+    w.colstat = f; f += (size_t)B * M * 2;
+    w.rowbest = f; f += (size_t)B * w.nspan_cap * N * 3;
+    w.colmax = f; f += (size_t)B * M;
+    w.rowlog = f; f += (size_t)B * N;
+    w.collog = f; f += (size_t)B * M;
+    w.planes = f; f += (size_t)B * (ntr + ntc) * TM * C + 64;      // fragment planes of both inputs (hi + lo bf16 = 4 bytes per element), rows padded to 128
+    w.total = f + 64;
+    return w;
+}
+
 }  // namespace
 
-extern "C" size_t ophip_coarse_workspace_floats(int B, int N, int M) {
-    const size_t ntr = (N + TM - 1) / TM, ntc = (M + TN - 1) / TN;
-    size_t f = 0;
-    f += (size_t)B * ntc * N * 2;          // rowpart
-    f += (size_t)B * ntr * M * 2;          // colpart
-    f += (size_t)B * N * 2 + (size_t)B * M * 2;     // rowstat, colstat
-    f += (size_t)B * conf_nspan(M) * N * 3;         // rowbest (one-pass form: per span)
-    f += (size_t)B * M;                    // colmax (float bits)
-    f += (size_t)B * (ntr + ntc) * TM * C + 64;     // fragment planes of both inputs (hi + lo bf16 = 4 bytes per element), rows padded to 128
-    return f + 64;
-}
+extern "C" size_t ophip_coarse_workspace_floats(int B, int N, int M) { return coarse_ws(B, N, M).total; }
 
 namespace {
 // where the fragment planes of the bf16 modes live inside the workspace (behind the partials; 64-byte aligned)
 void frag_plane_ptrs(float* workspace, int B, int N, int M, char** a, char** b) {
-    const size_t ntr = (N + TM - 1) / TM, ntc = (M + TN - 1) / TN;
-    float* w2 = workspace + (size_t)B * ntc * N * 2 + (size_t)B * ntr * M * 2 + (size_t)B * N * 2 + (size_t)B * M * 2
-                + (size_t)B * conf_nspan(M) * N * 3 + (size_t)B * M;
+    const size_t ntr = (N + TM - 1) / TM;
+    float* w2 = workspace + coarse_ws(B, N, M).planes;
     w2 += (16 - ((reinterpret_cast<uintptr_t>(w2) >> 2) & 15)) & 15;
     *a = reinterpret_cast<char*>(w2);
     *b = *a + (size_t)B * ntr * 4 * 32768;
@@ -839,25 +935,32 @@ int coarse_impl(int parts, const float* feat3d, const float* feat2d, const float
                 float* conf, float* workspace, long long* b_ids, long long* i_ids, long long* j_ids,
                 float* mconf, float* mkpts3d, float* mkpts_c, long long* m_bids, unsigned char* gt_mask,
                 int* count, int nsplit, void* stream_) {
-    if (!feat3d || !feat2d || !keypoints3d || !conf || !workspace || !b_ids || !i_ids || !j_ids || !mconf || !mkpts3d || !mkpts_c || !count)
+    if (!feat3d || !feat2d || !keypoints3d || !workspace || !b_ids || !i_ids || !j_ids || !mconf || !mkpts3d || !mkpts_c || !count)
         return ophip_bad_arg(__func__, "null pointer");
+    const bool lazy = conf == nullptr;               // conf_matrix not requested: nothing N x M is stored (bf16 modes)
     if (B < 1 || N < 1 || M < 1 || wc < 1 || M % wc != 0) return ophip_bad_arg(__func__, "bad sizes (need M == hc * wc)");
     const bool planes_ready = (nsplit & OPHIP_COARSE_PLANES_READY) != 0;       // the caller wrote the fragment planes (ophip_coarse_frag_planes)
     nsplit &= ~OPHIP_COARSE_PLANES_READY;
     if (nsplit != 0 && nsplit != 1 && nsplit != 3) return ophip_bad_arg(__func__, "nsplit must be 0 (exact f32), 1 (bf16) or 3 (split bf16)");
     if (planes_ready && nsplit == 0) return ophip_bad_arg(__func__, "fragment planes are an input of the bf16 modes only");
+    if (lazy && nsplit == 0) return ophip_bad_arg(__func__, "conf == NULL (lazy conf_matrix) needs a bf16 mode: the exact-f32 mode always materialises it");
     hipStream_t stream = (hipStream_t)stream_;
     const int ntr = (N + TM - 1) / TM, ntc = (M + TN - 1) / TN, nrb = (N + CONF_ROWS - 1) / CONF_ROWS;
     const int nspan = conf_nspan(M), spanw = conf_spanw(M);
-    float* rowpart = workspace;
-    float* colpart = rowpart + (size_t)B * ntc * N * 2;
-    float* rowstat = colpart + (size_t)B * ntr * M * 2;
-    float* colstat = rowstat + (size_t)B * N * 2;
-    float* rowbest = colstat + (size_t)B * M * 2;
-    float* colmax = rowbest + (size_t)B * nspan * N * 3;
+    const CoarseWs ws = coarse_ws(B, N, M);
+    float* rowpart = workspace + ws.rowpart;
+    float* colpart = workspace + ws.colpart;
+    float* rowstat = workspace + ws.rowstat;
+    float* colstat = workspace + ws.colstat;
+    float* rowbest = workspace + ws.rowbest;
+    float* colmax = workspace + ws.colmax;
+    float* rowlog = workspace + ws.rowlog;
+    float* collog = workspace + ws.collog;
 
     // bf16 modes: fragment planes + LDS-DMA tile kernel; exact-f32 mode: the f32-MFMA tile kernel (true maxima, libm)
-    const int sel_nspan = nspan;
+    const int sel_nspan = lazy ? ntc : nspan;
+    SimFragArgs sf{};
+    const int per_xcd = ((ntr + 7) / 8) * ntc;
     if ((parts & 1) && nsplit != 0) {
         char *fa_, *fb_;
         frag_plane_ptrs(workspace, B, N, M, &fa_, &fb_);
@@ -866,12 +969,15 @@ int coarse_impl(int parts, const float* feat3d, const float* feat2d, const float
             OPHIP_LAUNCH("frag_planes", stream, frag_planes_kernel, dim3(16 * (ntr + ntc), B), dim3(256), 0, stream, fr);
             OPHIP_CHECK_LAUNCH();
         }
-        SimFragArgs sf{fa_, fb_, conf, rowpart, colpart, N, M, ntr, ntc, (float)(temperature + 1e-4), ophip_stamp_buffer()};
-        const int per_xcd = ((ntr + 7) / 8) * ntc;
-        const void* fn = nsplit == 3 ? reinterpret_cast<const void*>(sim_frag_kernel<3>) : reinterpret_cast<const void*>(sim_frag_kernel<1>);
-        if (int rc = ophip_lds_attr(fn, SIM_FRAG_LDS, "hipFuncSetAttribute(sim_frag)")) return rc;
-        if (nsplit == 3) OPHIP_LAUNCH("sim_stats", stream, sim_frag_kernel<3>, dim3(8 * per_xcd, B), dim3(256), SIM_FRAG_LDS, stream, sf);
-        else OPHIP_LAUNCH("sim_stats", stream, sim_frag_kernel<1>, dim3(8 * per_xcd, B), dim3(256), SIM_FRAG_LDS, stream, sf);
+        sf = SimFragArgs{fa_, fb_, conf, rowpart, colpart, N, M, ntr, ntc, (float)(temperature + 1e-4), ophip_stamp_buffer(),
+                         rowstat, colstat, rowlog, collog, rowbest, reinterpret_cast<unsigned*>(colmax), thr, logf(thr) - 1e-3f};
+#define OPHIP_SIM_CASE(NS_, MODE_, NAME_)                                                                                          \
+        {                                                                                                                          \
+            if (int rc = ophip_lds_attr(reinterpret_cast<const void*>(sim_frag_kernel<NS_, MODE_>), SIM_FRAG_LDS, "hipFuncSetAttribute(sim_frag)")) return rc; \
+            OPHIP_LAUNCH(NAME_, stream, (sim_frag_kernel<NS_, MODE_>), dim3(8 * per_xcd, B), dim3(256), SIM_FRAG_LDS, stream, sf);    \
+        }
+        if (lazy) { if (nsplit == 3) OPHIP_SIM_CASE(3, 1, "sim_stats") else OPHIP_SIM_CASE(1, 1, "sim_stats") }
+        else { if (nsplit == 3) OPHIP_SIM_CASE(3, 0, "sim_stats") else OPHIP_SIM_CASE(1, 0, "sim_stats") }
         OPHIP_CHECK_LAUNCH();
     } else if (parts & 1) {
         SimArgs sa{feat3d, feat2d, conf, rowpart, colpart, N, M, ntr, ntc, (float)(temperature + 1e-4), ophip_stamp_buffer()};
@@ -883,9 +989,17 @@ int coarse_impl(int parts, const float* feat3d, const float* feat2d, const float
         OPHIP_CHECK_LAUNCH();
     }
     if (parts & 1) {
-        CombineArgs ca{rowpart, colpart, rowstat, colstat, reinterpret_cast<unsigned*>(colmax), N, M, ntr, ntc};
+        CombineArgs ca{rowpart, colpart, rowstat, colstat, reinterpret_cast<unsigned*>(colmax), N, M, ntr, ntc, lazy ? rowlog : nullptr, lazy ? collog : nullptr, lazy ? count + 1 : nullptr};
         OPHIP_LAUNCH("stat_combine", stream, stat_combine_kernel, dim3((N + M + 31) / 32, B), dim3(256), 0, stream, ca);
         OPHIP_CHECK_LAUNCH();
+    }
+    if ((parts & 1) && lazy) {
+        // second look at every tile: confidences from the merged statistics, only the candidates leave the chip
+        if (nsplit == 3) OPHIP_SIM_CASE(3, 2, "sim_cand") else OPHIP_SIM_CASE(1, 2, "sim_cand")
+        OPHIP_CHECK_LAUNCH();
+    }
+#undef OPHIP_SIM_CASE
+    if ((parts & 1) && !lazy) {
         ConfArgs fa{conf, rowstat, colstat, rowbest, reinterpret_cast<unsigned*>(colmax), N, M, nspan, spanw, nrb, thr};
         const bool vec = M % 4 == 0, fast = nsplit != 0;
         if (vec && fast) OPHIP_LAUNCH("conf", stream, (conf_kernel<true, true>), dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
@@ -896,7 +1010,7 @@ int coarse_impl(int parts, const float* feat3d, const float* feat2d, const float
     }
     if (parts & 2) {
         SelectArgs se{conf, rowbest, colmax, keypoints3d, kpts_bstride, B, N, M, sel_nspan, wc, border_rm, thr, scale,
-                      b_ids, i_ids, j_ids, mconf, mkpts3d, mkpts_c, m_bids, gt_mask, count};
+                      b_ids, i_ids, j_ids, mconf, mkpts3d, mkpts_c, m_bids, gt_mask, count};      // (conf == NULL: an exact row tie sets count[1])
         OPHIP_LAUNCH("select", stream, select_kernel, dim3(SEL_IT), dim3(1024), 0, stream, se);
         OPHIP_CHECK_LAUNCH();
     }

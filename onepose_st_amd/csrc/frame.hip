@@ -68,7 +68,7 @@ extern "C" int ophip_frame_layout(const ophip_frame_desc* d, int transpose_fine,
     L->z3d = external_x3d ? take(B * N * C * 4) : 0;
     L->stats = take((4 * B + 4) * 4);
     L->enc_ws = take(ophip_encoder_x3w8_workspace_bytes(d->B, d->N, d->M));
-    L->conf = take(B * N * M * 4);
+    L->conf = d->lazy_conf ? 0 : take(B * N * M * 4);          // lazy form: conf_matrix is never stored
     L->cws = take(ophip_coarse_workspace_floats(d->B, d->N, d->M) * 4);
     L->result = take(16 + 28 * cap);
     L->i_ids = take(cap * 8);
@@ -80,6 +80,10 @@ extern "C" int ophip_frame_layout(const ophip_frame_desc* d, int transpose_fine,
     L->expec = take(cap * 12);
     L->total = o;
     L->result_bytes = 16 + 28 * cap;
+    // where the encoder's final rows end up (the ping-pong of ophip_frame_enqueue): what a caller needs to materialise a lazy conf_matrix
+    const size_t z3 = external_x3d ? L->z3d : L->x3d;
+    L->feat3d_out = (d->n_coarse % 2 == 0) ? z3 : L->y3d;
+    L->feat2d_out = (d->n_coarse % 2 == 0) ? L->x2d : L->y2d;
     return 0;
 }
 
@@ -168,7 +172,7 @@ extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_
         float* t2 = x2; x2 = y2; y2 = t2;
     }
     // ---- a7 + a8: coarse matching; selection, fine stage and read-back on their side streams -----------------------------------
-    float* conf = F(L->conf);
+    float* conf = d->lazy_conf ? nullptr : F(L->conf);
     float* cws = F(L->cws);
     int* count = reinterpret_cast<int*>(blob + L->result);
     long long* b_ids = I64(L->result + 16);

@@ -24,7 +24,7 @@ c_ll = ctypes.c_longlong
 class FrameDesc(ctypes.Structure):
     """``ophip_frame_desc`` (include/onepose_hip.h)"""
     _fields_ = [("B", c_i), ("N", c_i), ("M", c_i), ("hc", c_i), ("wc", c_i), ("hf", c_i), ("wf", c_i), ("cf", c_i),
-                ("n_coarse", c_i), ("coarse_cross_bits", ctypes.c_uint),
+                ("lazy_conf", c_i), ("n_coarse", c_i), ("coarse_cross_bits", ctypes.c_uint),
                 ("n_fine", c_i), ("fine_cross_bits", ctypes.c_uint), ("fine_encoder_enable", c_i),
                 ("border_rm", c_i),
                 ("thr", ctypes.c_float), ("scale_c", ctypes.c_float), ("fine_scale", ctypes.c_float),
@@ -35,7 +35,7 @@ class FrameDesc(ctypes.Structure):
 class FrameLayout(ctypes.Structure):
     """``ophip_frame_layout_t``: byte offsets inside the frame's device block"""
     _fields_ = [(n, ctypes.c_size_t) for n in ("total", "result_bytes", "x2d", "ffcl", "x3d", "y3d", "y2d", "z3d", "stats", "enc_ws", "conf", "cws",
-                                               "result", "i_ids", "j_ids", "m_bids", "gt_mask", "mconf", "mkc", "expec")]
+                                               "result", "i_ids", "j_ids", "m_bids", "gt_mask", "mconf", "mkc", "expec", "feat3d_out", "feat2d_out")]
 
 
 _SIGNATURES = {

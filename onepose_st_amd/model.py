@@ -129,6 +129,14 @@ class OnePosePlus_model(nn.Module):
         # all of its work unless the caller opts in (bench.py reports both)
         self.cache_object = bool(config.get("hip_cache_object", False))
         self._obj_cache = None
+        # conf_matrix: "eager" (default) stores the N x M matrix every frame like the reference; "lazy" never stores it (the
+        # inference callers read only the match lists): ``data["conf_matrix"]`` is then a :class:`LazyConfMatrix` that materialises on
+        # first use.  Match indices and confidences are bit-identical in both forms.
+        self.conf_matrix_mode = str(config.get("hip_conf_matrix", "eager"))
+        if self.conf_matrix_mode not in ("eager", "lazy"):
+            raise ValueError(f"hip_conf_matrix {self.conf_matrix_mode!r}: expected 'eager' or 'lazy'")
+        if self.conf_matrix_mode == "lazy" and self.precision == "f32":
+            raise ValueError("hip_conf_matrix = 'lazy' needs a bf16 arithmetic mode (the exact-f32 mode always materialises conf_matrix)")
         # the default path as ONE C call per frame (csrc/frame.hip: same kernels, same streams, one device block per frame) instead of
         # ~27 ctypes calls + ~20 allocations + ~10 stream / event operations from Python: 0.39 -> ~0.1 ms of host time per frame
         self.frame_call = bool(config.get("hip_frame_call", os.environ.get("OPHIP_FRAME_CALL", "1") != "0"))
@@ -230,7 +238,7 @@ class OnePosePlus_model(nn.Module):
 
     @torch.no_grad()
     def enqueue_features(self, data, feat_c, feat_f, image_hw=None, want_fine_debug=False, host_copy=False, _pe_applied=False,
-                         inputs_ready=False):
+                         inputs_ready=False, _force_eager=False):
         """Enqueue the whole path for one batch on the current stream WITHOUT synchronising and return a
         :class:`PendingFrame`; ``.finish()`` waits for that frame only (an event, not the stream) and fills ``data``.
         A pipeline enqueues frame t + 1 before finishing frame t, so the GPU never idles on the host
@@ -277,6 +285,9 @@ class OnePosePlus_model(nn.Module):
 
         main = torch.cuda.current_stream(dev)
         fkey = (str(dev), main.cuda_stream)
+        lazy = self.conf_matrix_mode == "lazy" and not _force_eager
+        # a lazy frame whose selection meets an exact row tie it cannot resolve without the stored row is run again with conf_matrix
+        rerun = (lambda: self.enqueue_features(data, feat_c, feat_f, image_hw, want_fine_debug, host_copy, _pe_applied, False, True)) if lazy else None
         if (self.frame_call and self.precision == "bf16x3" and self.overlap_fine and not _pe_applied and not want_fine_debug
                 and not self.debug and isinstance(self.profiler, _NullProfiler) and bool(cfg["fine_matching"]["enable"])
                 and (self.kpt_3d_pos_encoding is not None or B == 1 or desc_in_d.shape[0] == B)
@@ -289,7 +300,7 @@ class OnePosePlus_model(nn.Module):
                     main.wait_event(self._obj_cache[2])
             if not self.cache_object or x3d_ext is not None:          # a cache miss takes the stage-by-stage path below, which fills the cache
                 return self._enqueue_frame_call(data, feat_c, feat_f, kpts_d, desc_in_d, desc_fine_d, x3d_ext, W, dev, main, fkey,
-                                                B, N, M, hc, wc, hf, wf, host_copy, inputs_ready)
+                                                B, N, M, hc, wc, hf, wf, host_copy, inputs_ready, lazy, rerun)
         if fkey in self._frame_call_pending:                          # order this frame's encoder behind the C path's last fine stage
             self._frame_call_pending.discard(fkey)
             lib_call("ophip_frame_order_after_fine", ctypes.c_void_p(main.cuda_stream))
@@ -402,7 +413,7 @@ class OnePosePlus_model(nn.Module):
         # ---- a7 + a8: coarse matching -----------------------------------------------------------
         cm = cfg["coarse_matching"]
         cap = B * N
-        conf = torch.empty(B, N, M, **f32)
+        conf = None if lazy else torch.empty(B, N, M, **f32)
         cws = torch.empty(hip.load().ophip_coarse_workspace_floats(B, N, M), **f32)
         i64 = dict(device=dev, dtype=torch.int64)
         # what the host reads back (count, b_ids, 3D points, refined 2D points) lives in one block: one D2H copy per frame
@@ -423,7 +434,8 @@ class OnePosePlus_model(nn.Module):
         split_select = fine_on and self.overlap_fine
         with self.profiler.record_function("LoFTR/coarse-matching/get_coarse_match"):
             lib_call("ophip_coarse_match_conf" if split_select else "ophip_coarse_match", *cm_args, S)
-        data["conf_matrix"] = conf
+        data["conf_matrix"] = conf if not lazy else LazyConfMatrix(x3d, x2d, float(cm["dual_softmax"]["temperature"]),
+                                                                     {"f32": 0, "bf16": 1, "bf16x3": 3}[self.precision], main)
 
         fine_ctx = contextlib.nullcontext()
         if fine_on and self.overlap_fine:
@@ -478,6 +490,7 @@ class OnePosePlus_model(nn.Module):
                                      m_bids=m_bids, gt_mask=gt_mask,
                                      expec=expec if fine_on else None, mkf=mkf if fine_on else None,
                                      dbg_w=dbg_w if fine_on else None, dbg_3=dbg_3 if fine_on else None, keep=keep), host_copy)
+            pend._rerun = rerun
         return pend
 
 
@@ -490,7 +503,7 @@ class OnePosePlus_model(nn.Module):
         return st
 
     def _enqueue_frame_call(self, data, feat_c, feat_f, kpts_d, desc_in_d, desc_fine_d, x3d_ext, W, dev, main, fkey,
-                            B, N, M, hc, wc, hf, wf, host_copy, inputs_ready):
+                            B, N, M, hc, wc, hf, wf, host_copy, inputs_ready, lazy=False, rerun=None):
         """The whole frame through ``ophip_frame_enqueue`` (csrc/frame.hip): one device block, one C call."""
         cfg = self.config
         fc = feat_c if (feat_c.dtype == torch.float32 and feat_c.is_contiguous()) else feat_c.float().contiguous()
@@ -501,11 +514,12 @@ class OnePosePlus_model(nn.Module):
         cf_ch = ff.shape[1]
         cm, lf = cfg["coarse_matching"], cfg["loftr_fine"]
         img_h = data["q_hw_i"][0]
-        pkey = (str(dev), B, N, M, hc, wc, hf, wf, cf_ch, bool(transpose_fine), x3d_ext is not None, int(img_h), id(W))
+        pkey = (str(dev), B, N, M, hc, wc, hf, wf, cf_ch, bool(transpose_fine), x3d_ext is not None, int(img_h), id(W), bool(lazy))
         plan = self._frame_plans.get(pkey)
         if plan is None:
             d = hip.FrameDesc()
             d.B, d.N, d.M, d.hc, d.wc, d.hf, d.wf, d.cf = B, N, M, hc, wc, hf, wf, cf_ch
+            d.lazy_conf = 1 if lazy else 0
             names_c, names_f = self.loftr_coarse.layer_names, self.loftr_fine.layer_names
             d.n_coarse, d.coarse_cross_bits = len(names_c), sum(1 << i for i, n in enumerate(names_c) if n == "cross")
             d.n_fine, d.fine_cross_bits = len(names_f), sum(1 << i for i, n in enumerate(names_f) if n == "cross")
@@ -570,9 +584,81 @@ class OnePosePlus_model(nn.Module):
             PendingFrame._pinned_pool.setdefault((cap, bool(host_copy)), []).append(pin)
             raise
         self._frame_call_pending.add(fkey)
-        data["conf_matrix"] = blob[L.conf:L.conf + 4 * B * N * M].view(torch.float32).view(B, N, M)
+        if lazy:
+            f3 = blob[L.feat3d_out:L.feat3d_out + 4 * B * N * 256].view(torch.float32).view(B, N, 256)
+            f2 = blob[L.feat2d_out:L.feat2d_out + 4 * B * M * 256].view(torch.float32).view(B, M, 256)
+            data["conf_matrix"] = LazyConfMatrix(f3, f2, float(cm["dual_softmax"]["temperature"]), 3, main)
+        else:
+            data["conf_matrix"] = blob[L.conf:L.conf + 4 * B * N * M].view(torch.float32).view(B, N, M)
         keep = [fc, ff, kpts_d, desc_in_d, desc_fine_d, x3d_ext, W]
-        return PendingFrame._from_block(self, data, dev, B, N, M, cap, blob, L, slot, pin, host_copy, keep)
+        pend = PendingFrame._from_block(self, data, dev, B, N, M, cap, blob, L, slot, pin, host_copy, keep)
+        pend._rerun = rerun
+        return pend
+
+class LazyConfMatrix:
+    """``data["conf_matrix"]`` of the lazy form (``config["hip_conf_matrix"] = "lazy"``): the N x M dual-softmax matrix is not stored
+    by the frame; this object keeps the encoder's final rows and computes it on first use -- same kernels, same bits as the eager
+    form (``ophip_coarse_match_conf`` with a conf buffer).  ``shape`` / ``dtype`` / ``device`` answer without materialising; indexing,
+    attribute access (``.max``, ``.cpu`` ...) and ``torch.*`` functions materialise first (``__torch_function__``).
+    Reference: ``utils/coarse_matching.py:115``; its readers at inference time: none (``inference.py:179-180``)."""
+
+    def __init__(self, feat3d, feat2d, temperature, nsplit, stream):
+        self._f3, self._f2, self._temp, self._nsplit, self._stream = feat3d, feat2d, temperature, nsplit, stream
+        self._t = None
+        self.shape = torch.Size((feat3d.shape[0], feat3d.shape[1], feat2d.shape[1]))
+        self.dtype, self.device = torch.float32, feat3d.device
+
+    def materialize(self) -> torch.Tensor:
+        if self._t is None:
+            B, N, M = self.shape
+            dev = self.device
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_stream(self._stream)             # the frame's encoder has produced the rows
+            conf = torch.empty(B, N, M, device=dev, dtype=torch.float32)
+            ws = torch.empty(hip.load().ophip_coarse_workspace_floats(B, N, M), device=dev, dtype=torch.float32)
+            cap = B * N
+            ids = torch.empty(3 * cap, dtype=torch.int64, device=dev)
+            fl = torch.empty(6 * cap + 3, dtype=torch.float32, device=dev)
+            cnt = torch.zeros(4, dtype=torch.int32, device=dev)
+            P = hip.ptr
+            hip.call("ophip_coarse_match_conf", P(self._f3), P(self._f2), P(fl[:3]), 0, B, N, M, M, self._temp, 0.5, 0, 1.0,
+                     P(conf), P(ws), P(ids[:cap], torch.int64), P(ids[cap:2 * cap], torch.int64), P(ids[2 * cap:], torch.int64),
+                     P(fl[3:3 + cap]), P(fl[3 + cap:3 + 4 * cap]), P(fl[3 + 4 * cap:3 + 6 * cap]), None, None, P(cnt, torch.int32),
+                     self._nsplit, hip.stream_handle())
+            self._t = conf
+            self._f3 = self._f2 = None
+        return self._t
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def dim(self):
+        return 3
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, idx):
+        return self.materialize()[idx]
+
+    def __getattr__(self, name):                      # anything a tensor has and this object does not: materialise, then delegate
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.materialize(), name)
+
+    def __repr__(self):
+        return f"LazyConfMatrix(shape={tuple(self.shape)}, materialised={self._t is not None})"
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        def conv(a):
+            if isinstance(a, LazyConfMatrix):
+                return a.materialize()
+            if isinstance(a, (list, tuple)):
+                return type(a)(conv(x) for x in a)
+            return a
+        return func(*conv(tuple(args)), **{k: conv(v) for k, v in (kwargs or {}).items()})
+
 
 def _result_views(blob, cap):
     """(blob, count int32[1], b_ids int64[cap], mkpts3d f32[cap,3], mkpts2d f32[cap,2]) views of one byte block."""
@@ -601,6 +687,7 @@ class PendingFrame:
         self._pin = PendingFrame._take_pin(key, nbytes)
         self._key, self._host_copy = key, bool(host_copy)
         self._slot = None
+        self._rerun = None
         # the D2H of the result block runs on a side stream behind an event: on the compute stream the PCIe round trip
         # (~40 us per frame) would sit between this frame's last kernel and the next frame's first one
         main = torch.cuda.current_stream(dev)
@@ -633,6 +720,7 @@ class PendingFrame:
         self._block, self._layout, self._slot, self._keep = blob, layout, slot, keep
         self._pin, self._key, self._host_copy = pin, (cap, bool(host_copy)), bool(host_copy)
         self.event = None
+        self._rerun = None
         self.done = False
         return self
 
@@ -689,6 +777,15 @@ class PendingFrame:
             return self.data
         self._wait()                                # the one host wait of the frame
         K = int(self._pin[:4].view(torch.int32)[0])
+        if self._rerun is not None and int(self._pin[4:8].view(torch.int32)[0]) != 0:
+            # lazy conf_matrix and an exact tie of a row maximum whose first column failed the mutual test: which column the reference
+            # takes next can only be read from the stored row -> this frame again, eagerly (identical arithmetic, conf_matrix stored)
+            self._release_pin()
+            self.done = True
+            again = self._rerun()
+            again.finish()
+            self.host = again.host
+            return self.data
         B, N, M, cap = self.B, self.N, self.M, self.cap
         if self._host_copy:
             _, _, hb, h3, h2 = _result_views(self._pin, cap)

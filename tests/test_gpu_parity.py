@@ -903,6 +903,90 @@ def test_object_cache_is_bit_identical(sd, cfg, dev):
         assert torch.equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("size", ["ragged_b2", "c1", "c2"])
+def test_lazy_conf_matrix_is_bit_identical_to_the_eager_form(sd, cfg, dev, size):
+    """config["hip_conf_matrix"] = "lazy": conf_matrix is never stored (two passes over the similarity tiles, candidates only);
+    every output the reference's inference callers read -- indices, mconf, keypoints, expec_f -- equals the eager form bit for bit,
+    on the one-call frame path and on the stage-by-stage path; data["conf_matrix"] materialises on first use to the eager matrix"""
+    from onepose_st_amd.model import LazyConfMatrix
+    if size == "ragged_b2":
+        i0 = make_synthetic_inputs(sd, n_points=333, image_hw=(96, 136), n_plant=120, seed=3, config=cfg, frame=0)
+        i1 = make_synthetic_inputs(sd, n_points=333, image_hw=(96, 136), n_plant=120, seed=3, config=cfg, frame=1)
+        inp = {k: torch.cat([i0[k], i1[k]], 0) for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db", "feat_c", "feat_f")}
+        inp["image_hw"] = i0["image_hw"]
+    elif size == "c1":
+        inp = make_synthetic_inputs(sd, n_points=1000, image_hw=(240, 320), n_plant=600, seed=1, config=cfg)
+    else:
+        inp = make_synthetic_inputs(sd, n_points=7000, image_hw=(480, 640), n_plant=3000, seed=1, config=cfg)
+    eager = _model(sd, cfg, dev, "bf16x3")
+    cl = copy.deepcopy(cfg)
+    cl["hip_conf_matrix"] = "lazy"
+    lazy = _model(sd, cl, dev, "bf16x3")
+    keys = ("b_ids", "i_ids", "j_ids", "m_bids", "mconf", "mkpts_3d_db", "mkpts_query_c", "mkpts_query_f", "expec_f", "gt_mask")
+    want = _run_features(eager, inp, dev)
+    assert want["i_ids"].numel() > 50
+    for frame_call in (True, False):
+        lazy.frame_call = frame_call
+        got = _run_features(lazy, inp, dev)
+        for k in keys:
+            assert torch.equal(got[k], want[k]), (k, frame_call)
+        cm = got["conf_matrix"]
+        assert isinstance(cm, LazyConfMatrix) and tuple(cm.shape) == tuple(want["conf_matrix"].shape) and cm._t is None
+        if size != "c2" or frame_call:
+            assert torch.equal(cm[0, :7], want["conf_matrix"][0, :7]) and cm._t is not None            # indexing materialises
+            assert torch.equal(torch.max(cm, dim=2)[0], want["conf_matrix"].max(dim=2)[0])             # torch functions too
+            assert torch.equal(cm.materialize(), want["conf_matrix"])
+    with pytest.raises(ValueError):
+        _model(sd, cl, dev, "f32")                    # the exact mode always materialises
+
+
+def test_lazy_conf_matrix_exact_tie_raises_the_rerun_flag(dev):
+    """the one thing the lazy selection cannot decide without the stored row: a row maximum tied exactly between two columns whose
+    first column fails the mask (here: it lies in the removed border, the construction of test_coarse_match_tie_and_border_semantics).
+    The C entry point then raises count[1] (OnePosePlus_model re-runs such a frame with a conf buffer); without a tie count[1] = 0 and
+    the match lists equal the eager form's."""
+    hc, wc, N = 8, 9, 40
+    M = hc * wc
+    g = torch.Generator().manual_seed(5)
+    f3 = torch.randn(1, N, 256, generator=g) * 1.5
+    f2 = torch.randn(1, M, 256, generator=g)
+    cell = lambda y, x: y * wc + x
+    f2[0, cell(7, 8)] = f3[0, 1] * 1.5
+    f2[0, cell(4, 4)] = f3[0, 3] * 1.5
+    kp = torch.zeros(1, N, 3)
+
+    def lazy_call(f2_):
+        d3, d2, dk = f3.to(dev), f2_.to(dev), kp.to(dev)
+        ws = torch.empty(hip.load().ophip_coarse_workspace_floats(1, N, M), device=dev)
+        ids = [torch.empty(N, dtype=torch.int64, device=dev) for _ in range(3)]
+        mconf, mk3, mkc = torch.empty(N, device=dev), torch.empty(N, 3, device=dev), torch.empty(N, 2, device=dev)
+        cnt = torch.full((4,), 7, dtype=torch.int32, device=dev)
+        hip.call("ophip_coarse_match", hip.ptr(d3), hip.ptr(d2), hip.ptr(dk), 0, 1, N, M, wc, 0.08, 0.1, 2, 8.0, None, hip.ptr(ws),
+                 *[hip.ptr(t, torch.int64) for t in ids], hip.ptr(mconf), hip.ptr(mk3), hip.ptr(mkc), None, None, hip.ptr(cnt, torch.int32), 3,
+                 hip.stream_handle())
+        K = int(cnt[0])
+        return K, int(cnt[1]), ids[1][:K].cpu(), ids[2][:K].cpu(), mconf[:K].cpu()
+    # no tie: flag 0, lists equal the eager form's
+    conf_e, ids_e, mconf_e, _, _ = _coarse_match(dev, f3, f2, kp, wc, nsplit=3)
+    K, flag, i_l, j_l, m_l = lazy_call(f2)
+    assert flag == 0 and K == len(ids_e[1]) == 2 and torch.equal(i_l, ids_e[1].cpu()) and torch.equal(j_l, ids_e[2].cpu()) and torch.equal(m_l, mconf_e.cpu())
+    # border copy + identical interior copy of row 0's descriptor: exact tie, first column masked out
+    f2t = f2.clone()
+    f2t[0, cell(0, 4)] = f3[0, 0] * 1.5
+    f2t[0, cell(3, 4)] = f3[0, 0] * 1.5
+    conf_t, ids_t, _, _, _ = _coarse_match(dev, f3, f2t, kp, wc, nsplit=3)
+    assert conf_t[0, 0, cell(0, 4)].item() == conf_t[0, 0, cell(3, 4)].item() and ids_t[2].tolist() == [cell(3, 4), cell(7, 8), cell(4, 4)]
+    K, flag, i_l, j_l, _ = lazy_call(f2t)
+    assert flag == 1                                   # "run this frame again with a conf buffer"
+    with pytest.raises(ValueError):                    # the exact-f32 mode has no lazy form
+        d3 = f3.to(dev)
+        hip.call("ophip_coarse_match", hip.ptr(d3), hip.ptr(f2.to(dev)), hip.ptr(kp.to(dev)), 0, 1, N, M, wc, 0.08, 0.1, 2, 8.0, None,
+                 hip.ptr(torch.empty(hip.load().ophip_coarse_workspace_floats(1, N, M), device=dev)),
+                 *[hip.ptr(torch.empty(N, dtype=torch.int64, device=dev), torch.int64) for _ in range(3)],
+                 hip.ptr(torch.empty(N, device=dev)), hip.ptr(torch.empty(N, 3, device=dev)), hip.ptr(torch.empty(N, 2, device=dev)), None, None,
+                 hip.ptr(torch.zeros(4, dtype=torch.int32, device=dev), torch.int32), 0, hip.stream_handle())
+
+
 def test_custom_ops_match_the_c_abi(sd, cfg, dev):
     """torch.ops.onepose_hip.* (onepose_st_amd/ops.py) forward to the same C symbols the model runs by default: the eight-wave
     encoder layer (plain and fragment-writing form), coarse matching and the fused fine stage through the ops equal the direct
