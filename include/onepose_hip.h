@@ -229,6 +229,38 @@ int ophip_conv2d_bf16(const void* in_hi, const void* in_lo, int B, int Hin, int 
                       const void* res_hi, const void* res_lo, const float* up, int Hup, int Wup, const float* table,
                       void* out_hi, void* out_lo, float* out_f32, int out_c, int nsplit, void* stream);
 
+/* Row f-3 -- the LoFTR 2D-2D matcher behind the object detector
+ * (src/local_feature_object_detector/local_feature_2D_detector.py:89-144 match_worker; model
+ * src/KeypointFreeSfM/loftr_for_sfm/loftr.py:16-167; its arithmetic lives in the un-vendored submodules/LoFTR and is restated from
+ * the published zju3dv/LoFTR definition: parity unpinned).  Backbone and coarse encoder reuse ophip_conv2d_bf16 /
+ * ophip_encoder_layer_x3w8; what is specific to the two-image matcher:
+ *
+ * ophip_coarse_match_2d: dual-softmax + mutual-nearest between the coarse grids of two images (loftr/utils/coarse_matching.py):
+ *   sim = <f0, f1> / C / temperature exactly (nothing added to the temperature), border removal on all four sides of BOTH grids.
+ *   feat0 [B][L0][256], feat1 [B][L1][256], L0 = h0c * w0c, L1 = h1c * w1c; points0 [B][L0][3] is gathered into mkpts0 [.][3] per
+ *   match (the caller tabulates (x, y, 0) of cell i in image pixels = mkpts0_c); mkpts1_c = (j % w1c, j / w1c) * scale.
+ * Fine stage, batched over all K matches (window W x W on both images, token rows [K][W*W][128] in HBM):
+ *   ophip_fine2_gather       one image's windows: feat_cl [hf*wf][128] channels-last, centre = stride * cell(cell_ids[k]), zero padding
+ *                            (loftr_module/fine_preprocess.py: F.unfold(kernel W, stride, padding W/2) + gather)
+ *   ophip_rows_linear_x3     y[T][N] = act([xa | xb] W^T), split-bf16 MFMA; K = ka + kb in {128, 256}, N in {128, 256};
+ *                            wpack: packing.pack_linear_x3 (ophip_rows_linear_wpack_bytes(K, N) bytes); relu != 0 -> ReLU
+ *   ophip_fine2_attention    LinearAttention (loftr_module/linear_attention.py) per match, 8 heads of 16: q [K][L][128], k, v [K][S][128]
+ *   ophip_rows_layernorm128  y = (residual or 0) + LayerNorm(x) * gamma + beta, rows of 128 features, eps 1e-5
+ *   ophip_fine2_match        FineMatching (utils/fine_matching.py): <f0[centre], f1[r]> / sqrt(128) -> softmax -> expectation over the
+ *                            normalised W x W grid, std; mkpts1_f = mkpts1_c + expectation * scale, scale = (W / 2) * (image h / fine h) */
+int ophip_coarse_match_2d(const float* feat0, const float* feat1, const float* points0, long long points_bstride,
+                          int B, int L0, int L1, int w0c, int w1c, double temperature, float thr, int border_rm, float scale,
+                          float* conf, float* workspace, long long* b_ids, long long* i_ids, long long* j_ids,
+                          float* mconf, float* mkpts0, float* mkpts1_c, long long* m_bids, unsigned char* gt_mask,
+                          int* count, int nsplit, void* stream);
+int ophip_fine2_gather(const float* feat_cl, int hf, int wf, const long long* cell_ids, int K, int wc, int stride, int W, float* out, void* stream);
+size_t ophip_rows_linear_wpack_bytes(int kin, int nout);
+int ophip_rows_linear_x3(const float* xa, int ka, const float* xb, int kb, int T, const void* wpack, int nout, int relu, float* y, void* stream);
+int ophip_fine2_attention(const float* q, const float* k, const float* v, int K, int L, int S, float* msg, void* stream);
+int ophip_rows_layernorm128(const float* x, const float* gamma, const float* beta, const float* residual, int T, float* y, void* stream);
+int ophip_fine2_match(const float* f0, const float* f1, const float* mkpts1_c, int K, int W, float scale, float* expec_f, float* mkpts1_f,
+                      void* stream);
+
 /* Row f-2 -- the query crop of the frame loop (local_feature_2D_detector.py:164-190 crop_img_by_bbox, called from
  * detect :208-247 and previous_pose_detect :249-280): box [x0, y0, x1, y1) of a grayscale uint8 frame [H][W] -> out [S][S]
  * float in [0, 1] (= the reference's two cv2.warpAffine passes + astype(float32) / 255: integer-shift crop, then isotropic

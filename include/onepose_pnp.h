@@ -37,6 +37,13 @@ long long oppnp_pool_submit(void* pool, const double* K, const float* pts2d, con
 long long oppnp_pool_wait_all(void* pool);
 int oppnp_pool_result(void* pool, long long ticket, double* pose_out, int* n_inliers);
 
+/* The detector's 2D affinity: replaces cv2.estimateAffine2D(src, dst, method=RANSAC, ransacReprojThreshold=thr)
+ * (src/local_feature_object_detector/local_feature_2D_detector.py:120-122; OpenCV defaults: 2 000 trials at most, confidence 0.99).
+ * src, dst [n][2] floats; affine2x3 row-major [a b tx; c d ty] with dst = A src + t; inlier_mask n bytes (may be NULL).
+ * Returns 0, 1 when no model was found (fewer than 3 points / inliers: affine = identity), -1 on invalid arguments. */
+int oppnp_estimate_affine2d(const float* src, const float* dst, int n, double reproj_thr, int max_iters, double confidence,
+                            unsigned long long seed, double* affine2x3, unsigned char* inlier_mask, int* n_inliers);
+
 #ifdef __cplusplus
 }
 #endif

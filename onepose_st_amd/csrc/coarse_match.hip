@@ -770,6 +770,9 @@ struct SelectArgs {
     const float* kpts;          // [B][N][3]
     long long kpts_bs;          // batch stride of kpts in floats (0 for a shared object block)
     int B, N, M, nspan, wc, border;
+    int border_mode;            // 0: OnePose++ (top rows / left columns of the query grid only: coarse_matching.py:19-20 slices -b:0 are empty);
+                                // 1: LoFTR (all four sides of BOTH grids: loftr/utils/coarse_matching.py mask_border)
+    int wi;                     // border_mode 1: width of the i grid (N = hi * wi)
     float thr, scale;
     long long* b_ids; long long* i_ids; long long* j_ids;
     float* mconf; float* mk3d; float* mkq;
@@ -830,9 +833,18 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs p) {
             for (int it = 0; it < SEL_IT; ++it) {
                 const int i = ib + it * 1024 + tid;
                 const float vv = v[it];
-                auto inside = [&](int jj) { return (jj / p.wc >= p.border) && (jj % p.wc >= p.border); };
+                auto inside = [&](int jj) {
+                    const int jy = jj / p.wc, jx = jj % p.wc;
+                    if (p.border_mode == 0) return (jy >= p.border) && (jx >= p.border);
+                    return jy >= p.border && jx >= p.border && jy < p.M / p.wc - p.border && jx < p.wc - p.border;
+                };
                 bool o = false;
-                if (i < p.N && vv > p.thr) {
+                bool i_ok = true;
+                if (p.border_mode == 1) {
+                    const int iy = i / p.wi, ix = i % p.wi;
+                    i_ok = iy >= p.border && ix >= p.border && iy < p.N / p.wi - p.border && ix < p.wi - p.border;
+                }
+                if (i < p.N && vv > p.thr && i_ok) {
                     o = inside(j[it]) && vv == cm[it];
                     if (!o && c[it] > 1) {
                         // exact tie of the row maximum: the reference takes the first j whose mask is true
@@ -930,7 +942,8 @@ void frag_plane_ptrs(float* workspace, int B, int N, int M, char** a, char** b) 
 }
 
 // parts: 1 = similarity / confidence kernels, 2 = select (threshold, mutual test, compaction), 3 = both
-int coarse_impl(int parts, const float* feat3d, const float* feat2d, const float* keypoints3d, long long kpts_bstride,
+int coarse_impl(int parts, int border_mode, int wi, double temp_eps,
+                const float* feat3d, const float* feat2d, const float* keypoints3d, long long kpts_bstride,
                 int B, int N, int M, int wc, double temperature, float thr, int border_rm, float scale,
                 float* conf, float* workspace, long long* b_ids, long long* i_ids, long long* j_ids,
                 float* mconf, float* mkpts3d, float* mkpts_c, long long* m_bids, unsigned char* gt_mask,
@@ -939,6 +952,7 @@ int coarse_impl(int parts, const float* feat3d, const float* feat2d, const float
         return ophip_bad_arg(__func__, "null pointer");
     const bool lazy = conf == nullptr;               // conf_matrix not requested: nothing N x M is stored (bf16 modes)
     if (B < 1 || N < 1 || M < 1 || wc < 1 || M % wc != 0) return ophip_bad_arg(__func__, "bad sizes (need M == hc * wc)");
+    if (border_mode == 1 && (wi < 1 || N % wi != 0)) return ophip_bad_arg(__func__, "bad sizes (need N == h0c * w0c)");
     const bool planes_ready = (nsplit & OPHIP_COARSE_PLANES_READY) != 0;       // the caller wrote the fragment planes (ophip_coarse_frag_planes)
     nsplit &= ~OPHIP_COARSE_PLANES_READY;
     if (nsplit != 0 && nsplit != 1 && nsplit != 3) return ophip_bad_arg(__func__, "nsplit must be 0 (exact f32), 1 (bf16) or 3 (split bf16)");
@@ -969,7 +983,7 @@ int coarse_impl(int parts, const float* feat3d, const float* feat2d, const float
             OPHIP_LAUNCH("frag_planes", stream, frag_planes_kernel, dim3(16 * (ntr + ntc), B), dim3(256), 0, stream, fr);
             OPHIP_CHECK_LAUNCH();
         }
-        sf = SimFragArgs{fa_, fb_, conf, rowpart, colpart, N, M, ntr, ntc, (float)(temperature + 1e-4), ophip_stamp_buffer(),
+        sf = SimFragArgs{fa_, fb_, conf, rowpart, colpart, N, M, ntr, ntc, (float)(temperature + temp_eps), ophip_stamp_buffer(),
                          rowstat, colstat, rowlog, collog, rowbest, reinterpret_cast<unsigned*>(colmax), thr, logf(thr) - 1e-3f};
 #define OPHIP_SIM_CASE(NS_, MODE_, NAME_)                                                                                          \
         {                                                                                                                          \
@@ -980,7 +994,7 @@ int coarse_impl(int parts, const float* feat3d, const float* feat2d, const float
         else { if (nsplit == 3) OPHIP_SIM_CASE(3, 0, "sim_stats") else OPHIP_SIM_CASE(1, 0, "sim_stats") }
         OPHIP_CHECK_LAUNCH();
     } else if (parts & 1) {
-        SimArgs sa{feat3d, feat2d, conf, rowpart, colpart, N, M, ntr, ntc, (float)(temperature + 1e-4), ophip_stamp_buffer()};
+        SimArgs sa{feat3d, feat2d, conf, rowpart, colpart, N, M, ntr, ntc, (float)(temperature + temp_eps), ophip_stamp_buffer()};
         // dynamic LDS = max(operand tiles, S staging image of the epilogue)
         const size_t tiles = (size_t)(TM + TN) * LDT * sizeof(float);
         const size_t lds = tiles > SIM_STAGE_BYTES ? tiles : SIM_STAGE_BYTES;
@@ -1009,7 +1023,7 @@ int coarse_impl(int parts, const float* feat3d, const float* feat2d, const float
         OPHIP_CHECK_LAUNCH();
     }
     if (parts & 2) {
-        SelectArgs se{conf, rowbest, colmax, keypoints3d, kpts_bstride, B, N, M, sel_nspan, wc, border_rm, thr, scale,
+        SelectArgs se{conf, rowbest, colmax, keypoints3d, kpts_bstride, B, N, M, sel_nspan, wc, border_rm, border_mode, wi, thr, scale,
                       b_ids, i_ids, j_ids, mconf, mkpts3d, mkpts_c, m_bids, gt_mask, count};      // (conf == NULL: an exact row tie sets count[1])
         OPHIP_LAUNCH("select", stream, select_kernel, dim3(SEL_IT), dim3(1024), 0, stream, se);
         OPHIP_CHECK_LAUNCH();
@@ -1031,7 +1045,7 @@ extern "C" int ophip_coarse_match(const float* feat3d, const float* feat2d, cons
                                   float* conf, float* workspace, long long* b_ids, long long* i_ids, long long* j_ids,
                                   float* mconf, float* mkpts3d, float* mkpts_c, long long* m_bids, unsigned char* gt_mask,
                                   int* count, int nsplit, void* stream) {
-    return coarse_impl(3, feat3d, feat2d, keypoints3d, kpts_bstride, B, N, M, wc, temperature, thr, border_rm, scale, conf, workspace,
+    return coarse_impl(3, 0, 0, 1e-4, feat3d, feat2d, keypoints3d, kpts_bstride, B, N, M, wc, temperature, thr, border_rm, scale, conf, workspace,
                        b_ids, i_ids, j_ids, mconf, mkpts3d, mkpts_c, m_bids, gt_mask, count, nsplit, stream);
 }
 
@@ -1043,7 +1057,7 @@ extern "C" int ophip_coarse_match_conf(const float* feat3d, const float* feat2d,
                                        float* conf, float* workspace, long long* b_ids, long long* i_ids, long long* j_ids,
                                        float* mconf, float* mkpts3d, float* mkpts_c, long long* m_bids, unsigned char* gt_mask,
                                        int* count, int nsplit, void* stream) {
-    return coarse_impl(1, feat3d, feat2d, keypoints3d, kpts_bstride, B, N, M, wc, temperature, thr, border_rm, scale, conf, workspace,
+    return coarse_impl(1, 0, 0, 1e-4, feat3d, feat2d, keypoints3d, kpts_bstride, B, N, M, wc, temperature, thr, border_rm, scale, conf, workspace,
                        b_ids, i_ids, j_ids, mconf, mkpts3d, mkpts_c, m_bids, gt_mask, count, nsplit, stream);
 }
 
@@ -1052,6 +1066,21 @@ extern "C" int ophip_coarse_match_select(const float* feat3d, const float* feat2
                                          float* conf, float* workspace, long long* b_ids, long long* i_ids, long long* j_ids,
                                          float* mconf, float* mkpts3d, float* mkpts_c, long long* m_bids, unsigned char* gt_mask,
                                          int* count, int nsplit, void* stream) {
-    return coarse_impl(2, feat3d, feat2d, keypoints3d, kpts_bstride, B, N, M, wc, temperature, thr, border_rm, scale, conf, workspace,
+    return coarse_impl(2, 0, 0, 1e-4, feat3d, feat2d, keypoints3d, kpts_bstride, B, N, M, wc, temperature, thr, border_rm, scale, conf, workspace,
                        b_ids, i_ids, j_ids, mconf, mkpts3d, mkpts_c, m_bids, gt_mask, count, nsplit, stream);
+}
+
+// LoFTR's 2D-2D coarse matching (loftr/utils/coarse_matching.py of the un-vendored submodule, called at
+// src/KeypointFreeSfM/loftr_for_sfm/loftr.py:74): the same dual-softmax + mutual-nearest stage between the coarse grids of TWO
+// images -- sim = <f0, f1> / C / temperature (no 1e-4 added), border removal on all four sides of both grids.
+// feat0 [B][L0][256], feat1 [B][L1][256], L0 = h0c * w0c, L1 = h1c * w1c.  points0 [B][L0][3]: a caller-made table whose row i is
+// gathered into mkpts0 for every match (the detector passes (x, y, 0) of cell i times the image / grid scale = mkpts0_c); mkpts1_c
+// is computed as (j % w1c, j / w1c) * scale.  Other arguments as ophip_coarse_match (conf may be NULL: lazy form).
+extern "C" int ophip_coarse_match_2d(const float* feat0, const float* feat1, const float* points0, long long points_bstride,
+                                     int B, int L0, int L1, int w0c, int w1c, double temperature, float thr, int border_rm, float scale,
+                                     float* conf, float* workspace, long long* b_ids, long long* i_ids, long long* j_ids,
+                                     float* mconf, float* mkpts0, float* mkpts1_c, long long* m_bids, unsigned char* gt_mask,
+                                     int* count, int nsplit, void* stream) {
+    return coarse_impl(3, 1, w0c, 0.0, feat0, feat1, points0, points_bstride, B, L0, L1, w1c, temperature, thr, border_rm, scale, conf, workspace,
+                       b_ids, i_ids, j_ids, mconf, mkpts0, mkpts1_c, m_bids, gt_mask, count, nsplit, stream);
 }

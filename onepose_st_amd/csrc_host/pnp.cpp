@@ -1157,3 +1157,89 @@ extern "C" int oppnp_pool_result(void* pool_, long long ticket, double* pose_out
     if (n_inliers) *n_inliers = r.n_inliers;
     return r.rc;
 }
+
+// ---- 2D affinity by RANSAC: the detector's box estimate -----------------------------------------------------------------------
+// Replaces cv2.estimateAffine2D(mkpts0, mkpts1, method=cv2.RANSAC, ransacReprojThreshold=6) of the reference's match_worker
+// (src/local_feature_object_detector/local_feature_2D_detector.py:120-122).  OpenCV is absent: own estimator, same model (six
+// parameters, dst = A src + t), same inlier rule (distance below the threshold), OpenCV's defaults as defaults (2 000 trials at
+// most, confidence 0.99); minimal samples of three non-collinear points, adaptive stop, least squares on the winning inlier set.
+// Deterministic for a seed.  Parity with OpenCV's sampling sequence is unpinned.
+namespace {
+bool affine_from3(const float* s, const float* d, const int* idx, double* A) {
+    const double x0 = s[2 * idx[0]], y0 = s[2 * idx[0] + 1], x1 = s[2 * idx[1]], y1 = s[2 * idx[1] + 1], x2 = s[2 * idx[2]], y2 = s[2 * idx[2] + 1];
+    const double det = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
+    const double scale = std::fabs(x1 - x0) + std::fabs(y1 - y0) + std::fabs(x2 - x0) + std::fabs(y2 - y0);
+    if (!(std::fabs(det) > 1e-9 * scale * scale) || !(scale > 0.0)) return false;
+    for (int r = 0; r < 2; ++r) {
+        const double u0 = d[2 * idx[0] + r], u1 = d[2 * idx[1] + r], u2 = d[2 * idx[2] + r];
+        const double a = ((u1 - u0) * (y2 - y0) - (u2 - u0) * (y1 - y0)) / det;
+        const double b = ((x1 - x0) * (u2 - u0) - (x2 - x0) * (u1 - u0)) / det;
+        A[3 * r] = a; A[3 * r + 1] = b; A[3 * r + 2] = u0 - a * x0 - b * y0;
+    }
+    return true;
+}
+int affine_inliers(const float* s, const float* d, int n, const double* A, double thr2, unsigned char* mask) {
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) {
+        const double ex = A[0] * s[2 * i] + A[1] * s[2 * i + 1] + A[2] - d[2 * i], ey = A[3] * s[2 * i] + A[4] * s[2 * i + 1] + A[5] - d[2 * i + 1];
+        const bool in = ex * ex + ey * ey < thr2;
+        if (mask) mask[i] = in ? 1 : 0;
+        cnt += in;
+    }
+    return cnt;
+}
+}  // namespace
+
+extern "C" int oppnp_estimate_affine2d(const float* src, const float* dst, int n, double reproj_thr, int max_iters, double confidence,
+                                       unsigned long long seed, double* affine2x3, unsigned char* inlier_mask, int* n_inliers) {
+    if (!affine2x3 || (n > 0 && (!src || !dst)) || max_iters < 1 || !(reproj_thr > 0.0)) return -1;
+    const double ident[6] = {1, 0, 0, 0, 1, 0};
+    std::memcpy(affine2x3, ident, sizeof(ident));
+    if (inlier_mask && n > 0) std::memset(inlier_mask, 0, (size_t)n);
+    if (n_inliers) *n_inliers = 0;
+    if (n < 3) return 1;
+    Rng rng(seed);
+    const double thr2 = reproj_thr * reproj_thr;
+    std::vector<unsigned char> mask((size_t)n), best_mask((size_t)n, 0);
+    int best = 0, needed = max_iters;
+    for (int it = 0; it < needed && it < max_iters; ++it) {
+        int idx[3];
+        for (int k = 0; k < 3;) {
+            const int c = rng.below(n);
+            bool dup = false;
+            for (int j = 0; j < k; ++j) dup |= idx[j] == c;
+            if (!dup) idx[k++] = c;
+        }
+        double A[6];
+        if (!affine_from3(src, dst, idx, A)) continue;
+        const int cnt = affine_inliers(src, dst, n, A, thr2, mask.data());
+        if (cnt > best) {
+            best = cnt;
+            best_mask = mask;
+            const double w = (double)cnt / n, pw = w * w * w;
+            needed = pw > 1.0 - 1e-12 ? 1 : (pw > 1e-12 ? (int)std::ceil(std::log(1.0 - confidence) / std::log(1.0 - pw)) : max_iters);
+        }
+    }
+    if (best < 3) return 1;
+    // least squares on the inliers: normal equations of [x y 1] shared by both rows
+    double S[9] = {0}, bu[3] = {0}, bv[3] = {0};
+    for (int i = 0; i < n; ++i) {
+        if (!best_mask[i]) continue;
+        const double p[3] = {src[2 * i], src[2 * i + 1], 1.0};
+        for (int a = 0; a < 3; ++a) {
+            for (int b = 0; b < 3; ++b) S[a * 3 + b] += p[a] * p[b];
+            bu[a] += p[a] * dst[2 * i];
+            bv[a] += p[a] * dst[2 * i + 1];
+        }
+    }
+    if (std::fabs(det3(S)) < 1e-12) return 1;
+    double Si[9];
+    inv3(S, Si);
+    for (int a = 0; a < 3; ++a) {
+        affine2x3[a] = Si[a * 3] * bu[0] + Si[a * 3 + 1] * bu[1] + Si[a * 3 + 2] * bu[2];
+        affine2x3[3 + a] = Si[a * 3] * bv[0] + Si[a * 3 + 1] * bv[1] + Si[a * 3 + 2] * bv[2];
+    }
+    if (inlier_mask) std::memcpy(inlier_mask, best_mask.data(), (size_t)n);
+    if (n_inliers) *n_inliers = best;
+    return 0;
+}

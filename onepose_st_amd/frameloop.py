@@ -12,8 +12,9 @@ What the reference does per sequence (``inference.py:100-190``) with the pieces 
   (``metric_utils.py:121-209`` with reprojection error 7, scale 1000).
 
 Here the crop runs on the GPU from the uploaded uint8 frame (``ophip_crop_resize_gray``), the matcher is the HIP path and
-PnP the C++ solver.  The 2D-2D LoFTR detector (row f-3) is *not* part of this build: ``SequenceRunner`` takes it as a
-callable.  ``.npz`` files are read with ``allow_pickle=False``.
+PnP the C++ solver.  ``SequenceRunner`` takes the object detector as a callable ``detector(frame, t) -> box``: the LoFTR 2D-2D
+detector of row f-3 is :class:`onepose_st_amd.detector.LocalFeatureObjectDetector` (its ``__call__``).  ``.npz`` files are read
+with ``allow_pickle=False``.
 """
 from __future__ import annotations
 

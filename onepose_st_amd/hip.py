@@ -79,6 +79,14 @@ _SIGNATURES = {
     "ophip_fine_bf16_wpack_bytes": (ctypes.c_size_t, [c_i]),
     "ophip_fine_refine_bf16": (c_i, [c_f, c_ll, c_ll, c_ll, c_ll, c_i, c_i, c_f, c_ll, c_ll, c_f, c_f, c_f, c_f, c_i,
                                      c_f, c_f, c_i, ctypes.c_uint, c_i, c_i, c_i, c_i, ctypes.c_float, c_f, c_f, c_f, c_f, ctypes.c_void_p]),
+    "ophip_coarse_match_2d": (c_i, [c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_i, c_i, ctypes.c_double, ctypes.c_float, c_i, ctypes.c_float,
+                                    c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, ctypes.c_void_p]),
+    "ophip_fine2_gather": (c_i, [c_f, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f, ctypes.c_void_p]),
+    "ophip_rows_linear_wpack_bytes": (ctypes.c_size_t, [c_i, c_i]),
+    "ophip_rows_linear_x3": (c_i, [c_f, c_i, c_f, c_i, c_i, c_f, c_i, c_i, c_f, ctypes.c_void_p]),
+    "ophip_fine2_attention": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f, ctypes.c_void_p]),
+    "ophip_rows_layernorm128": (c_i, [c_f, c_f, c_f, c_f, c_i, c_f, ctypes.c_void_p]),
+    "ophip_fine2_match": (c_i, [c_f, c_f, c_f, c_i, c_i, ctypes.c_float, c_f, c_f, ctypes.c_void_p]),
     "ophip_conv_wpack_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "ophip_stem_conv7": (c_i, [c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_i, ctypes.c_void_p]),
     "ophip_conv2d_bf16": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_i, c_i, c_f,

@@ -92,6 +92,13 @@ def split_planes(flat: torch.Tensor):
     return hi, lo
 
 
+def pack_linear_x3(w: torch.Tensor) -> torch.Tensor:
+    """uint8 block ``[hi fragments][lo fragments]`` of one ``Linear`` weight ``[out, in]`` for ``ophip_rows_linear_x3``
+    (16-k fragment order of :func:`pack_linear_frag16`, split-bf16 planes)."""
+    hi, lo = split_planes(pack_linear_frag16(w))
+    return _bytes(hi, lo)
+
+
 def _bytes(*tensors) -> torch.Tensor:
     return torch.cat([t.contiguous().view(torch.uint8).reshape(-1) for t in tensors])
 

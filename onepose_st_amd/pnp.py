@@ -47,6 +47,9 @@ def load():
         lib.oppnp_pool_wait_all.argtypes = [ctypes.c_void_p]
         lib.oppnp_pool_result.restype = ctypes.c_int
         lib.oppnp_pool_result.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+        lib.oppnp_estimate_affine2d.restype = ctypes.c_int
+        lib.oppnp_estimate_affine2d.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double,
+                                                ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
         if lib.oppnp_abi_version() != 2:
             raise RuntimeError("libonepose_pnp.so ABI version mismatch")
         _lib = lib
@@ -116,6 +119,25 @@ def ransac_PnP(K, pts_2d, pts_3d, scale=1, pnp_reprojection_error=5, img_hw=None
     pose_homo = np.concatenate([pose, np.array([[0.0, 0.0, 0.0, 1.0]])], axis=0)
     inliers = np.nonzero(mask[:n])[0].astype(np.int64) if rc == 0 else np.array([], dtype=np.int64)
     return pose, pose_homo, inliers
+
+
+def estimate_affine2d(src, dst, ransac_reproj_threshold=6.0, max_iters=2000, confidence=0.99, seed=1):
+    """``cv2.estimateAffine2D(src, dst, method=cv2.RANSAC, ransacReprojThreshold=...)`` as the reference's detector calls it
+    (``local_feature_2D_detector.py:120-122``): -> ``(affine [2, 3] float64 or None, inliers [n, 1] uint8)``."""
+    lib = load()
+    s = np.ascontiguousarray(np.asarray(src, dtype=np.float32).reshape(-1, 2))
+    d = np.ascontiguousarray(np.asarray(dst, dtype=np.float32).reshape(-1, 2))
+    if s.shape != d.shape:
+        raise ValueError("src and dst must have the same shape")
+    n = s.shape[0]
+    A = np.zeros((2, 3), dtype=np.float64)
+    mask = np.zeros(max(n, 1), dtype=np.uint8)
+    n_in = ctypes.c_int(0)
+    rc = lib.oppnp_estimate_affine2d(s.ctypes.data, d.ctypes.data, n, float(ransac_reproj_threshold), int(max_iters), float(confidence),
+                                     int(seed), A.ctypes.data, mask.ctypes.data, ctypes.byref(n_in))
+    if rc < 0:
+        raise ValueError("oppnp_estimate_affine2d: invalid arguments")
+    return (A if rc == 0 else None), mask[:n].reshape(-1, 1)
 
 
 class PnPPool:

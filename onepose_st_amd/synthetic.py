@@ -76,6 +76,28 @@ def make_synthetic_state_dict(seed: int = 0, config: dict | None = None, backbon
     return {k: v.float().contiguous() for k, v in sd.items()}
 
 
+def make_synthetic_loftr_state_dict(seed: int = 0, n_coarse: int = 8, n_fine: int = 2) -> dict:
+    """Seeded weights with the key layout of ``LoFTR_for_OnePose_Plus`` (``loftr_for_sfm/loftr.py:16-31``: ``backbone.*``,
+    ``loftr_coarse.layers.{0..7}.*``, ``loftr_fine.layers.{0,1}.*``; what ``build_2D_match_model`` loads strictly)."""
+    gen = torch.Generator().manual_seed(seed)
+    sd: dict = {}
+    torch_state = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    bb = build_backbone({"type": "ResNetFPN", "resolution": [8, 2],
+                         "resnetfpn": {"block_type": "BasicBlock", "initial_dim": 128, "block_dims": [128, 196, 256], "output_layers": [3, 1]}})
+    torch.random.set_rng_state(torch_state)
+    for k, v in bb.state_dict().items():
+        v = v.clone()
+        if k.endswith("running_mean"):
+            v = 0.05 * torch.randn(v.shape, generator=gen)
+        elif k.endswith("running_var"):
+            v = 1.0 + 0.1 * torch.rand(v.shape, generator=gen)
+        sd["backbone." + k] = v
+    _encoder_state(gen, "loftr_coarse", 256, n_coarse, sd)
+    _encoder_state(gen, "loftr_fine", 128, n_fine, sd)
+    return {k: v.float().contiguous() for k, v in sd.items()}
+
+
 # ----------------------------------------------------------------------------------------------
 # inputs
 # ----------------------------------------------------------------------------------------------
