@@ -492,7 +492,6 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_pair_kern
         const bf16x8* w_hi = reinterpret_cast<const bf16x8*>(p.wpack);
         const bf16x8* w_lo = w_hi + W_ELEMS / 8;
         rq.fill(w_hi + OQ + (size_t)ft * TS + lane, w_lo + OQ + (size_t)ft * TS + lane, TS);
-        rkv.fill(w_hi + OKV + (size_t)(2 * ft) * TS + lane, w_lo + OKV + (size_t)(2 * ft) * TS + lane, TS);
     }
 
     // ---- gather both matches into the f32 staging image (all loads issued before the first LDS write) -------------------
@@ -606,6 +605,7 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_pair_kern
         f32x16 q[1][2] = {{zero16(), zero16()}};
         {
             const int ln_ = opaque(lane);
+            rkv.fill(w_hi + OKV + (size_t)(2 * ft) * TS + ln_, w_lo + OKV + (size_t)(2 * ft) * TS + ln_, TS);      // travels under the Q GEMM
             gemm_bf16_ring<1, 2, NS, true, KB, 2>(q, rq, w_hi + OQ + (size_t)ft * TS + ln_, w_lo + OQ + (size_t)ft * TS + ln_, TS, XH, XL, ROWB, 0, lane);
         }
         OPHIP_STAMP(p.stamps, blockIdx.x, 2 + 8 * l);
@@ -731,7 +731,6 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_pair_kern
             const bf16x8* n_lo = n_hi + W_ELEMS / 8;
             const int ln_ = opaque(lane);
             rq.fill(n_hi + OQ + (size_t)ft * TS + ln_, n_lo + OQ + (size_t)ft * TS + ln_, TS);
-            rkv.fill(n_hi + OKV + (size_t)(2 * ft) * TS + ln_, n_lo + OKV + (size_t)(2 * ft) * TS + ln_, TS);
         }
         layernorm_pair(o, ln + 2 * CF, ln + 3 * CF, scratch, ft, lane);  // its first barrier: every wave is done reading the hidden planes
 #pragma unroll
