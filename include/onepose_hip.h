@@ -164,6 +164,43 @@ int ophip_fine_refine_bf16(const float* feat_f, long long fs_b, long long fs_c, 
                            int wc, int stride, float fine_scale, float* expec_f, float* mkpts_f,
                            float* dbg_win, float* dbg_f3, void* stream);
 
+/* Padded / resized query images (datasets with img_pad / img_resize; the demo config has neither).  The reference's forward takes
+ * two optional inputs (OnePosePlusModel.py:104,156-158):
+ *   data["query_image_mask"] [B][hc][wc] bool, 1 = real cell, 0 = padding  -> query_mask [B][M] bytes (flatten(-2));
+ *   data["query_image_scale"] [B][2] f32, (h, w) factors original / resized -> query_scale.
+ * query_mask: in the coarse encoder the 2D stream's padded rows are masked as queries AND as sources (transformer.py:148-159 passes it
+ * as x_mask / source_mask, linear_attention.py:49-53 zeroes phi(Q) resp. phi(K), V of those rows; v_length stays the padded length);
+ * in coarse matching -1e9 is added to the padded cells' columns of the similarity (coarse_matching.py:108-114: their confidences
+ * are exactly 0).  query_scale: mkpts_query_c = (x, y) * scale * query_scale[b][[1, 0]] (coarse_matching.py:224) and the fine offset
+ * is multiplied by the same factors (fine_matching.py:104).  The *_masked / *_scaled entry points below are the plain ones with
+ * these pointers added; the mask / scale must not be NULL in the encoder / fine variants (call the plain entry point instead),
+ * either may be NULL in ophip_coarse_match_masked (parts: 3 = whole stage, 1 = the _conf half, 2 = the _select half). */
+int ophip_encoder_layer_masked(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
+                               const float* wpack, int is_cross, float* workspace, const unsigned char* query_mask, void* stream);
+int ophip_encoder_layer_bf16_masked(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
+                                    const void* wpack, const void* wpack_next, int nsplit, int is_cross, int kv_from_prev, int slot,
+                                    void* workspace, const unsigned char* query_mask, void* stream);
+int ophip_encoder_layer_x3w8_masked(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
+                                    const void* wpack, const void* wpack_next, int is_cross, int kv_from_prev, int slot,
+                                    void* workspace, const unsigned char* query_mask, void* stream);
+int ophip_coarse_match_masked(const float* feat3d, const float* feat2d, const float* keypoints3d, long long kpts_bstride,
+                              int B, int N, int M, int wc, double temperature, float thr, int border_rm, float scale,
+                              float* conf, float* workspace, long long* b_ids, long long* i_ids, long long* j_ids,
+                              float* mconf, float* mkpts3d, float* mkpts_c, long long* m_bids, unsigned char* gt_mask,
+                              int* count, int nsplit, int parts, const unsigned char* query_mask, const float* query_scale, void* stream);
+int ophip_fine_refine_scaled(const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x, int hf, int wf,
+                             const float* desc3d_f, long long ds_b, long long ds_c,
+                             const long long* b_ids, const long long* i_ids, const long long* j_ids, const int* count, int max_matches,
+                             const float* mkpts_c, const float* wpack, int nlayers, unsigned cross_bits, int encoder_enable,
+                             int wc, int stride, float fine_scale, float* expec_f, float* mkpts_f,
+                             float* dbg_win, float* dbg_f3, const float* query_scale, void* stream);
+int ophip_fine_refine_bf16_scaled(const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x, int hf, int wf,
+                                  const float* desc3d_f, long long ds_b, long long ds_c,
+                                  const long long* b_ids, const long long* i_ids, const long long* j_ids, const int* count, int max_matches,
+                                  const float* mkpts_c, const void* wpack, int nlayers, unsigned cross_bits, int encoder_enable, int nsplit,
+                                  int wc, int stride, float fine_scale, float* expec_f, float* mkpts_f,
+                                  float* dbg_win, float* dbg_f3, const float* query_scale, void* stream);
+
 /* One call per frame -- OnePosePlus_model.forward after the backbone (OnePosePlusModel.py:115-203), default split-bf16 path:
  * rows a1-a11 on three streams (input kernels | encoder + coarse matching | selection + fine stage) and the read-back of the
  * result block, issued from C (csrc/frame.hip) instead of ~27 separate calls from the host language.

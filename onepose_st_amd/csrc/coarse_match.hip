@@ -33,6 +33,7 @@ struct SimArgs {
     int N, M, ntr, ntc;
     float temp;          // temperature + 1e-4
     unsigned long long* stamps;
+    const unsigned char* colmask;   // [B][M] 1 = real query cell, 0 = padding: -1e9 is added to its column (coarse_matching.py:108-114); NULL: none
 };
 
 // exact-f32 mode keeps libm expf; the bf16 modes (error budget ~1e-5) use v_exp_f32
@@ -115,6 +116,18 @@ __device__ __forceinline__ void sim_epilogue(f32x16 (&acc)[2][2], const SimArgs&
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg)
                 St[(64 * wr + 32 * x + acc_row(reg, h)) * SLD + 64 * wc + 32 * y + r] = FAST ? acc[x][y][reg] * inv_temp : acc[x][y][reg] / p.temp;
+    if (p.colmask) {                                  // sim_matrix += -1e9 on the padded query cells' columns
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int col = j0 + 64 * wc + 32 * y + r;
+            if (col < p.M && !p.colmask[(size_t)b * p.M + col]) {
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) St[(64 * wr + 32 * x + acc_row(reg, h)) * SLD + 64 * wc + 32 * y + r] += -1e9f;
+            }
+        }
+    }
     __syncthreads();
     // ---- S -> conf buffer, whole rows ------------------------------------------------------------
     float* conf = p.conf + (size_t)b * p.N * p.M;
@@ -269,6 +282,7 @@ struct SimFragArgs {
     float* rowbest;              // [B][ntc][N][3] (value, j as float bits, tie count as float bits)
     unsigned* colmax_bits;       // [B][M]
     float thr, logthr_lo;        // strict threshold; logf(thr) - 1e-3: conservative prefilter on the exponent (saves the exponential)
+    const unsigned char* colmask;   // see SimArgs
 };
 
 // XCD-aware tile of this block: label x = blockIdx.x % 8 owns row tiles [r0, r1) (sizes differ by at most one) and walks
@@ -406,13 +420,21 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_frag_kerne
     const bool edge = (i0 + TM > p.N) || (j0 + TN > p.M);
     __syncthreads();                                  // every wave is done reading the operand buffers that St overlays
     float vmax = -INFINITY;
+    float pad[2] = {0.f, 0.f};                        // sim_matrix += -1e9 on the padded query cells' columns (0 elsewhere: exact)
+    if (p.colmask) {
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int col = j0 + 64 * wc + 32 * y + r;
+            pad[y] = (col < p.M && !p.colmask[(size_t)b * p.M + col]) ? -1e9f : 0.f;
+        }
+    }
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const float sv = acc[x][y][reg] * inv_temp;
+                const float sv = acc[x][y][reg] * inv_temp + pad[y];
                 St[(64 * wr + 32 * x + acc_row(reg, h)) * FLD + 64 * wc + 32 * y + r] = sv;
                 vmax = fmaxf(vmax, sv);
             }
@@ -541,7 +563,7 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_frag_kerne
             o[0] = m; o[1] = ctot;
         }
     } else {
-        SimArgs q{nullptr, nullptr, nullptr, p.rowpart, p.colpart, p.N, p.M, p.ntr, p.ntc, p.temp, nullptr};
+        SimArgs q{nullptr, nullptr, nullptr, p.rowpart, p.colpart, p.N, p.M, p.ntr, p.ntc, p.temp, nullptr, nullptr};
         tile_stats_lds<true, FLD>(q, St, tid, i0, j0, b);
     }
     OPHIP_STAMP(p.stamps, wg, 4);
@@ -774,6 +796,7 @@ struct SelectArgs {
                                 // 1: LoFTR (all four sides of BOTH grids: loftr/utils/coarse_matching.py mask_border)
     int wi;                     // border_mode 1: width of the i grid (N = hi * wi)
     float thr, scale;
+    const float* qscale;        // [B][2] query_image_scale (h, w factors; coarse_matching.py:224) or NULL
     long long* b_ids; long long* i_ids; long long* j_ids;
     float* mconf; float* mk3d; float* mkq;
     long long* m_bids;          // optional second copy of b_ids (the reference's 'm_bids')
@@ -887,8 +910,11 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs p) {
                     p.b_ids[pos] = b; p.i_ids[pos] = i; p.j_ids[pos] = j[it];
                     p.mconf[pos] = v[it];
                     p.mk3d[3 * pos] = kx[it]; p.mk3d[3 * pos + 1] = ky[it]; p.mk3d[3 * pos + 2] = kz[it];
-                    p.mkq[2 * pos] = (float)(j[it] % p.wc) * p.scale;
-                    p.mkq[2 * pos + 1] = (float)(j[it] / p.wc) * p.scale;
+                    // scale_total = scale * query_image_scale[b][[1, 0]] (f32), then (x, y) * scale_total
+                    const float sx = p.qscale ? __fmul_rn(p.scale, p.qscale[2 * b + 1]) : p.scale;
+                    const float sy = p.qscale ? __fmul_rn(p.scale, p.qscale[2 * b]) : p.scale;
+                    p.mkq[2 * pos] = (float)(j[it] % p.wc) * sx;
+                    p.mkq[2 * pos + 1] = (float)(j[it] / p.wc) * sy;
                     if (p.m_bids) p.m_bids[pos] = b;
                     if (p.gt_mask) p.gt_mask[pos] = v[it] == 0.f ? 1 : 0;
                 }
@@ -947,7 +973,7 @@ int coarse_impl(int parts, int border_mode, int wi, double temp_eps,
                 int B, int N, int M, int wc, double temperature, float thr, int border_rm, float scale,
                 float* conf, float* workspace, long long* b_ids, long long* i_ids, long long* j_ids,
                 float* mconf, float* mkpts3d, float* mkpts_c, long long* m_bids, unsigned char* gt_mask,
-                int* count, int nsplit, void* stream_) {
+                int* count, int nsplit, void* stream_, const unsigned char* qmask = nullptr, const float* qscale = nullptr) {
     if (!feat3d || !feat2d || !keypoints3d || !workspace || !b_ids || !i_ids || !j_ids || !mconf || !mkpts3d || !mkpts_c || !count)
         return ophip_bad_arg(__func__, "null pointer");
     const bool lazy = conf == nullptr;               // conf_matrix not requested: nothing N x M is stored (bf16 modes)
@@ -984,7 +1010,7 @@ int coarse_impl(int parts, int border_mode, int wi, double temp_eps,
             OPHIP_CHECK_LAUNCH();
         }
         sf = SimFragArgs{fa_, fb_, conf, rowpart, colpart, N, M, ntr, ntc, (float)(temperature + temp_eps), ophip_stamp_buffer(),
-                         rowstat, colstat, rowlog, collog, rowbest, reinterpret_cast<unsigned*>(colmax), thr, logf(thr) - 1e-3f};
+                         rowstat, colstat, rowlog, collog, rowbest, reinterpret_cast<unsigned*>(colmax), thr, logf(thr) - 1e-3f, qmask};
 #define OPHIP_SIM_CASE(NS_, MODE_, NAME_)                                                                                          \
         {                                                                                                                          \
             if (int rc = ophip_lds_attr(reinterpret_cast<const void*>(sim_frag_kernel<NS_, MODE_>), SIM_FRAG_LDS, "hipFuncSetAttribute(sim_frag)")) return rc; \
@@ -994,7 +1020,7 @@ int coarse_impl(int parts, int border_mode, int wi, double temp_eps,
         else { if (nsplit == 3) OPHIP_SIM_CASE(3, 0, "sim_stats") else OPHIP_SIM_CASE(1, 0, "sim_stats") }
         OPHIP_CHECK_LAUNCH();
     } else if (parts & 1) {
-        SimArgs sa{feat3d, feat2d, conf, rowpart, colpart, N, M, ntr, ntc, (float)(temperature + temp_eps), ophip_stamp_buffer()};
+        SimArgs sa{feat3d, feat2d, conf, rowpart, colpart, N, M, ntr, ntc, (float)(temperature + temp_eps), ophip_stamp_buffer(), qmask};
         // dynamic LDS = max(operand tiles, S staging image of the epilogue)
         const size_t tiles = (size_t)(TM + TN) * LDT * sizeof(float);
         const size_t lds = tiles > SIM_STAGE_BYTES ? tiles : SIM_STAGE_BYTES;
@@ -1023,7 +1049,7 @@ int coarse_impl(int parts, int border_mode, int wi, double temp_eps,
         OPHIP_CHECK_LAUNCH();
     }
     if (parts & 2) {
-        SelectArgs se{conf, rowbest, colmax, keypoints3d, kpts_bstride, B, N, M, sel_nspan, wc, border_rm, border_mode, wi, thr, scale,
+        SelectArgs se{conf, rowbest, colmax, keypoints3d, kpts_bstride, B, N, M, sel_nspan, wc, border_rm, border_mode, wi, thr, scale, qscale,
                       b_ids, i_ids, j_ids, mconf, mkpts3d, mkpts_c, m_bids, gt_mask, count};      // (conf == NULL: an exact row tie sets count[1])
         OPHIP_LAUNCH("select", stream, select_kernel, dim3(SEL_IT), dim3(1024), 0, stream, se);
         OPHIP_CHECK_LAUNCH();
@@ -1068,6 +1094,20 @@ extern "C" int ophip_coarse_match_select(const float* feat3d, const float* feat2
                                          int* count, int nsplit, void* stream) {
     return coarse_impl(2, 0, 0, 1e-4, feat3d, feat2d, keypoints3d, kpts_bstride, B, N, M, wc, temperature, thr, border_rm, scale, conf, workspace,
                        b_ids, i_ids, j_ids, mconf, mkpts3d, mkpts_c, m_bids, gt_mask, count, nsplit, stream);
+}
+
+// ophip_coarse_match with the reference's optional inputs of padded / resized query images: query_mask [B][M] (1 = real cell, 0 = padding;
+// data["query_image_mask"].flatten(-2), coarse_matching.py:108-114: -1e9 is added to the padded cells' columns of the similarity, so
+// their confidences are exactly 0) and query_scale [B][2] = data["query_image_scale"] ((h, w) factors, coarse_matching.py:224: mkpts_query_c
+// = (x, y) * scale * query_scale[b][[1, 0]]).  Either may be NULL.  parts: 3 = the whole stage, 1 / 2 = the _conf / _select halves.
+extern "C" int ophip_coarse_match_masked(const float* feat3d, const float* feat2d, const float* keypoints3d, long long kpts_bstride,
+                                         int B, int N, int M, int wc, double temperature, float thr, int border_rm, float scale,
+                                         float* conf, float* workspace, long long* b_ids, long long* i_ids, long long* j_ids,
+                                         float* mconf, float* mkpts3d, float* mkpts_c, long long* m_bids, unsigned char* gt_mask,
+                                         int* count, int nsplit, int parts, const unsigned char* query_mask, const float* query_scale, void* stream) {
+    if (parts < 1 || parts > 3) return ophip_bad_arg(__func__, "parts must be 1 (conf), 2 (select) or 3 (both)");
+    return coarse_impl(parts, 0, 0, 1e-4, feat3d, feat2d, keypoints3d, kpts_bstride, B, N, M, wc, temperature, thr, border_rm, scale, conf, workspace,
+                       b_ids, i_ids, j_ids, mconf, mkpts3d, mkpts_c, m_bids, gt_mask, count, nsplit, stream, query_mask, query_scale);
 }
 
 // LoFTR's 2D-2D coarse matching (loftr/utils/coarse_matching.py of the un-vendored submodule, called at

@@ -28,6 +28,7 @@ struct KvReduceArgs {
     int tiles[2];
     const f32x4* wkv;      // packed, rows ordered per wave: [w][K heads 2w,2w+1 | V heads 2w,2w+1]
     float* partial;        // [B][tiles0 + tiles1][KV_FLOATS]
+    const unsigned char* mask2d;   // [B][L[1]] 1 = real cell, 0 = padding of the 2D stream (linear_attention.py:49-53); NULL: none
 };
 
 __device__ __forceinline__ void load_x_tile(float* lds, const float* __restrict__ x, int tok0, int L, int tid) {
@@ -57,11 +58,13 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void kv_reduce_kern
     gemm_lds_x_packed<4>(acc, smem + r * LDX + 4 * h, KB, a.wkv + (size_t)(4 * wave) * TSTRIDE + lane, TSTRIDE);
 
     const float flen = (float)L;
+    const unsigned char* mk = (s == 1 && a.mask2d) ? a.mask2d + (size_t)b * L : nullptr;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-            const bool valid = tok0 + acc_row(reg, h) < L;
+            const int tok = tok0 + acc_row(reg, h);
+            const bool valid = tok < L && (!mk || mk[tok]);          // kv_mask: a padded cell's phi(K) row is zero (so is its K^T V term)
             acc[t][reg] = valid ? elu_plus_one(acc[t][reg]) : 0.f;      // phi(K); padded tokens drop out
             acc[2 + t][reg] = acc[2 + t][reg] / flen;                   // values / v_length
         }
@@ -126,6 +129,7 @@ struct AttnArgs {
     float srclen[2];       // length of the source stream feeding stream s
     const f32x4 *wq, *wm, *w0, *w2;
     const float *g1, *b1, *g2, *b2;
+    const unsigned char* mask2d;   // q_mask of the 2D stream (see KvReduceArgs)
 };
 
 __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 1) void attn_apply_kernel(AttnArgs a) {
@@ -152,10 +156,15 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 1) void attn_apply_ker
     {
         f32x16 q[2] = {zero16(), zero16()};
         gemm_lds_x_packed<2>(q, xa, KB, a.wq + (size_t)(2 * wave) * TS + lane, TS);
+        const unsigned char* mk = (s == 1 && a.mask2d) ? a.mask2d + (size_t)b * L : nullptr;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) q[t][reg] = elu_plus_one(q[t][reg]);
+            for (int reg = 0; reg < 16; ++reg) {
+                const int tok = tok0 + acc_row(reg, h);
+                const bool live = !mk || tok >= L || mk[tok];        // q_mask: phi(Q) = 0 => message 0 (rows >= L are never stored)
+                q[t][reg] = live ? elu_plus_one(q[t][reg]) : 0.f;
+            }
             acc_to_lds(q[t], P, LDX, 64 * wave + 32 * t, lane);
         }
     }
@@ -235,8 +244,9 @@ extern "C" size_t ophip_encoder_workspace_floats(int B, int L3d, int L2d) {
     return (size_t)B * tiles * KV_FLOATS + (size_t)B * 2 * KV_FLOATS;
 }
 
-extern "C" int ophip_encoder_layer(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
-                                   const float* wpack, int is_cross, float* workspace, void* stream_) {
+namespace {
+int layer_f32(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
+              const float* wpack, int is_cross, float* workspace, const unsigned char* mask2d, void* stream_) {
     if (!x3d || !x2d || !y3d || !y2d || !wpack || !workspace) return ophip_bad_arg(__func__, "null pointer");
     if (B < 1 || L3d < 1 || L2d < 1) return ophip_bad_arg(__func__, "B, L3d, L2d must be >= 1");
     if (x3d == y3d || x2d == y2d) return ophip_bad_arg(__func__, "in-place layer is not supported (cross layers read the pre-update streams)");
@@ -259,6 +269,7 @@ extern "C" int ophip_encoder_layer(const float* x3d, const float* x2d, float* y3
     ka.tiles[0] = t3; ka.tiles[1] = t2;
     ka.wkv = reinterpret_cast<const f32x4*>(wkv);
     ka.partial = partial;
+    ka.mask2d = mask2d;
     const size_t lds_kv = (size_t)OPHIP_TOK * LDX * sizeof(float);
     OPHIP_LAUNCH("kv_reduce", stream, kv_reduce_kernel, dim3(t3 + t2, B), dim3(256), lds_kv, stream, ka);
     OPHIP_CHECK_LAUNCH();
@@ -281,9 +292,23 @@ extern "C" int ophip_encoder_layer(const float* x3d, const float* x2d, float* y3
     aa.wq = reinterpret_cast<const f32x4*>(wq); aa.wm = reinterpret_cast<const f32x4*>(wm);
     aa.w0 = reinterpret_cast<const f32x4*>(w0); aa.w2 = reinterpret_cast<const f32x4*>(w2);
     aa.g1 = ln; aa.b1 = ln + C; aa.g2 = ln + 2 * C; aa.b2 = ln + 3 * C;
+    aa.mask2d = mask2d;
     const size_t lds_attn = (size_t)OPHIP_TOK * (2 * LDX + LDH) * sizeof(float);
     if (int rc = ophip_lds_attr(reinterpret_cast<const void*>(attn_apply_kernel), lds_attn, "hipFuncSetAttribute(attn_apply)")) return rc;
     OPHIP_LAUNCH("attn_apply", stream, attn_apply_kernel, dim3(t3 + t2, B), dim3(256), lds_attn, stream, aa);
     OPHIP_CHECK_LAUNCH();
     return 0;
+}
+}  // namespace
+
+extern "C" int ophip_encoder_layer(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
+                                   const float* wpack, int is_cross, float* workspace, void* stream) {
+    return layer_f32(x3d, x2d, y3d, y2d, B, L3d, L2d, wpack, is_cross, workspace, nullptr, stream);
+}
+
+// The same layer with the reference's query_mask (transformer.py:148-159, linear_attention.py:49-53): mask2d [B][L2d], 1 = real cell.
+extern "C" int ophip_encoder_layer_masked(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
+                                          const float* wpack, int is_cross, float* workspace, const unsigned char* mask2d, void* stream) {
+    if (!mask2d) return ophip_bad_arg(__func__, "null mask (use ophip_encoder_layer)");
+    return layer_f32(x3d, x2d, y3d, y2d, B, L3d, L2d, wpack, is_cross, workspace, mask2d, stream);
 }

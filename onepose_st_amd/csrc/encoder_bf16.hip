@@ -37,6 +37,7 @@ struct KvRedArgs {
     int slabs[2];                   // 32-token partial slabs per stream (= ceil(L / 32))
     const bf16x8 *w_hi, *w_lo;      // Wkv fragments
     float* partial;                 // [B][slabs0 + slabs1][KV_PART_FLOATS]
+    const unsigned char* mask2d;    // MASKED kernels: [B][L[1]] 1 = real cell, 0 = padding of the 2D stream (linear_attention.py:49-53)
 };
 
 // K, V projection of TT 32-token tiles (rows 0 .. 32 TT - 1 of the planes) for heads 2 fw, 2 fw + 1, then each tile's
@@ -44,7 +45,8 @@ struct KvRedArgs {
 // start beyond L write nothing).  `ring` must be filled from whi / wlo.
 template <int NS, int TT, int HW = 2>      // HW = heads per wave
 __device__ __forceinline__ void kv_slab_from_planes(WRing<2 * HW, 2, NS>& ring, const bf16x8* whi, const bf16x8* wlo, const char* xh, const char* xl,
-                                                    int tok_base, int L, float* out, int fw, int lane, int tstride = TS, int head0 = -1) {
+                                                    int tok_base, int L, float* out, int fw, int lane, int tstride = TS, int head0 = -1,
+                                                    const unsigned char* mk = nullptr) {
     const int r = lane & 31, h = lane >> 5;
     if (head0 < 0) head0 = 2 * fw;
     // D[token][feature]: t < HW -> K of heads head0 + t;  HW + t -> V of the same heads (tiles `tstride` fragments apart)
@@ -63,7 +65,10 @@ __device__ __forceinline__ void kv_slab_from_planes(WRing<2 * HW, 2, NS>& ring, 
     for (int tt = 0; tt < TT; ++tt) {
         const int tb = tok_base + 32 * tt;
         if (tb >= L) break;                                                                                   // wave-uniform
-        auto f_k = [&](int reg, float v) { return tb + acc_row(reg, h) < L ? elu_plus_one_fast(v) : 0.f; };   // padded tokens drop out
+        auto f_k = [&](int reg, float v) {                                                                    // padded tokens (and masked cells: kv_mask) drop out
+            const int tok = tb + acc_row(reg, h);
+            return (tok < L && (!mk || mk[tok])) ? elu_plus_one_fast(v) : 0.f;
+        };
         auto f_v = [&](int reg, float v) { return v * inv_len; };                                             // values / v_length
         float* outt = out + (size_t)tt * KV_PART_FLOATS;
 #pragma unroll
@@ -95,7 +100,7 @@ __device__ __forceinline__ void kv_slab_from_planes(WRing<2 * HW, 2, NS>& ring, 
     }
 }
 
-template <int NS, int TOK>
+template <int NS, int TOK, bool MASKED = false>
 __global__ __launch_bounds__(TOK * 8) OPHIP_WAVES_PER_SIMD(1, 2) void kv_reduce_bf16_kernel(KvRedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PL = NS == 3 ? 2 : 1;
@@ -118,7 +123,8 @@ __global__ __launch_bounds__(TOK * 8) OPHIP_WAVES_PER_SIMD(1, 2) void kv_reduce_
     if (tok0 + 32 * tt >= L) return;                 // second half of a ragged last tile: no tokens, no slab
 
     float* out = a.partial + ((size_t)b * (a.slabs[0] + a.slabs[1]) + (s ? a.slabs[0] : 0) + (TOK / 32) * lt + tt) * KV_PART_FLOATS;
-    kv_slab_from_planes<NS, 1>(ring, whi, wlo, XH + 32 * tt * ROWB, XL + 32 * tt * ROWB, tok0 + 32 * tt, L, out, fw, lane);
+    const unsigned char* mk = (MASKED && s == 1) ? a.mask2d + (size_t)b * L : nullptr;
+    kv_slab_from_planes<NS, 1>(ring, whi, wlo, XH + 32 * tt * ROWB, XL + 32 * tt * ROWB, tok0 + 32 * tt, L, out, fw, lane, TS, -1, mk);
 }
 
 struct KvSumBArgs {
@@ -175,6 +181,7 @@ struct AttnBArgs {
     float* npartial;
     int slabs[2];
     unsigned long long* stamps;
+    const unsigned char* mask2d;   // MASKED kernels: q_mask of the 2D stream (see KvRedArgs)
 };
 
 // LayerNorm over the 256 features of a token held as D[feature][token] accumulators by the 4 feature-group waves
@@ -230,7 +237,7 @@ __device__ __forceinline__ void layernorm_featrow(f32x16 (&m)[2][TT], const floa
     }
 }
 
-template <int NS, int TT>
+template <int NS, int TT, bool MASKED = false>
 __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(TT == 1 ? 2 : 1, TT == 1 ? 2 : 1) void attn_apply_bf16_kernel(AttnBArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PL = NS == 3 ? 2 : 1;
@@ -252,6 +259,7 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(TT == 1 ? 2 : 1, TT == 1 
     const int lt = s ? tile - a.tiles[0] : tile;
     const int L = a.L[s], tok0 = lt * TOK;
     const float* xg = a.x[s] + (size_t)b * a.xbs[s];
+    const unsigned char* mk = (MASKED && s == 1) ? a.mask2d + (size_t)b * L : nullptr;
 
     const bf16x8 *wq_hi = a.w_hi + (size_t)(2 * fw) * TS + lane, *wq_lo = a.w_lo + (size_t)(2 * fw) * TS + lane;
     const bf16x8 *wm_hi = a.w_hi + 3 * C * C / 8 + (size_t)(2 * fw) * TS + lane, *wm_lo = a.w_lo + 3 * C * C / 8 + (size_t)(2 * fw) * TS + lane;
@@ -287,8 +295,10 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(TT == 1 ? 2 : 1, TT == 1 
 #pragma unroll
             for (int tt = 0; tt < TT; ++tt) {
                 num[tt] = zero16(); den[tt] = zero16();
+                bool live = true;                    // q_mask: phi(Q) = 0 for a padded cell => its message is 0
+                if (MASKED && mk) { const int tok = tok0 + 32 * tt + r; live = tok >= L || mk[tok]; }
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) q[t][tt][reg] = elu_plus_one_fast(q[t][tt][reg]);
+                for (int reg = 0; reg < 16; ++reg) q[t][tt][reg] = live ? elu_plus_one_fast(q[t][tt][reg]) : 0.f;
             }
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
@@ -422,7 +432,7 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(TT == 1 ? 2 : 1, TT == 1 
         // ---- kv_reduce of the next layer on the tile that is still on chip (saves a launch and a re-read of the streams) ----
         __syncthreads();
         float* out = a.npartial + ((size_t)b * (a.slabs[0] + a.slabs[1]) + (s ? a.slabs[0] : 0) + TT * lt) * KV_PART_FLOATS;
-        kv_slab_from_planes<NS, TT>(rkv, nhi, nlo, KH, KL, tok0, L, out, fw, lane);
+        kv_slab_from_planes<NS, TT>(rkv, nhi, nlo, KH, KL, tok0, L, out, fw, lane, TS, -1, mk);
     }
     OPHIP_STAMP(a.stamps, wg, 31);
 }
@@ -441,9 +451,10 @@ extern "C" size_t ophip_encoder_bf16_workspace_bytes(int B, int L3d, int L2d) {
 
 extern "C" size_t ophip_encoder_bf16_wpack_bytes(void) { return (size_t)2 * W_ELEMS * 2 + 4 * C * 4; }
 
-extern "C" int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
-                                        const void* wpack, const void* wpack_next, int nsplit, int is_cross, int kv_from_prev, int slot,
-                                        void* workspace, void* stream_) {
+namespace {
+int layer_bf16(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
+               const void* wpack, const void* wpack_next, int nsplit, int is_cross, int kv_from_prev, int slot,
+               void* workspace, const unsigned char* mask2d, void* stream_) {
     if (!x3d || !x2d || !y3d || !y2d || !wpack || !workspace) return ophip_bad_arg(__func__, "null pointer");
     if (B < 1 || L3d < 1 || L2d < 1) return ophip_bad_arg(__func__, "B, L3d, L2d must be >= 1");
     if (nsplit != 1) return ophip_bad_arg(__func__, "nsplit must be 1: this is the plain-bf16 mode's layer (split-bf16: ophip_encoder_layer_x3w8)");
@@ -473,11 +484,17 @@ extern "C" int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, floa
         ka.L[0] = L3d; ka.L[1] = L2d; ka.tiles[0] = s3; ka.tiles[1] = s2; ka.slabs[0] = s3; ka.slabs[1] = s2;
         ka.w_hi = w_hi + C * C / 8; ka.w_lo = w_lo + C * C / 8;
         ka.partial = partial;
+        ka.mask2d = mask2d;
         const size_t lds_kv = (size_t)PL * 32 * ROWB;
 #define OPHIP_KV_CASE(NS_)                                                                                                       \
         {                                                                                                                        \
-            if (int rc = set_lds(kv_reduce_bf16_kernel<NS_, 32>, lds_kv, "hipFuncSetAttribute(kv_reduce_bf16)")) return rc; \
-            OPHIP_LAUNCH("kv_reduce", stream, (kv_reduce_bf16_kernel<NS_, 32>), dim3(s3 + s2, B), dim3(256), lds_kv, stream, ka);  \
+            if (mask2d) {                                                                                                        \
+                if (int rc = set_lds(kv_reduce_bf16_kernel<NS_, 32, true>, lds_kv, "hipFuncSetAttribute(kv_reduce_bf16 masked)")) return rc; \
+                OPHIP_LAUNCH("kv_reduce", stream, (kv_reduce_bf16_kernel<NS_, 32, true>), dim3(s3 + s2, B), dim3(256), lds_kv, stream, ka);  \
+            } else {                                                                                                             \
+                if (int rc = set_lds(kv_reduce_bf16_kernel<NS_, 32>, lds_kv, "hipFuncSetAttribute(kv_reduce_bf16)")) return rc;  \
+                OPHIP_LAUNCH("kv_reduce", stream, (kv_reduce_bf16_kernel<NS_, 32>), dim3(s3 + s2, B), dim3(256), lds_kv, stream, ka); \
+            }                                                                                                                    \
         }
         OPHIP_KV_CASE(1)
 #undef OPHIP_KV_CASE
@@ -506,17 +523,38 @@ extern "C" int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, floa
         aa.nkv_lo = n_hi + W_ELEMS / 8 + C * C / 8;
     }
     aa.stamps = ophip_stamp_buffer();
+    aa.mask2d = mask2d;
     // LDS: X, Y planes + hidden chunk; the fused tail needs the output planes behind the 64 KiB f32 stage
     size_t lds_at = (size_t)PL * (2 * TOK * ROWB + TOK * HROWB);
     const size_t lds_fuse = (size_t)TOK * C * 4 + (size_t)PL * TOK * ROWB;
     if (lds_fuse > lds_at) lds_at = lds_fuse;
 #define OPHIP_AT_CASE(NS_, TT_)                                                                                                  \
     {                                                                                                                            \
-        if (int rc = set_lds(attn_apply_bf16_kernel<NS_, TT_>, lds_at, "hipFuncSetAttribute(attn_apply_bf16)")) return rc; \
-        OPHIP_LAUNCH("attn_apply", stream, (attn_apply_bf16_kernel<NS_, TT_>), dim3(t3 + t2, B), dim3(256), lds_at, stream, aa);    \
+        if (mask2d) {                                                                                                            \
+            if (int rc = set_lds(attn_apply_bf16_kernel<NS_, TT_, true>, lds_at, "hipFuncSetAttribute(attn_apply_bf16 masked)")) return rc; \
+            OPHIP_LAUNCH("attn_apply", stream, (attn_apply_bf16_kernel<NS_, TT_, true>), dim3(t3 + t2, B), dim3(256), lds_at, stream, aa); \
+        } else {                                                                                                                 \
+            if (int rc = set_lds(attn_apply_bf16_kernel<NS_, TT_>, lds_at, "hipFuncSetAttribute(attn_apply_bf16)")) return rc;   \
+            OPHIP_LAUNCH("attn_apply", stream, (attn_apply_bf16_kernel<NS_, TT_>), dim3(t3 + t2, B), dim3(256), lds_at, stream, aa); \
+        }                                                                                                                        \
     }
     OPHIP_AT_CASE(1, 1)
 #undef OPHIP_AT_CASE
     OPHIP_CHECK_LAUNCH();
     return 0;
+}
+}  // namespace
+
+extern "C" int ophip_encoder_layer_bf16(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
+                                        const void* wpack, const void* wpack_next, int nsplit, int is_cross, int kv_from_prev, int slot,
+                                        void* workspace, void* stream) {
+    return layer_bf16(x3d, x2d, y3d, y2d, B, L3d, L2d, wpack, wpack_next, nsplit, is_cross, kv_from_prev, slot, workspace, nullptr, stream);
+}
+
+// The same layer with the reference's query_mask (transformer.py:148-159): mask2d [B][L2d], 1 = real cell, 0 = padding.
+extern "C" int ophip_encoder_layer_bf16_masked(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
+                                               const void* wpack, const void* wpack_next, int nsplit, int is_cross, int kv_from_prev, int slot,
+                                               void* workspace, const unsigned char* mask2d, void* stream) {
+    if (!mask2d) return ophip_bad_arg(__func__, "null mask (use ophip_encoder_layer_bf16)");
+    return layer_bf16(x3d, x2d, y3d, y2d, B, L3d, L2d, wpack, wpack_next, nsplit, is_cross, kv_from_prev, slot, workspace, mask2d, stream);
 }

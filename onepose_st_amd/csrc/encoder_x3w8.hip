@@ -43,6 +43,7 @@ struct EncW8Args {
     unsigned long long* stamps;
     char* frag[2];             // optional: the output rows also as the similarity kernel's operand fragments (csrc/coarse_match.hip:
     int frag_rows[2];          // frag_planes layout, rows padded to frag_rows = a multiple of 128); NULL: not written
+    const unsigned char* mask2d;   // MASKED kernels: [B][L[1]] 1 = real cell, 0 = padding of the 2D stream (linear_attention.py:49-53)
 };
 
 __device__ __forceinline__ int stash_off(int row, int chunk) { return row * (C * 4) + ((chunk ^ (row & 15)) << 4); }
@@ -76,8 +77,9 @@ __device__ __forceinline__ void publish_moments(float* scratch, const float (&s)
 }
 
 // K|V projection of the 48 tokens in the X planes for head fw and its phi(K)^T V / Ksum slab slice
+// (mk: the stream's padding mask or NULL -- kv_mask: a padded cell's phi(K) row is zero, and with it its K^T V term)
 __device__ __forceinline__ void kv_tail(Ring& ring, const WStream& wsk, const char* XH, const char* XL, int tok0, int L, float* __restrict__ out,
-                                        int fw, int lane) {
+                                        int fw, int lane, const unsigned char* mk = nullptr) {
     const int c16 = lane & 15, q = lane >> 4;
     f32x4 kk[4][NTT];            // D[token 4q + r][feature c16]: ft 0, 1 = K of head fw, ft 2, 3 = V
 #pragma unroll
@@ -92,7 +94,8 @@ __device__ __forceinline__ void kv_tail(Ring& ring, const WStream& wsk, const ch
         for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                kk[ft][tt][r] = (tok0 + 16 * tt + 4 * q + r < L) ? elu_plus_one_fast(kk[ft][tt][r]) : 0.f;
+                const int tok = tok0 + 16 * tt + 4 * q + r;
+                kk[ft][tt][r] = (tok < L && (!mk || mk[tok])) ? elu_plus_one_fast(kk[ft][tt][r]) : 0.f;
                 kk[2 + ft][tt][r] *= inv_len;
             }
     const f32x4 z4 = zero4();
@@ -122,7 +125,7 @@ __device__ __forceinline__ void kv_tail(Ring& ring, const WStream& wsk, const ch
     }
 }
 
-template <bool ONLY_KV>
+template <bool ONLY_KV, bool MASKED = false>
 __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kernel(EncW8Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* XH = smem;
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
     const int lt = s ? tile - a.tiles[0] : tile;
     const int L = a.L[s], tok0 = lt * TOK;
     const float* xg = a.x[s] + (size_t)b * a.xbs[s];
+    const unsigned char* mk = (MASKED && s == 1) ? a.mask2d + (size_t)b * L : nullptr;
     const int wg = blockIdx.y * gridDim.x + blockIdx.x;
     float* slab = a.partial + ((size_t)b * (a.tiles[0] + a.tiles[1]) + tile) * KV_PART_FLOATS;
     const int fwu = __builtin_amdgcn_readfirstlane(fw);
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
     }
     __syncthreads();
     if (ONLY_KV) {
-        kv_tail(ring, wsk, XH, XL, tok0, L, slab, fw, lane);
+        kv_tail(ring, wsk, XH, XL, tok0, L, slab, fw, lane, mk);
         return;
     }
     f32x4 xr[2][NTT];
@@ -233,10 +237,12 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
         for (int tt = 0; tt < NTT; ++tt) {
             f32x4 p0, p1;
             float den = 0.f;
+            bool live = true;                        // q_mask: phi(Q) = 0 for a padded cell => its message is 0
+            if (MASKED && mk) { const int tok = tok0 + 16 * tt + c16; live = tok >= L || mk[tok]; }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                p0[r] = elu_plus_one_fast(qa[0][tt][r]);
-                p1[r] = elu_plus_one_fast(qa[1][tt][r]);
+                p0[r] = live ? elu_plus_one_fast(qa[0][tt][r]) : 0.f;
+                p1[r] = live ? elu_plus_one_fast(qa[1][tt][r]) : 0.f;
                 den += p0[r] * ksm[0][r] + p1[r] * ksm[1][r];
             }
             den = sum_over_q(den);
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
     OPHIP_STAMP(a.stamps, wg, 10);
     if (tail) {
         __syncthreads();
-        kv_tail(ring, wsk, XH, XL, tok0, L, slab, fw, lane);
+        kv_tail(ring, wsk, XH, XL, tok0, L, slab, fw, lane, mk);
     }
     OPHIP_STAMP(a.stamps, wg, 11);
     OPHIP_STAMP_REAL(a.stamps, wg, 31);
@@ -447,7 +453,7 @@ extern "C" size_t ophip_encoder_x3w8_wpack_bytes(void) { return (size_t)NW * (MA
 namespace {
 int layer_x3w8(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
                const void* wpack, const void* wpack_next, int is_cross, int kv_from_prev, int slot,
-               void* workspace, void* stream_, void* frag3d, void* frag2d) {
+               void* workspace, void* stream_, void* frag3d, void* frag2d, const unsigned char* mask2d = nullptr) {
     if (!x3d || !x2d || !y3d || !y2d || !wpack || !workspace) return ophip_bad_arg(__func__, "null pointer");
     if (B < 1 || L3d < 1 || L2d < 1) return ophip_bad_arg(__func__, "B, L3d, L2d must be >= 1");
     if (slot != 0 && slot != 1) return ophip_bad_arg(__func__, "slot must be 0 or 1");
@@ -466,6 +472,10 @@ int layer_x3w8(const float* x3d, const float* x2d, float* y3d, float* y2d, int B
     const float* ln = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wpack) + (size_t)NW * (MAIN_FRAGS + KV_FRAGS) * 1024);
     if (int rc = ophip_lds_attr(reinterpret_cast<const void*>(enc_x3w8_kernel<false>), LDS_BYTES, "hipFuncSetAttribute(enc_x3w8)")) return rc;
     if (int rc = ophip_lds_attr(reinterpret_cast<const void*>(enc_x3w8_kernel<true>), LDS_BYTES, "hipFuncSetAttribute(enc_x3w8 kv)")) return rc;
+    if (mask2d) {
+        if (int rc = ophip_lds_attr(reinterpret_cast<const void*>(enc_x3w8_kernel<false, true>), LDS_BYTES, "hipFuncSetAttribute(enc_x3w8 masked)")) return rc;
+        if (int rc = ophip_lds_attr(reinterpret_cast<const void*>(enc_x3w8_kernel<true, true>), LDS_BYTES, "hipFuncSetAttribute(enc_x3w8 kv masked)")) return rc;
+    }
 
     EncW8Args aa;
     aa.x[0] = x3d; aa.x[1] = x2d; aa.y[0] = y3d; aa.y[1] = y2d;
@@ -478,6 +488,7 @@ int layer_x3w8(const float* x3d, const float* x2d, float* y3d, float* y2d, int B
     aa.stamps = ophip_stamp_buffer();
     aa.frag[0] = static_cast<char*>(frag3d); aa.frag[1] = static_cast<char*>(frag2d);
     aa.frag_rows[0] = (L3d + 127) / 128 * 128; aa.frag_rows[1] = (L2d + 127) / 128 * 128;
+    aa.mask2d = mask2d;
     if (!kv_from_prev) {
         EncW8Args ka = aa;
         ka.kv[0] = ka.kv[1] = nullptr;
@@ -485,7 +496,8 @@ int layer_x3w8(const float* x3d, const float* x2d, float* y3d, float* y2d, int B
         ka.wkv = wkv_own;
         ka.partial = partial;
         ka.stamps = nullptr;
-        OPHIP_LAUNCH("kv_reduce", stream, enc_x3w8_kernel<true>, dim3(t3 + t2, B), dim3(512), LDS_BYTES, stream, ka);
+        if (mask2d) { OPHIP_LAUNCH("kv_reduce", stream, (enc_x3w8_kernel<true, true>), dim3(t3 + t2, B), dim3(512), LDS_BYTES, stream, ka); }
+        else { OPHIP_LAUNCH("kv_reduce", stream, enc_x3w8_kernel<true>, dim3(t3 + t2, B), dim3(512), LDS_BYTES, stream, ka); }
         OPHIP_CHECK_LAUNCH();
     }
     KvSumArgs sa;
@@ -498,7 +510,8 @@ int layer_x3w8(const float* x3d, const float* x2d, float* y3d, float* y2d, int B
     aa.wkv = nullptr;
     aa.partial = partial_next;
     if (wpack_next) aa.wkv = reinterpret_cast<const bf16x8*>(wpack_next) + (size_t)NW * MAIN_FRAGS * 64;
-    OPHIP_LAUNCH("attn_apply", stream, enc_x3w8_kernel<false>, dim3(t3 + t2, B), dim3(512), LDS_BYTES, stream, aa);
+    if (mask2d) { OPHIP_LAUNCH("attn_apply", stream, (enc_x3w8_kernel<false, true>), dim3(t3 + t2, B), dim3(512), LDS_BYTES, stream, aa); }
+    else { OPHIP_LAUNCH("attn_apply", stream, enc_x3w8_kernel<false>, dim3(t3 + t2, B), dim3(512), LDS_BYTES, stream, aa); }
     OPHIP_CHECK_LAUNCH();
     return 0;
 }
@@ -518,4 +531,13 @@ extern "C" int ophip_encoder_layer_x3w8_frag(const float* x3d, const float* x2d,
                                              void* workspace, void* frag3d, void* frag2d, void* stream) {
     if (!frag3d || !frag2d) return ophip_bad_arg(__func__, "null fragment buffer");
     return layer_x3w8(x3d, x2d, y3d, y2d, B, L3d, L2d, wpack, wpack_next, is_cross, kv_from_prev, slot, workspace, stream, frag3d, frag2d);
+}
+
+// The same layer with the reference's query_mask (transformer.py:148-159): mask2d [B][L2d], 1 = real cell, 0 = padding.  The 2D stream's
+// padded rows drop out as sources (phi(K) = 0) and get a zero message as queries (phi(Q) = 0); their rows are still updated.
+extern "C" int ophip_encoder_layer_x3w8_masked(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
+                                               const void* wpack, const void* wpack_next, int is_cross, int kv_from_prev, int slot,
+                                               void* workspace, const unsigned char* mask2d, void* stream) {
+    if (!mask2d) return ophip_bad_arg(__func__, "null mask (use ophip_encoder_layer_x3w8)");
+    return layer_x3w8(x3d, x2d, y3d, y2d, B, L3d, L2d, wpack, wpack_next, is_cross, kv_from_prev, slot, workspace, stream, nullptr, nullptr, mask2d);
 }

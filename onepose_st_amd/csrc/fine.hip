@@ -31,6 +31,7 @@ struct FineArgs {
     int enc_enable;
     int wc, stride;
     float fine_scale;            // (W // 2) * (H_img / H_f)
+    const float* qscale;         // [B][2] query_image_scale (h, w factors; fine_matching.py:104) or NULL
     float* expec_f; float* mkq_f;
     float* dbg_win; float* dbg_f3;                       // optional [K][25][128], [K][128]
 };
@@ -210,20 +211,20 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void fine_refine_ke
             const float vx = ex2 - ex * ex, vy = ey2 - ey * ey;
             const float sd = sqrtf(fmaxf(vx, 1e-10f)) + sqrtf(fmaxf(vy, 1e-10f));
             p.expec_f[3 * k] = ex; p.expec_f[3 * k + 1] = ey; p.expec_f[3 * k + 2] = sd;
-            p.mkq_f[2 * k] = p.mkq_c[2 * k] + ex * p.fine_scale;
-            p.mkq_f[2 * k + 1] = p.mkq_c[2 * k + 1] + ey * p.fine_scale;
+            store_fine_keypoint(p, k, ex, ey);
         }
     }
 }
 
 }  // namespace
 
-extern "C" int ophip_fine_refine(const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x, int hf, int wf,
-                                 const float* desc3d_f, long long ds_b, long long ds_c,
-                                 const long long* b_ids, const long long* i_ids, const long long* j_ids, const int* count, int max_matches,
-                                 const float* mkpts_c, const float* wpack, int nlayers, unsigned cross_bits, int encoder_enable,
-                                 int wc, int stride, float fine_scale, float* expec_f, float* mkpts_f,
-                                 float* dbg_win, float* dbg_f3, void* stream_) {
+namespace {
+int fine_f32(const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x, int hf, int wf,
+             const float* desc3d_f, long long ds_b, long long ds_c,
+             const long long* b_ids, const long long* i_ids, const long long* j_ids, const int* count, int max_matches,
+             const float* mkpts_c, const float* wpack, int nlayers, unsigned cross_bits, int encoder_enable,
+             int wc, int stride, float fine_scale, float* expec_f, float* mkpts_f,
+             float* dbg_win, float* dbg_f3, const float* query_scale, void* stream_) {
     if (!feat_f || !desc3d_f || !b_ids || !i_ids || !j_ids || !count || !mkpts_c || !expec_f || !mkpts_f)
         return ophip_bad_arg(__func__, "null pointer");
     if (encoder_enable && (!wpack || nlayers < 1 || nlayers > 32)) return ophip_bad_arg(__func__, "encoder enabled without weights");
@@ -234,11 +235,35 @@ extern "C" int ophip_fine_refine(const float* feat_f, long long fs_b, long long 
     a.desc_f = desc3d_f; a.ds_b = ds_b; a.ds_c = ds_c;
     a.b_ids = b_ids; a.i_ids = i_ids; a.j_ids = j_ids; a.count = count; a.mkq_c = mkpts_c;
     a.wpack = wpack; a.nlayers = nlayers; a.cross_bits = cross_bits; a.enc_enable = encoder_enable;
-    a.wc = wc; a.stride = stride; a.fine_scale = fine_scale;
+    a.wc = wc; a.stride = stride; a.fine_scale = fine_scale; a.qscale = query_scale;
     a.expec_f = expec_f; a.mkq_f = mkpts_f; a.dbg_win = dbg_win; a.dbg_f3 = dbg_f3;
     const size_t lds = (size_t)32 * (2 * LDF + LDF2) * sizeof(float);
     if (int rc = ophip_lds_attr(reinterpret_cast<const void*>(fine_refine_kernel), lds, "hipFuncSetAttribute(fine_refine)")) return rc;
     OPHIP_LAUNCH("fine_refine", (hipStream_t)stream_, fine_refine_kernel, dim3(max_matches), dim3(256), lds, (hipStream_t)stream_, a);
     OPHIP_CHECK_LAUNCH();
     return 0;
+}
+}  // namespace
+
+extern "C" int ophip_fine_refine(const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x, int hf, int wf,
+                                 const float* desc3d_f, long long ds_b, long long ds_c,
+                                 const long long* b_ids, const long long* i_ids, const long long* j_ids, const int* count, int max_matches,
+                                 const float* mkpts_c, const float* wpack, int nlayers, unsigned cross_bits, int encoder_enable,
+                                 int wc, int stride, float fine_scale, float* expec_f, float* mkpts_f,
+                                 float* dbg_win, float* dbg_f3, void* stream) {
+    return fine_f32(feat_f, fs_b, fs_c, fs_y, fs_x, hf, wf, desc3d_f, ds_b, ds_c, b_ids, i_ids, j_ids, count, max_matches, mkpts_c, wpack, nlayers,
+                    cross_bits, encoder_enable, wc, stride, fine_scale, expec_f, mkpts_f, dbg_win, dbg_f3, nullptr, stream);
+}
+
+// ophip_fine_refine with query_scale [B][2] = data["query_image_scale"] ((h, w) factors; fine_matching.py:104): the refinement offset of
+// match k is scaled by query_scale[b_ids[k]][[1, 0]].
+extern "C" int ophip_fine_refine_scaled(const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x, int hf, int wf,
+                                        const float* desc3d_f, long long ds_b, long long ds_c,
+                                        const long long* b_ids, const long long* i_ids, const long long* j_ids, const int* count, int max_matches,
+                                        const float* mkpts_c, const float* wpack, int nlayers, unsigned cross_bits, int encoder_enable,
+                                        int wc, int stride, float fine_scale, float* expec_f, float* mkpts_f,
+                                        float* dbg_win, float* dbg_f3, const float* query_scale, void* stream) {
+    if (!query_scale) return ophip_bad_arg(__func__, "null query_scale (use ophip_fine_refine)");
+    return fine_f32(feat_f, fs_b, fs_c, fs_y, fs_x, hf, wf, desc3d_f, ds_b, ds_c, b_ids, i_ids, j_ids, count, max_matches, mkpts_c, wpack, nlayers,
+                    cross_bits, encoder_enable, wc, stride, fine_scale, expec_f, mkpts_f, dbg_win, dbg_f3, query_scale, stream);
 }

@@ -36,6 +36,7 @@ struct FineBArgs {
     int nlayers; unsigned cross_bits; int enc_enable;
     int wc, stride;
     float fine_scale;
+    const float* qscale;         // [B][2] query_image_scale (h, w factors; fine_matching.py:104) or NULL
     float* expec_f; float* mkq_f;
     float* dbg_win; float* dbg_f3;
     unsigned long long* stamps;
@@ -391,8 +392,7 @@ __global__ __launch_bounds__(NM * 256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_refi
             const float vx = ex2 - ex * ex, vy = ey2 - ey * ey;
             const float sd = sqrtf(fmaxf(vx, 1e-10f)) + sqrtf(fmaxf(vy, 1e-10f));
             p.expec_f[3 * k] = ex; p.expec_f[3 * k + 1] = ey; p.expec_f[3 * k + 2] = sd;
-            p.mkq_f[2 * k] = p.mkq_c[2 * k] + ex * p.fine_scale;
-            p.mkq_f[2 * k + 1] = p.mkq_c[2 * k + 1] + ey * p.fine_scale;
+            store_fine_keypoint(p, k, ex, ey);
         }
     }
     OPHIP_STAMP(p.stamps, blockIdx.x, 31);
@@ -789,8 +789,7 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_pair_kern
             const float vx = ex2 - ex * ex, vy = ey2 - ey * ey;
             const float sd = sqrtf(fmaxf(vx, 1e-10f)) + sqrtf(fmaxf(vy, 1e-10f));
             p.expec_f[3 * k] = ex; p.expec_f[3 * k + 1] = ey; p.expec_f[3 * k + 2] = sd;
-            p.mkq_f[2 * k] = p.mkq_c[2 * k] + ex * p.fine_scale;
-            p.mkq_f[2 * k + 1] = p.mkq_c[2 * k + 1] + ey * p.fine_scale;
+            store_fine_keypoint(p, k, ex, ey);
         }
     }
     OPHIP_STAMP(p.stamps, blockIdx.x, 31);
@@ -805,12 +804,13 @@ int set_lds(K kernel, size_t bytes, const char* what) {
 
 extern "C" size_t ophip_fine_bf16_wpack_bytes(int nlayers) { return (size_t)nlayers * ((size_t)2 * W_ELEMS * 2 + 4 * CF * 4); }
 
-extern "C" int ophip_fine_refine_bf16(const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x, int hf, int wf,
-                                      const float* desc3d_f, long long ds_b, long long ds_c,
-                                      const long long* b_ids, const long long* i_ids, const long long* j_ids, const int* count, int max_matches,
-                                      const float* mkpts_c, const void* wpack, int nlayers, unsigned cross_bits, int encoder_enable, int nsplit,
-                                      int wc, int stride, float fine_scale, float* expec_f, float* mkpts_f,
-                                      float* dbg_win, float* dbg_f3, void* stream_) {
+namespace {
+int fine_bf16(const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x, int hf, int wf,
+              const float* desc3d_f, long long ds_b, long long ds_c,
+              const long long* b_ids, const long long* i_ids, const long long* j_ids, const int* count, int max_matches,
+              const float* mkpts_c, const void* wpack, int nlayers, unsigned cross_bits, int encoder_enable, int nsplit,
+              int wc, int stride, float fine_scale, float* expec_f, float* mkpts_f,
+              float* dbg_win, float* dbg_f3, const float* query_scale, void* stream_) {
     if (!feat_f || !desc3d_f || !b_ids || !i_ids || !j_ids || !count || !mkpts_c || !expec_f || !mkpts_f)
         return ophip_bad_arg(__func__, "null pointer");
     if (encoder_enable && (!wpack || nlayers < 1 || nlayers > 32)) return ophip_bad_arg(__func__, "encoder enabled without weights");
@@ -824,7 +824,7 @@ extern "C" int ophip_fine_refine_bf16(const float* feat_f, long long fs_b, long 
     a.desc_f = desc3d_f; a.ds_b = ds_b; a.ds_c = ds_c;
     a.b_ids = b_ids; a.i_ids = i_ids; a.j_ids = j_ids; a.count = count; a.mkq_c = mkpts_c;
     a.wpack = reinterpret_cast<const char*>(wpack); a.nlayers = nlayers; a.cross_bits = cross_bits; a.enc_enable = encoder_enable;
-    a.wc = wc; a.stride = stride; a.fine_scale = fine_scale;
+    a.wc = wc; a.stride = stride; a.fine_scale = fine_scale; a.qscale = query_scale;
     a.expec_f = expec_f; a.mkq_f = mkpts_f; a.dbg_win = dbg_win; a.dbg_f3 = dbg_f3;
     a.stamps = ophip_stamp_buffer();
     hipStream_t stream = (hipStream_t)stream_;
@@ -856,4 +856,27 @@ extern "C" int ophip_fine_refine_bf16(const float* feat_f, long long fs_b, long 
 #undef OPHIP_FINE_CASE
     OPHIP_CHECK_LAUNCH();
     return 0;
+}
+}  // namespace
+
+extern "C" int ophip_fine_refine_bf16(const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x, int hf, int wf,
+                                      const float* desc3d_f, long long ds_b, long long ds_c,
+                                      const long long* b_ids, const long long* i_ids, const long long* j_ids, const int* count, int max_matches,
+                                      const float* mkpts_c, const void* wpack, int nlayers, unsigned cross_bits, int encoder_enable, int nsplit,
+                                      int wc, int stride, float fine_scale, float* expec_f, float* mkpts_f,
+                                      float* dbg_win, float* dbg_f3, void* stream) {
+    return fine_bf16(feat_f, fs_b, fs_c, fs_y, fs_x, hf, wf, desc3d_f, ds_b, ds_c, b_ids, i_ids, j_ids, count, max_matches, mkpts_c, wpack, nlayers,
+                     cross_bits, encoder_enable, nsplit, wc, stride, fine_scale, expec_f, mkpts_f, dbg_win, dbg_f3, nullptr, stream);
+}
+
+// ophip_fine_refine_bf16 with query_scale [B][2] = data["query_image_scale"] ((h, w) factors; fine_matching.py:104).
+extern "C" int ophip_fine_refine_bf16_scaled(const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x, int hf, int wf,
+                                             const float* desc3d_f, long long ds_b, long long ds_c,
+                                             const long long* b_ids, const long long* i_ids, const long long* j_ids, const int* count, int max_matches,
+                                             const float* mkpts_c, const void* wpack, int nlayers, unsigned cross_bits, int encoder_enable, int nsplit,
+                                             int wc, int stride, float fine_scale, float* expec_f, float* mkpts_f,
+                                             float* dbg_win, float* dbg_f3, const float* query_scale, void* stream) {
+    if (!query_scale) return ophip_bad_arg(__func__, "null query_scale (use ophip_fine_refine_bf16)");
+    return fine_bf16(feat_f, fs_b, fs_c, fs_y, fs_x, hf, wf, desc3d_f, ds_b, ds_c, b_ids, i_ids, j_ids, count, max_matches, mkpts_c, wpack, nlayers,
+                     cross_bits, encoder_enable, nsplit, wc, stride, fine_scale, expec_f, mkpts_f, dbg_win, dbg_f3, query_scale, stream);
 }

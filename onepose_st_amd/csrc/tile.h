@@ -86,6 +86,22 @@ __device__ __forceinline__ void acc_to_lds(const f32x16& acc, float* img, int ld
     for (int reg = 0; reg < 16; ++reg) img[acc_row(reg, h) * ld + col0 + r] = acc[reg];
 }
 
+// mkpts_query_f = mkpts_query_c + expectation * (W // 2) * scale_f [* query_image_scale[b][[1, 0]]]   (fine_matching.py:104-105).
+// fine_scale = (W // 2) * scale_f with W // 2 = 2 (5 x 5 windows).  With a per-image scale the reference multiplies scale_f by it
+// first (f32), then the doubled expectation by that product, then adds: the same three roundings here (no contraction).
+template <typename Args>
+__device__ __forceinline__ void store_fine_keypoint(const Args& p, int k, float ex, float ey) {
+    if (!p.qscale) {
+        p.mkq_f[2 * k] = p.mkq_c[2 * k] + ex * p.fine_scale;
+        p.mkq_f[2 * k + 1] = p.mkq_c[2 * k + 1] + ey * p.fine_scale;
+        return;
+    }
+    const int b = (int)p.b_ids[k];
+    const float sf = p.fine_scale * 0.5f;
+    p.mkq_f[2 * k] = __fadd_rn(p.mkq_c[2 * k], __fmul_rn(ex * 2.0f, __fmul_rn(sf, p.qscale[2 * b + 1])));
+    p.mkq_f[2 * k + 1] = __fadd_rn(p.mkq_c[2 * k + 1], __fmul_rn(ey * 2.0f, __fmul_rn(sf, p.qscale[2 * b])));
+}
+
 // phi(x) = elu(x) + 1 with the reference's arithmetic: (exp(x) - 1) + 1 on the negative side
 // (torch.nn.functional.elu(x) + 1, linear_attention.py:10-11)
 __device__ __forceinline__ float elu_plus_one(float x) { return x > 0.f ? x + 1.0f : (expf(x) - 1.0f) + 1.0f; }

@@ -79,6 +79,15 @@ _SIGNATURES = {
     "ophip_fine_bf16_wpack_bytes": (ctypes.c_size_t, [c_i]),
     "ophip_fine_refine_bf16": (c_i, [c_f, c_ll, c_ll, c_ll, c_ll, c_i, c_i, c_f, c_ll, c_ll, c_f, c_f, c_f, c_f, c_i,
                                      c_f, c_f, c_i, ctypes.c_uint, c_i, c_i, c_i, c_i, ctypes.c_float, c_f, c_f, c_f, c_f, ctypes.c_void_p]),
+    "ophip_encoder_layer_masked": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_i, c_f, c_f, ctypes.c_void_p]),
+    "ophip_encoder_layer_bf16_masked": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, ctypes.c_void_p]),
+    "ophip_encoder_layer_x3w8_masked": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_i, c_i, c_i, c_f, c_f, ctypes.c_void_p]),
+    "ophip_coarse_match_masked": (c_i, [c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_i, ctypes.c_double, ctypes.c_float, c_i, ctypes.c_float,
+                                        c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, ctypes.c_void_p]),
+    "ophip_fine_refine_scaled": (c_i, [c_f, c_ll, c_ll, c_ll, c_ll, c_i, c_i, c_f, c_ll, c_ll, c_f, c_f, c_f, c_f, c_i,
+                                       c_f, c_f, c_i, ctypes.c_uint, c_i, c_i, c_i, ctypes.c_float, c_f, c_f, c_f, c_f, c_f, ctypes.c_void_p]),
+    "ophip_fine_refine_bf16_scaled": (c_i, [c_f, c_ll, c_ll, c_ll, c_ll, c_i, c_i, c_f, c_ll, c_ll, c_f, c_f, c_f, c_f, c_i,
+                                            c_f, c_f, c_i, ctypes.c_uint, c_i, c_i, c_i, c_i, ctypes.c_float, c_f, c_f, c_f, c_f, c_f, ctypes.c_void_p]),
     "ophip_coarse_match_2d": (c_i, [c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_i, c_i, ctypes.c_double, ctypes.c_float, c_i, ctypes.c_float,
                                     c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, ctypes.c_void_p]),
     "ophip_fine2_gather": (c_i, [c_f, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f, ctypes.c_void_p]),

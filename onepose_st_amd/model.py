@@ -207,8 +207,8 @@ class OnePosePlus_model(nn.Module):
         if self.training:
             raise NotImplementedError("the HIP path implements inference; call .eval() (training padding "
                                       "of coarse_matching.py:177-217 is out of scope)")
-        if "query_image_mask" in data or "query_image_scale" in data or "mask0" in data:
-            raise NotImplementedError("query_image_mask / query_image_scale are not supported (img_pad: False path)")
+        if "mask0" in data:
+            raise NotImplementedError("data['mask0']: not implemented (the reference raises as well, coarse_matching.py:149-152)")
         data.update({"bs": data["query_image"].size(0), "q_hw_i": data["query_image"].shape[2:]})
         img = data["query_image"]
         if self.hip_backbone:
@@ -283,6 +283,20 @@ class OnePosePlus_model(nn.Module):
             if t.shape[0] not in (1, B):
                 raise ValueError(f"{name}: batch {t.shape[0]} does not match the query batch {B}")
 
+        # optional inputs of padded / resized query images (OnePosePlusModel.py:104,156-158; datasets with img_pad / img_resize)
+        qmask = qscale = None
+        if "query_image_mask" in data:
+            qm = data["query_image_mask"]
+            if tuple(qm.shape) != (B, hc, wc):
+                raise ValueError(f"query_image_mask: expected shape {(B, hc, wc)} (the coarse grid), got {tuple(qm.shape)}")
+            qmask = (qm if qm.dtype == torch.bool else qm != 0).to(dev).contiguous().view(torch.uint8).view(B, M)
+        if "query_image_scale" in data:
+            qs = data["query_image_scale"]
+            if tuple(qs.shape) != (B, 2):
+                raise ValueError(f"query_image_scale: expected shape {(B, 2)} ((h, w) factors per image), got {tuple(qs.shape)}")
+            qscale = qs.to(device=dev, dtype=torch.float32).contiguous()
+        PM = lambda: P(qmask, torch.uint8)
+
         main = torch.cuda.current_stream(dev)
         fkey = (str(dev), main.cuda_stream)
         lazy = self.conf_matrix_mode == "lazy" and not _force_eager
@@ -291,7 +305,7 @@ class OnePosePlus_model(nn.Module):
         if (self.frame_call and self.precision == "bf16x3" and self.overlap_fine and not _pe_applied and not want_fine_debug
                 and not self.debug and isinstance(self.profiler, _NullProfiler) and bool(cfg["fine_matching"]["enable"])
                 and (self.kpt_3d_pos_encoding is not None or B == 1 or desc_in_d.shape[0] == B)
-                and len(self.loftr_coarse.layer_names) <= 16):
+                and len(self.loftr_coarse.layer_names) <= 16 and qmask is None and qscale is None):
             x3d_ext = None
             if self.cache_object:
                 ckey = (str(dev), B, N, kpts_d.data_ptr(), kpts_d._version, desc_in_d.data_ptr(), desc_in_d._version, id(W))
@@ -381,8 +395,12 @@ class OnePosePlus_model(nn.Module):
             wait_previous_fine()
             ws = torch.empty(hip.load().ophip_encoder_workspace_floats(B, N, M), **f32)
             for li, name in enumerate(self.loftr_coarse.layer_names):
-                lib_call("ophip_encoder_layer", P(x3d), P(x2d), P(y3d), P(y2d), B, N, M, P(W["coarse"][li]),
-                         1 if name == "cross" else 0, P(ws), S)
+                if qmask is None:
+                    lib_call("ophip_encoder_layer", P(x3d), P(x2d), P(y3d), P(y2d), B, N, M, P(W["coarse"][li]),
+                             1 if name == "cross" else 0, P(ws), S)
+                else:
+                    lib_call("ophip_encoder_layer_masked", P(x3d), P(x2d), P(y3d), P(y2d), B, N, M, P(W["coarse"][li]),
+                             1 if name == "cross" else 0, P(ws), PM(), S)
                 x3d, y3d, x2d, y2d = y3d, (z3d if li == 0 else x3d), y2d, x2d
         elif self.precision == "bf16x3":
             # 16-token tiles, one eight-wave workgroup per CU, per-wave weight streams (csrc/encoder_x3w8.hip)
@@ -393,8 +411,8 @@ class OnePosePlus_model(nn.Module):
                 nxt = W["coarse_x3"][li + 1] if li + 1 < len(names_c) else None
                 if li == 0:
                     wait_previous_fine()
-                lib_call(entry, P(x3d), P(x2d), P(y3d), P(y2d), B, N, M, P(W["coarse_x3"][li], None), P(nxt, None),
-                         1 if name == "cross" else 0, 1 if li > 0 else 0, li & 1, P(ws, None), S)
+                lib_call(entry + ("_masked" if qmask is not None else ""), P(x3d), P(x2d), P(y3d), P(y2d), B, N, M, P(W["coarse_x3"][li], None), P(nxt, None),
+                         1 if name == "cross" else 0, 1 if li > 0 else 0, li & 1, P(ws, None), *((PM(),) if qmask is not None else ()), S)
                 x3d, y3d, x2d, y2d = y3d, (z3d if li == 0 else x3d), y2d, x2d
         else:
             nsplit = 1                                            # plain-bf16 mode
@@ -405,8 +423,9 @@ class OnePosePlus_model(nn.Module):
                 nxt = W["coarse_bf16"][li + 1] if li + 1 < len(names_c) else None
                 if li == 0:
                     wait_previous_fine()                          # attn_apply, the roofline kernel, never shares the chip with fine
-                lib_call("ophip_encoder_layer_bf16", P(x3d), P(x2d), P(y3d), P(y2d), B, N, M, P(W["coarse_bf16"][li], None), P(nxt, None),
-                         nsplit, 1 if name == "cross" else 0, 1 if li > 0 else 0, li & 1, P(ws, None), S)
+                lib_call("ophip_encoder_layer_bf16" + ("_masked" if qmask is not None else ""), P(x3d), P(x2d), P(y3d), P(y2d), B, N, M,
+                         P(W["coarse_bf16"][li], None), P(nxt, None),
+                         nsplit, 1 if name == "cross" else 0, 1 if li > 0 else 0, li & 1, P(ws, None), *((PM(),) if qmask is not None else ()), S)
                 x3d, y3d, x2d, y2d = y3d, (z3d if li == 0 else x3d), y2d, x2d
         if self.debug:
             data["_feat3d_c"], data["_feat2d_c"] = x3d, x2d
@@ -432,10 +451,14 @@ class OnePosePlus_model(nn.Module):
         # the single-workgroup select kernel goes with the fine stage onto the side stream (it only feeds that stage and the
         # read-back): the next frame's input kernels then run beside it instead of behind it
         split_select = fine_on and self.overlap_fine
+        padded = qmask is not None or qscale is not None
         with self.profiler.record_function("LoFTR/coarse-matching/get_coarse_match"):
-            lib_call("ophip_coarse_match_conf" if split_select else "ophip_coarse_match", *cm_args, S)
+            if padded:
+                lib_call("ophip_coarse_match_masked", *cm_args, 1 if split_select else 3, PM() if qmask is not None else None, P(qscale), S)
+            else:
+                lib_call("ophip_coarse_match_conf" if split_select else "ophip_coarse_match", *cm_args, S)
         data["conf_matrix"] = conf if not lazy else LazyConfMatrix(x3d, x2d, float(cm["dual_softmax"]["temperature"]),
-                                                                     {"f32": 0, "bf16": 1, "bf16x3": 3}[self.precision], main)
+                                                                     {"f32": 0, "bf16": 1, "bf16x3": 3}[self.precision], main, qmask)
 
         fine_ctx = contextlib.nullcontext()
         if fine_on and self.overlap_fine:
@@ -448,11 +471,13 @@ class OnePosePlus_model(nn.Module):
             coarse_done.record(main)
             sfine.wait_event(coarse_done)
             fine_ctx = torch.cuda.stream(sfine)
-        keep = [desc_fine_d, W]      # inputs of the side-stream kernels stay referenced until finish()
+        keep = [desc_fine_d, W, qmask, qscale]      # inputs of the side-stream kernels stay referenced until finish()
         keep += [x3d, x2d, cws, conf]
         with fine_ctx:
             S = hip.stream_handle()
-            if split_select:
+            if split_select and padded:
+                lib_call("ophip_coarse_match_masked", *cm_args, 2, PM() if qmask is not None else None, P(qscale), S)
+            elif split_select:
                 lib_call("ophip_coarse_match_select", *cm_args, S)
             if fine_on:
                 # ---- a9-a11: fine refinement (grid sized by capacity, device-side count: no sync yet) ----
@@ -468,18 +493,18 @@ class OnePosePlus_model(nn.Module):
                 fine_scale = (cf["window_size"] // 2) * (data["q_hw_i"][0] / hf)
                 max_matches = cap                                # one match per 3D point at most: the grid covers every possible K (surplus workgroups exit)
                 if self.precision == "f32":
-                    lib_call("ophip_fine_refine", P(ff), *ff_strides, hf, wf,
+                    lib_call("ophip_fine_refine" + ("_scaled" if qscale is not None else ""), P(ff), *ff_strides, hf, wf,
                              P(desc_fine_d), bstride(desc_fine_d), desc_fine_d.stride(1),
                              P(b_ids, torch.int64), P(i_ids, torch.int64), P(j_ids, torch.int64), P(count, torch.int32), max_matches,
                              P(mkc), P(W["fine"]), len(names_f), ctypes.c_uint(cross_bits), 1 if cf["enable"] else 0,
-                             wc, stride, float(fine_scale), P(expec), P(mkf), P(dbg_w), P(dbg_3), S)
+                             wc, stride, float(fine_scale), P(expec), P(mkf), P(dbg_w), P(dbg_3), *((P(qscale),) if qscale is not None else ()), S)
                 else:
-                    lib_call("ophip_fine_refine_bf16", P(ff), *ff_strides, hf, wf,
+                    lib_call("ophip_fine_refine_bf16" + ("_scaled" if qscale is not None else ""), P(ff), *ff_strides, hf, wf,
                              P(desc_fine_d), bstride(desc_fine_d), desc_fine_d.stride(1),
                              P(b_ids, torch.int64), P(i_ids, torch.int64), P(j_ids, torch.int64), P(count, torch.int32), max_matches,
                              P(mkc), P(W["fine_bf16"], None), len(names_f), ctypes.c_uint(cross_bits), 1 if cf["enable"] else 0,
                              3 if self.precision == "bf16x3" else 1,
-                             wc, stride, float(fine_scale), P(expec), P(mkf), P(dbg_w), P(dbg_3), S)
+                             wc, stride, float(fine_scale), P(expec), P(mkf), P(dbg_w), P(dbg_3), *((P(qscale),) if qscale is not None else ()), S)
 
             if fine_on and self.overlap_fine:
                 fine_done = torch.cuda.Event()
@@ -602,8 +627,8 @@ class LazyConfMatrix:
     attribute access (``.max``, ``.cpu`` ...) and ``torch.*`` functions materialise first (``__torch_function__``).
     Reference: ``utils/coarse_matching.py:115``; its readers at inference time: none (``inference.py:179-180``)."""
 
-    def __init__(self, feat3d, feat2d, temperature, nsplit, stream):
-        self._f3, self._f2, self._temp, self._nsplit, self._stream = feat3d, feat2d, temperature, nsplit, stream
+    def __init__(self, feat3d, feat2d, temperature, nsplit, stream, query_mask=None):
+        self._f3, self._f2, self._temp, self._nsplit, self._stream, self._qmask = feat3d, feat2d, temperature, nsplit, stream, query_mask
         self._t = None
         self.shape = torch.Size((feat3d.shape[0], feat3d.shape[1], feat2d.shape[1]))
         self.dtype, self.device = torch.float32, feat3d.device
@@ -621,10 +646,13 @@ class LazyConfMatrix:
             fl = torch.empty(6 * cap + 3, dtype=torch.float32, device=dev)
             cnt = torch.zeros(4, dtype=torch.int32, device=dev)
             P = hip.ptr
-            hip.call("ophip_coarse_match_conf", P(self._f3), P(self._f2), P(fl[:3]), 0, B, N, M, M, self._temp, 0.5, 0, 1.0,
-                     P(conf), P(ws), P(ids[:cap], torch.int64), P(ids[cap:2 * cap], torch.int64), P(ids[2 * cap:], torch.int64),
-                     P(fl[3:3 + cap]), P(fl[3 + cap:3 + 4 * cap]), P(fl[3 + 4 * cap:3 + 6 * cap]), None, None, P(cnt, torch.int32),
-                     self._nsplit, hip.stream_handle())
+            args = (P(self._f3), P(self._f2), P(fl[:3]), 0, B, N, M, M, self._temp, 0.5, 0, 1.0,
+                    P(conf), P(ws), P(ids[:cap], torch.int64), P(ids[cap:2 * cap], torch.int64), P(ids[2 * cap:], torch.int64),
+                    P(fl[3:3 + cap]), P(fl[3 + cap:3 + 4 * cap]), P(fl[3 + 4 * cap:3 + 6 * cap]), None, None, P(cnt, torch.int32), self._nsplit)
+            if self._qmask is None:
+                hip.call("ophip_coarse_match_conf", *args, hip.stream_handle())
+            else:
+                hip.call("ophip_coarse_match_masked", *args, 1, P(self._qmask, torch.uint8), None, hip.stream_handle())
             self._t = conf
             self._f3 = self._f2 = None
         return self._t

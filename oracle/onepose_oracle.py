@@ -87,11 +87,17 @@ def keypoint_encode(sd: dict, kpts_n: torch.Tensor, descriptors: torch.Tensor) -
 # a5 / a6  encoder layer with linear attention
 # ----------------------------------------------------------------------------------------------
 
-def linear_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
-    """loftr_module/linear_attention.py:29-61 with masks ``None``.  q ``[B,L,H,D]``,
-    k, v ``[B,S,H,D]``."""
+def linear_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, eps: float = 1e-6,
+                     q_mask: torch.Tensor | None = None, kv_mask: torch.Tensor | None = None) -> torch.Tensor:
+    """loftr_module/linear_attention.py:29-61.  q ``[B,L,H,D]``, k, v ``[B,S,H,D]``; ``q_mask [B,L]`` / ``kv_mask [B,S]``
+    (``:49-53``) zero the padded rows of phi(Q) resp. phi(K) and V; ``v_length`` stays the padded length."""
     Q = F.elu(q) + 1
     K = F.elu(k) + 1
+    if q_mask is not None:
+        Q = Q * q_mask[:, :, None, None]
+    if kv_mask is not None:
+        K = K * kv_mask[:, :, None, None]
+        v = v * kv_mask[:, :, None, None]
     v_length = v.size(1)
     v = v / v_length
     KV = torch.einsum("nshd,nshv->nhdv", K, v)
@@ -99,14 +105,15 @@ def linear_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, eps: flo
     return (torch.einsum("nlhd,nhdv,nlh->nlhv", Q, KV, Z) * v_length).contiguous()
 
 
-def encoder_layer(sd: dict, p: str, x: torch.Tensor, source: torch.Tensor, nhead: int) -> torch.Tensor:
+def encoder_layer(sd: dict, p: str, x: torch.Tensor, source: torch.Tensor, nhead: int,
+                  x_mask: torch.Tensor | None = None, source_mask: torch.Tensor | None = None) -> torch.Tensor:
     """loftr_module/transformer.py:65-94 (dropout 0, no rezero, LayerNorm eps 1e-5)."""
     bs, C = x.size(0), x.size(2)
     dim = C // nhead
     q = F.linear(x, sd[p + "q_proj.weight"]).view(bs, -1, nhead, dim)
     k = F.linear(source, sd[p + "k_proj.weight"]).view(bs, -1, nhead, dim)
     v = F.linear(source, sd[p + "v_proj.weight"]).view(bs, -1, nhead, dim)
-    msg = linear_attention(q, k, v)
+    msg = linear_attention(q, k, v, q_mask=x_mask, kv_mask=source_mask)
     msg = F.linear(msg.view(bs, -1, C), sd[p + "merge.weight"])
     msg = F.layer_norm(msg, (C,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-5)
     msg = F.linear(F.relu(F.linear(torch.cat([x, msg], dim=2), sd[p + "mlp.0.weight"])), sd[p + "mlp.2.weight"])
@@ -115,18 +122,20 @@ def encoder_layer(sd: dict, p: str, x: torch.Tensor, source: torch.Tensor, nhead
 
 
 def feature_transformer(sd: dict, prefix: str, layer_names: list, nhead: int,
-                        desc3d: torch.Tensor, desc2d: torch.Tensor, trace: list | None = None):
+                        desc3d: torch.Tensor, desc2d: torch.Tensor, trace: list | None = None,
+                        query_mask: torch.Tensor | None = None):
     """loftr_module/transformer.py:133-171: ``desc3d [B,C,L] -> [B,L,C]`` then the
     layers; both streams of a layer read the *pre-update* tensors.  ``trace`` (optional
-    list) receives ``(desc3d, desc2d)`` after every layer."""
+    list) receives ``(desc3d, desc2d)`` after every layer.  ``query_mask [B, P]`` (``:148-159``): the 2D stream's rows are masked as
+    queries AND as sources (self: both; cross: ``x_mask`` for the 2D update, ``source_mask`` for the 3D update)."""
     d3 = torch.einsum("bdn->bnd", desc3d)
     d2 = desc2d
     for i, name in enumerate(layer_names):
         p = f"{prefix}.layers.{i}."
         if name == "self":
-            d2, d3 = encoder_layer(sd, p, d2, d2, nhead), encoder_layer(sd, p, d3, d3, nhead)
+            d2, d3 = encoder_layer(sd, p, d2, d2, nhead, query_mask, query_mask), encoder_layer(sd, p, d3, d3, nhead)
         elif name == "cross":
-            d2, d3 = encoder_layer(sd, p, d2, d3, nhead), encoder_layer(sd, p, d3, d2, nhead)
+            d2, d3 = encoder_layer(sd, p, d2, d3, nhead, x_mask=query_mask), encoder_layer(sd, p, d3, d2, nhead, source_mask=query_mask)
         else:
             raise NotImplementedError
         if trace is not None:
@@ -138,17 +147,24 @@ def feature_transformer(sd: dict, prefix: str, layer_names: list, nhead: int,
 # a7 / a8  coarse matching
 # ----------------------------------------------------------------------------------------------
 
-def dual_softmax_confidence(feat3d: torch.Tensor, feat2d: torch.Tensor, temperature: float) -> torch.Tensor:
-    """utils/coarse_matching.py:101-115 (``sqrt_feat_dim`` normaliser, no mask)."""
+def dual_softmax_confidence(feat3d: torch.Tensor, feat2d: torch.Tensor, temperature: float,
+                            mask_query: torch.Tensor | None = None) -> torch.Tensor:
+    """utils/coarse_matching.py:101-115 (``sqrt_feat_dim`` normaliser); ``mask_query [B, S]`` (``:108-114``) adds -1e9 to the
+    columns of padded query cells."""
     a = feat3d / feat3d.shape[-1] ** 0.5
     b = feat2d / feat2d.shape[-1] ** 0.5
     sim = torch.einsum("nlc,nsc->nls", a, b) / (temperature + 1e-4)
+    if mask_query is not None:
+        pad = torch.zeros_like(sim)
+        pad[~mask_query.bool()[:, None, :].expand_as(sim)] = -1e9
+        sim = sim + pad
     return F.softmax(sim, 1) * F.softmax(sim, 2)
 
 
-def coarse_match_select(conf: torch.Tensor, hw_c, hw_i, keypoints3d: torch.Tensor, thr: float, border_rm: int) -> dict:
+def coarse_match_select(conf: torch.Tensor, hw_c, hw_i, keypoints3d: torch.Tensor, thr: float, border_rm: int,
+                        query_image_scale: torch.Tensor | None = None) -> dict:
     """utils/coarse_matching.py:125-242, inference branch (``self.training`` False, no
-    ``mask0``, no ``query_image_scale``).  ``mask_border`` (``:10-20``) slices
+    ``mask0``); ``query_image_scale [B, 2]`` (h, w factors, ``:224``) rescales the coarse keypoints per batch element.  ``mask_border`` (``:10-20``) slices
     ``-b:0`` for the bottom/right edges, which is empty: only the top ``b`` rows and the
     left ``b`` columns are removed."""
     B, N, M = conf.shape
@@ -166,7 +182,8 @@ def coarse_match_select(conf: torch.Tensor, hw_c, hw_i, keypoints3d: torch.Tenso
     j_ids = all_j[b_ids, i_ids]
     mconf = conf[b_ids, i_ids, j_ids]
     scale = hw_i[0] / hw_c[0]
-    mk_q = torch.stack([j_ids % w, j_ids // w], dim=1) * scale
+    scale_total = scale * query_image_scale[b_ids][:, [1, 0]] if query_image_scale is not None else scale
+    mk_q = torch.stack([j_ids % w, j_ids // w], dim=1) * scale_total
     mk_3d = keypoints3d[b_ids, i_ids]
     keep = mconf != 0
     return {
@@ -211,9 +228,10 @@ def spatial_expectation_5x5(heatmap: torch.Tensor, W: int):
     return coords, grid
 
 
-def fine_match(feat3d: torch.Tensor, windows: torch.Tensor, mkpts_query_c: torch.Tensor, hw_i, hw_f) -> dict:
+def fine_match(feat3d: torch.Tensor, windows: torch.Tensor, mkpts_query_c: torch.Tensor, hw_i, hw_f,
+               query_image_scale: torch.Tensor | None = None, b_ids: torch.Tensor | None = None) -> dict:
     """utils/fine_matching.py:28-110, ``heatmap`` type.  feat3d ``[K,L,C]`` (L odd, centre
-    token picked), windows ``[K,WW,C]``."""
+    token picked), windows ``[K,WW,C]``; ``query_image_scale [B, 2]`` with the matches' ``b_ids`` (``:104``)."""
     K, WW, C = windows.shape
     W = int(math.sqrt(WW))
     scale = hw_i[0] / hw_f[0]
@@ -227,6 +245,8 @@ def fine_match(feat3d: torch.Tensor, windows: torch.Tensor, mkpts_query_c: torch
     var = torch.sum(grid ** 2 * heatmap.view(-1, WW, 1), dim=1) - coords ** 2
     std = torch.sum(torch.sqrt(torch.clamp(var, min=1e-10)), -1)
     expec = torch.cat([coords, std.unsqueeze(1)], -1)
+    if query_image_scale is not None:
+        scale = scale * query_image_scale[b_ids][:, [1, 0]]
     mk_f = mkpts_query_c + (coords * (W // 2) * scale)[: len(mkpts_query_c)]
     return {"expec_f": expec, "mkpts_query_f": mk_f}
 
@@ -292,13 +312,15 @@ def forward_from_features(sd: dict, cfg: dict, data: dict, feat_c: torch.Tensor,
         d3 = desc_in
     if trace is not None:
         trace["q2d_in"], trace["d3_in"], trace["coarse_layers"] = q2d, d3, []
+    query_mask = data["query_image_mask"].flatten(-2) if "query_image_mask" in data else None      # OnePosePlusModel.py:156-158
+    qscale = data.get("query_image_scale")
     d3, q2d = feature_transformer(sd, "loftr_coarse", names_c, cc["nhead"], d3, q2d,
-                                  None if trace is None else trace["coarse_layers"])
+                                  None if trace is None else trace["coarse_layers"], query_mask=query_mask)
 
     cm = cfg["coarse_matching"]
-    conf = dual_softmax_confidence(d3, q2d, cm["dual_softmax"]["temperature"])
+    conf = dual_softmax_confidence(d3, q2d, cm["dual_softmax"]["temperature"], mask_query=query_mask)
     out["conf_matrix"] = conf
-    out.update(coarse_match_select(conf, out["q_hw_c"], out["q_hw_i"], data["keypoints3d"], cm["thr"], cm["border_rm"]))
+    out.update(coarse_match_select(conf, out["q_hw_c"], out["q_hw_i"], data["keypoints3d"], cm["thr"], cm["border_rm"], qscale))
 
     if not cfg["fine_matching"]["enable"]:
         out["mkpts_query_f"] = out["mkpts_query_c"]
@@ -314,7 +336,7 @@ def forward_from_features(sd: dict, cfg: dict, data: dict, feat_c: torch.Tensor,
         f3 = torch.einsum("bdn->bnd", f3)
     if trace is not None:
         trace["fine_f3_out"], trace["fine_win_out"] = f3, win
-    out.update(fine_match(f3, win, out["mkpts_query_c"], out["q_hw_i"], out["q_hw_f"]))
+    out.update(fine_match(f3, win, out["mkpts_query_c"], out["q_hw_i"], out["q_hw_f"], qscale, out["b_ids"]))
     return out
 
 

@@ -119,8 +119,9 @@ class _FeatureStub(torch.nn.Module):
         return [self.feat_c, self.feat_f]
 
 
-def run_feature_case(model, inp):
-    """Reference forward from the feature boundary, with hooks capturing stage outputs."""
+def run_feature_case(model, inp, extra=None):
+    """Reference forward from the feature boundary, with hooks capturing stage outputs; ``extra``: further ``data`` keys
+    (``query_image_mask``, ``query_image_scale``)."""
     caps = {"coarse": [], "fine": [], "kpt": [], "pe": [], "fine_in": []}
     hooks = []
     for lyr in model.loftr_coarse.layers:
@@ -139,6 +140,7 @@ def run_feature_case(model, inp):
         "descriptors3d_db": inp["descriptors3d_db"],
         "descriptors3d_coarse_db": inp["descriptors3d_coarse_db"],
     }
+    data.update(extra or {})
     with torch.no_grad():
         model(data)
     model.backbone = real_backbone
@@ -185,6 +187,25 @@ def pack_feature_case(inp, data, caps) -> dict:
     return g
 
 
+def masked_case_inputs(sd, cfg):
+    """Case E's inputs (shared with tests/test_gpu_parity.py through the fixture's checksums): the ragged B = 2 frame pair of case B
+    with a padded-image mask per element (element 0: the right 4 coarse columns are padding, element 1: the bottom 3 coarse rows) and
+    different (h, w) image scales, as ``OnePosePlus_dataset.py:283,329`` produces for ``img_pad`` / ``img_resize`` datasets."""
+    from onepose_st_amd.synthetic import make_synthetic_inputs
+    i0 = make_synthetic_inputs(sd, n_points=333, image_hw=(96, 136), n_plant=120, seed=3, config=cfg, frame=0)
+    i1 = make_synthetic_inputs(sd, n_points=333, image_hw=(96, 136), n_plant=120, seed=3, config=cfg, frame=1)
+    both = {k: torch.cat([i0[k], i1[k]], 0) for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db", "feat_c", "feat_f")}
+    both["image_hw"] = i0["image_hw"]
+    both["planted_i"], both["planted_j"] = i0["planted_i"], i0["planted_j"]
+    both["pose_gt"], both["K"] = i0["pose_gt"], i0["K"]
+    hc, wc = 96 // 8, 136 // 8
+    mask = torch.ones(2, hc, wc, dtype=torch.bool)
+    mask[0, :, wc - 4:] = False
+    mask[1, hc - 3:, :] = False
+    scale = torch.tensor([[1.25, 1.5], [0.8, 1.0]], dtype=torch.float32)
+    return both, {"query_image_mask": mask, "query_image_scale": scale}
+
+
 def main():
     from onepose_st_amd.config import default_config
     from onepose_st_amd.synthetic import make_synthetic_inputs, make_synthetic_state_dict
@@ -193,6 +214,9 @@ def main():
     cfg = default_config()
     sd = make_synthetic_state_dict(seed=0, config=cfg)
     model = load_reference_model(cfg, sd)
+    if "--only-masked" in sys.argv:
+        make_masked_case(model, sd, cfg)
+        return
     print("reference model loaded; state_dict tensors:", len(sd), "params:", sum(v.numel() for k, v in sd.items()
                                                                                   if "running" not in k and "num_batches" not in k))
 
@@ -268,6 +292,24 @@ def main():
           "min |mconf - thr| =", float(np.abs(mc - 0.1).min()) if len(mc) else None,
           "row maxima within 1e-3 of thr:", int((np.abs(g["conf_rowmax"] - 0.1) < 1e-3).sum()))
     np.savez_compressed(os.path.join(HERE, "full_forward_planted.npz"), **g)
+
+    make_masked_case(model, sd, cfg)
+
+
+def make_masked_case(model, sd, cfg):
+    # ---- case E: query_image_mask + query_image_scale (coarse_matching.py:108-114,224; fine_matching.py:104; transformer.py:148-159)
+    both, extra = masked_case_inputs(sd, cfg)
+    data, caps = run_feature_case(model, both, extra)
+    g = pack_feature_case(both, data, caps)
+    g["query_image_mask"] = extra["query_image_mask"].numpy()
+    g["query_image_scale"] = extra["query_image_scale"].numpy()
+    conf = data["conf_matrix"]
+    g["conf_rowmax_b1"] = conf.max(dim=2)[0][1].numpy()
+    dead = ~extra["query_image_mask"].flatten(1)
+    print("case masked: K =", len(g["i_ids"]), "per batch:", np.bincount(g["b_ids"], minlength=2),
+          "max conf in padded columns:", float(conf.transpose(1, 2)[dead].max()),
+          "matches in padded cells:", int(dead[data["b_ids"], data["j_ids"]].sum()))
+    np.savez_compressed(os.path.join(HERE, "b2_masked_scaled_feature_boundary.npz"), **g)
 
 
 if __name__ == "__main__":

@@ -35,10 +35,15 @@ def _inputs(sd, cfg, case):
     return both
 
 
-@pytest.mark.parametrize("case,fname", [("c1", "c1_feature_boundary.npz"), ("b2", "b2_ragged_feature_boundary.npz")])
+@pytest.mark.parametrize("case,fname", [("c1", "c1_feature_boundary.npz"), ("b2", "b2_ragged_feature_boundary.npz"),
+                                        ("b2m", "b2_masked_scaled_feature_boundary.npz")])
 def test_oracle_matches_reference_golden(sd, cfg, golden_dir, case, fname):
     g = np.load(os.path.join(golden_dir, fname))
     inp = _inputs(sd, cfg, case)
+    if case == "b2m":          # query_image_mask + query_image_scale (the reference's img_pad / img_resize branches)
+        inp["query_image_mask"] = torch.from_numpy(g["query_image_mask"])
+        inp["query_image_scale"] = torch.from_numpy(g["query_image_scale"])
+        assert (~inp["query_image_mask"]).any() and len(g["i_ids"]) > 100
     # the seeded generator still produces the inputs the goldens were made from
     for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db", "feat_c", "feat_f"):
         np.testing.assert_allclose(cs(inp[k]), g["in_" + k], rtol=1e-12, atol=1e-9)
@@ -71,6 +76,10 @@ def test_oracle_matches_reference_golden(sd, cfg, golden_dir, case, fname):
     close_cs(cs(trace["fine_win_in"]), g["fine_in_win_cs"])
     close_cs(cs(trace["fine_win_out"]), g["fine1_win_cs"])
     close_cs(cs(trace["fine_f3_out"]), g["fine1_f3_cs"])
+    if case == "b2m":          # no match in a padded cell; the padded columns of conf_matrix are exactly zero
+        dead = ~inp["query_image_mask"].flatten(1)
+        assert not dead[out["b_ids"], out["j_ids"]].any()
+        assert float(conf.transpose(1, 2)[dead].max()) == 0.0
     # the planted matches are recovered (sanity of the generator, not of the oracle)
     got = set(zip(out["i_ids"][out["b_ids"] == 0].tolist(), out["j_ids"][out["b_ids"] == 0].tolist()))
     planted = set(zip(g["planted_i"].tolist(), g["planted_j"].tolist()))

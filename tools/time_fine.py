@@ -22,7 +22,7 @@ head = (hip.ptr(ff), hf * wf * 128, 1, wf * 128, 128, hf, wf, hip.ptr(desc), des
 tail = (wc, 4, 4.0, hip.ptr(expec), hip.ptr(mkf), None, None, hip.stream_handle())
 w1 = packing.pack_fine_layers_bf16(sd, "loftr_fine.layers.", 2).to(dev)
 def v1(): hip.call("ophip_fine_refine_bf16", *head, hip.ptr(w1, None), 2, ctypes.c_uint(2), 1, 3, *tail)
-for name, fn in (("fine_refine_bf16 (1 match / workgroup)", v1),):
+for name, fn in (("fine_refine_bf16 (fine_pair_kernel: two matches per workgroup; OPHIP_FINE_PAIR=0: one)", v1),):
     for _ in range(3): fn()
     torch.cuda.synchronize(); hip.timing_select("fine_refine")
     for _ in range(20): fn()
