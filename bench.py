@@ -82,6 +82,9 @@ def main():
                     help="compute streams the frames alternate over.  Default 1: the model already runs the fine stage and the result "
                          "read-back on side streams (frame t's refinement under frame t + 1's input kernels) while attn_apply never shares "
                          "the chip, so its HIP-event time is its own; 2 measured no gain on top of that")
+    ap.add_argument("--depth", type=int, default=0,
+                    help="frames in flight between enqueue and finish (0: streams + 2 -- frame t's fine stage is launched behind frame t + 1's "
+                         "encoder, so frame t + 2 must be queued before the host waits for frame t; streams + 1 with OPHIP_FRAME_DEFER_FINE=0)")
     ap.add_argument("--with-backbone", action="store_true",
                     help="also run the ResNet-FPN backbone (SURVEY 8f-1, HIP convolution kernels) on a synthetic image in every step; "
                          "its maps are then replaced by the planted feature maps (a random image has no matches)")
@@ -222,6 +225,7 @@ def main():
     # frames alternate over `--streams` HIP streams: consecutive frames are independent, so the single-workgroup
     # kernels and launch tails of one frame (select, kpt_stats, kv_sum ...) overlap the wide kernels of the next
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
+    depth = args.depth if args.depth > 0 else len(streams) + (1 if os.environ.get("OPHIP_FRAME_DEFER_FINE", "1") == "0" else 2)
 
     image = torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(7)).to(dev) if args.with_backbone else None
 
@@ -235,7 +239,7 @@ def main():
             inflight.append(model.enqueue_features(dict(obj_b), fc, ff, image_hw, host_copy=pool is not None,
                                                    inputs_ready=image is None and not args.inputs_behind))
         host_t["enqueue"] += time.perf_counter() - t
-        if len(inflight) > len(streams):
+        if len(inflight) >= depth:
             return complete(inflight.pop(0))
         return None
 
@@ -427,7 +431,7 @@ def main():
                             + f"; {pnp_threads} host threads, overlapped with the following frames, all joined before the clock stops)")
                             + ("; backbone (HIP convolutions) inside, on a synthetic image" if args.with_backbone else "; backbone outside"),
             "pnp_inliers_per_frame": n_inliers,
-            "streams": len(streams),
+            "streams": len(streams), "frames_in_flight": depth,
             "parallelism": f"frames sharded over {world} rank(s), one RCCL broadcast of weights + 3D block ({bcast_bytes} B)",
         },
         "host": {

@@ -967,7 +967,9 @@ void frag_plane_ptrs(float* workspace, int B, int N, int M, char** a, char** b) 
     *b = *a + (size_t)B * ntr * 4 * 32768;
 }
 
-// parts: 1 = similarity / confidence kernels, 2 = select (threshold, mutual test, compaction), 3 = both
+// parts (bit mask): 1 = similarity + confidence kernels (= 4 | 8), 2 = select (threshold, mutual test, compaction), 3 = the whole stage;
+// 4 = the similarity tiles with their statistics only, 8 = the rest of 1 (statistics merge, then conf_kernel -- or the candidate pass of
+// the lazy form): a pipeline may put other work between the matrix-bound and the HBM-bound half
 int coarse_impl(int parts, int border_mode, int wi, double temp_eps,
                 const float* feat3d, const float* feat2d, const float* keypoints3d, long long kpts_bstride,
                 int B, int N, int M, int wc, double temperature, float thr, int border_rm, float scale,
@@ -1001,10 +1003,11 @@ int coarse_impl(int parts, int border_mode, int wi, double temp_eps,
     const int sel_nspan = lazy ? ntc : nspan;
     SimFragArgs sf{};
     const int per_xcd = ((ntr + 7) / 8) * ntc;
-    if ((parts & 1) && nsplit != 0) {
+    const bool do_sim = (parts & 5) != 0, do_conf = (parts & 9) != 0;
+    if ((do_sim || do_conf) && nsplit != 0) {
         char *fa_, *fb_;
         frag_plane_ptrs(workspace, B, N, M, &fa_, &fb_);
-        if (!planes_ready) {
+        if (!planes_ready && do_sim) {
             FragArgs fr{feat3d, feat2d, fa_, fb_, N, M, 4 * ntr, 4 * ntc};
             OPHIP_LAUNCH("frag_planes", stream, frag_planes_kernel, dim3(16 * (ntr + ntc), B), dim3(256), 0, stream, fr);
             OPHIP_CHECK_LAUNCH();
@@ -1016,10 +1019,11 @@ int coarse_impl(int parts, int border_mode, int wi, double temp_eps,
             if (int rc = ophip_lds_attr(reinterpret_cast<const void*>(sim_frag_kernel<NS_, MODE_>), SIM_FRAG_LDS, "hipFuncSetAttribute(sim_frag)")) return rc; \
             OPHIP_LAUNCH(NAME_, stream, (sim_frag_kernel<NS_, MODE_>), dim3(8 * per_xcd, B), dim3(256), SIM_FRAG_LDS, stream, sf);    \
         }
-        if (lazy) { if (nsplit == 3) OPHIP_SIM_CASE(3, 1, "sim_stats") else OPHIP_SIM_CASE(1, 1, "sim_stats") }
+        if (!do_sim) {}
+        else if (lazy) { if (nsplit == 3) OPHIP_SIM_CASE(3, 1, "sim_stats") else OPHIP_SIM_CASE(1, 1, "sim_stats") }
         else { if (nsplit == 3) OPHIP_SIM_CASE(3, 0, "sim_stats") else OPHIP_SIM_CASE(1, 0, "sim_stats") }
         OPHIP_CHECK_LAUNCH();
-    } else if (parts & 1) {
+    } else if (do_sim) {
         SimArgs sa{feat3d, feat2d, conf, rowpart, colpart, N, M, ntr, ntc, (float)(temperature + temp_eps), ophip_stamp_buffer(), qmask};
         // dynamic LDS = max(operand tiles, S staging image of the epilogue)
         const size_t tiles = (size_t)(TM + TN) * LDT * sizeof(float);
@@ -1028,18 +1032,18 @@ int coarse_impl(int parts, int border_mode, int wi, double temp_eps,
         OPHIP_LAUNCH("sim_stats", stream, sim_stats_kernel, dim3(ntc, ntr, B), dim3(256), lds, stream, sa);
         OPHIP_CHECK_LAUNCH();
     }
-    if (parts & 1) {
+    if (do_conf) {
         CombineArgs ca{rowpart, colpart, rowstat, colstat, reinterpret_cast<unsigned*>(colmax), N, M, ntr, ntc, lazy ? rowlog : nullptr, lazy ? collog : nullptr, lazy ? count + 1 : nullptr};
         OPHIP_LAUNCH("stat_combine", stream, stat_combine_kernel, dim3((N + M + 31) / 32, B), dim3(256), 0, stream, ca);
         OPHIP_CHECK_LAUNCH();
     }
-    if ((parts & 1) && lazy) {
+    if (do_conf && lazy) {
         // second look at every tile: confidences from the merged statistics, only the candidates leave the chip
         if (nsplit == 3) OPHIP_SIM_CASE(3, 2, "sim_cand") else OPHIP_SIM_CASE(1, 2, "sim_cand")
         OPHIP_CHECK_LAUNCH();
     }
 #undef OPHIP_SIM_CASE
-    if ((parts & 1) && !lazy) {
+    if (do_conf && !lazy) {
         ConfArgs fa{conf, rowstat, colstat, rowbest, reinterpret_cast<unsigned*>(colmax), N, M, nspan, spanw, nrb, thr};
         const bool vec = M % 4 == 0, fast = nsplit != 0;
         if (vec && fast) OPHIP_LAUNCH("conf", stream, (conf_kernel<true, true>), dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
@@ -1099,13 +1103,14 @@ extern "C" int ophip_coarse_match_select(const float* feat3d, const float* feat2
 // ophip_coarse_match with the reference's optional inputs of padded / resized query images: query_mask [B][M] (1 = real cell, 0 = padding;
 // data["query_image_mask"].flatten(-2), coarse_matching.py:108-114: -1e9 is added to the padded cells' columns of the similarity, so
 // their confidences are exactly 0) and query_scale [B][2] = data["query_image_scale"] ((h, w) factors, coarse_matching.py:224: mkpts_query_c
-// = (x, y) * scale * query_scale[b][[1, 0]]).  Either may be NULL.  parts: 3 = the whole stage, 1 / 2 = the _conf / _select halves.
+// = (x, y) * scale * query_scale[b][[1, 0]]).  Either may be NULL.  parts (bit mask): 3 = the whole stage, 1 / 2 = the _conf / _select halves, 4 / 8 = the two halves of 1 (similarity
+// tiles with their statistics | statistics merge + confidence pass), see coarse_impl.
 extern "C" int ophip_coarse_match_masked(const float* feat3d, const float* feat2d, const float* keypoints3d, long long kpts_bstride,
                                          int B, int N, int M, int wc, double temperature, float thr, int border_rm, float scale,
                                          float* conf, float* workspace, long long* b_ids, long long* i_ids, long long* j_ids,
                                          float* mconf, float* mkpts3d, float* mkpts_c, long long* m_bids, unsigned char* gt_mask,
                                          int* count, int nsplit, int parts, const unsigned char* query_mask, const float* query_scale, void* stream) {
-    if (parts < 1 || parts > 3) return ophip_bad_arg(__func__, "parts must be 1 (conf), 2 (select) or 3 (both)");
+    if (parts < 1 || parts > 15) return ophip_bad_arg(__func__, "parts: bit mask of 1 (= 4 | 8: similarity | confidence), 2 (select)");
     return coarse_impl(parts, 0, 0, 1e-4, feat3d, feat2d, keypoints3d, kpts_bstride, B, N, M, wc, temperature, thr, border_rm, scale, conf, workspace,
                        b_ids, i_ids, j_ids, mconf, mkpts3d, mkpts_c, m_bids, gt_mask, count, nsplit, stream, query_mask, query_scale);
 }

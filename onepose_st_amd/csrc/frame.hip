@@ -13,16 +13,31 @@
 namespace {
 
 constexpr int kSlots = 16;          // frames that may be in flight between enqueue and wait
+// The fine stage + read-back of a frame, kept back until the NEXT frame's encoder is queued (see ophip_frame_enqueue): everything
+// ophip_fine_refine_bf16 and the copy need.  The caller keeps the buffers alive until ophip_frame_wait() on the frame's ticket.
+struct FineJob {
+    bool pending = false;
+    hipStream_t s_main = nullptr, s_fine = nullptr, s_copy = nullptr;
+    const float* ff = nullptr; long long fs_b = 0, fs_c = 0, fs_y = 0, fs_x = 0; int hf = 0, wf = 0;
+    const float* desc_f = nullptr; long long desc_f_bs = 0, desc_f_cs = 0;
+    const long long *b_ids = nullptr, *i_ids = nullptr, *j_ids = nullptr; const int* count = nullptr; int cap = 0;
+    const float* mkc = nullptr; const void* w_fine = nullptr; int n_fine = 0; unsigned fine_cross_bits = 0; int fine_encoder_enable = 0;
+    int wc = 0, stride = 0; float fine_scale = 0.f;
+    float *expec = nullptr, *mk2d = nullptr;
+    void* host_dst = nullptr; const void* result_src = nullptr; size_t host_bytes = 0;
+};
 struct Slot {
-    hipEvent_t prep_done = nullptr, coarse_done = nullptr, fine_done = nullptr, ready = nullptr;
+    hipEvent_t prep_done = nullptr, coarse_done = nullptr, fine_done = nullptr, ready = nullptr, enc_done = nullptr;
     int dev = -1;
     int gen = 0;                     // how often the slot has been handed out: a ticket is gen * kSlots + index
     bool recorded = false;           // `ready` has been recorded for the current generation
+    FineJob job;
 };
 struct DevState {
     Slot slots[kSlots];
     int next = 0;
-    std::unordered_map<hipStream_t, hipEvent_t> last_fine;      // compute stream -> fine_done of the last frame enqueued on it
+    std::unordered_map<hipStream_t, hipEvent_t> last_fine;      // compute stream -> fine_done of the last fine stage LAUNCHED for it
+    std::unordered_map<hipStream_t, int> deferred;              // compute stream -> slot whose fine stage is still kept back
 };
 std::mutex g_mu;
 std::unordered_map<int, DevState> g_dev;
@@ -31,7 +46,7 @@ size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 int make_events(Slot& s, int dev) {
     if (s.ready && s.dev == dev) return 0;
-    hipEvent_t* ev[4] = {&s.prep_done, &s.coarse_done, &s.fine_done, &s.ready};
+    hipEvent_t* ev[5] = {&s.prep_done, &s.coarse_done, &s.fine_done, &s.ready, &s.enc_done};
     for (auto e : ev) {
         hipError_t rc = hipEventCreateWithFlags(e, hipEventDisableTiming);
         if (rc != hipSuccess) return ophip_fail(rc, "hipEventCreateWithFlags(frame)");
@@ -52,6 +67,37 @@ int make_events(Slot& s, int dev) {
         const hipError_t e__ = (call);                  \
         if (e__ != hipSuccess) return ophip_fail(e__, what); \
     } while (0)
+
+namespace {
+// fine stage (a9-a11) + read-back of slot `s` on its side streams, ordered behind `after` (an event of its compute stream)
+int launch_fine_job(int dev, Slot& s, hipEvent_t after) {
+    FineJob& j = s.job;
+    if (j.s_fine != j.s_main) FR_HIP(hipStreamWaitEvent(j.s_fine, after, 0), "hipStreamWaitEvent(fine job)");
+    FR_CHECK(ophip_fine_refine_bf16(j.ff, j.fs_b, j.fs_c, j.fs_y, j.fs_x, j.hf, j.wf, j.desc_f, j.desc_f_bs, j.desc_f_cs, j.b_ids, j.i_ids, j.j_ids,
+                                    j.count, j.cap, j.mkc, j.w_fine, j.n_fine, j.fine_cross_bits, j.fine_encoder_enable, 3, j.wc, j.stride,
+                                    j.fine_scale, j.expec, j.mk2d, nullptr, nullptr, j.s_fine));
+    FR_HIP(hipEventRecord(s.fine_done, j.s_fine), "hipEventRecord(fine)");
+    // ---- read-back of the result block (count | b_ids | 3D points | refined 2D points) behind the fine stage ---------------------
+    FR_HIP(hipStreamWaitEvent(j.s_copy, s.fine_done, 0), "hipStreamWaitEvent(fine)");
+    FR_HIP(hipMemcpyAsync(j.host_dst, j.result_src, j.host_bytes, hipMemcpyDeviceToHost, j.s_copy), "hipMemcpyAsync(result block)");
+    FR_HIP(hipEventRecord(s.ready, j.s_copy), "hipEventRecord(ready)");
+    std::lock_guard<std::mutex> lk(g_mu);
+    DevState& st = g_dev[dev];
+    if (st.last_fine.size() > 64) st.last_fine.clear();
+    st.last_fine[j.s_main] = s.fine_done;                   // published only once it is recorded: the next encoder on s_main orders behind it
+    auto it = st.deferred.find(j.s_main);
+    if (it != st.deferred.end() && &st.slots[it->second] == &s) st.deferred.erase(it);
+    j.pending = false;
+    s.recorded = true;
+    return 0;
+}
+
+// OPHIP_FRAME_DEFER_FINE=0: the fine stage follows its own frame's selection at once (the round-2 order)
+bool defer_fine_enabled() {
+    static const bool on = [] { const char* e = getenv("OPHIP_FRAME_DEFER_FINE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+}  // namespace
 
 extern "C" int ophip_frame_layout(const ophip_frame_desc* d, int transpose_fine, int external_x3d, ophip_frame_layout_t* L) {
     if (!d || !L) return ophip_bad_arg(__func__, "null pointer");
@@ -102,9 +148,19 @@ extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_
     const int B = d->B, N = d->N, M = d->M, cap = B * N;
     int dev = 0;
     FR_HIP(hipGetDevice(&dev), "hipGetDevice");
+    // Order of a pipeline's frames on the chip (defer mode, the default; the caller passes distinct side streams):
+    //     s_main:  encoder(t+1) | similarity(t+1) | statistics merge, confidence, selection (t+1) ...... | encoder(t+2) ...
+    //     s_fine:                                 | fine stage(t)  ------------------------------------>|
+    // Frame t's fine stage is kept back until frame t + 1's encoder and similarity tiles are queued and runs BESIDE the HBM-bound half
+    // of frame t + 1's coarse matching (conf_kernel streams 269 MB and needs no matrix pipe; the fine stage is matrix-bound and moves
+    // little).  The encoder's 150 KB workgroups leave no LDS for a second kernel on a CU (it never shares the chip with a fine stage, as
+    // before).  A frame with no successor is completed by ophip_frame_wait() (or ophip_frame_order_after_fine()).
+    const bool defer = defer_fine_enabled() && s_fine != s_main;
     Slot* slot;
+    Slot* kept = nullptr;             // the previous frame of this compute stream whose fine stage is still kept back
     int idx, gen;
     hipEvent_t prev_fine = nullptr, prev_ready = nullptr;
+    bool stale_job = false;
     {
         std::lock_guard<std::mutex> lk(g_mu);
         DevState& st = g_dev[dev];
@@ -112,9 +168,18 @@ extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_
         st.next = (st.next + 1) % kSlots;
         slot = &st.slots[idx];
         FR_CHECK(make_events(*slot, dev));
+        stale_job = slot->job.pending;
+    }
+    // (a slot that comes round with its fine stage still kept back -- its stream saw no further frame --: complete that frame first)
+    if (stale_job) FR_CHECK(launch_fine_job(dev, *slot, slot->coarse_done));
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        DevState& st = g_dev[dev];
         if (slot->recorded) prev_ready = slot->ready;
         auto it = st.last_fine.find(s_main);
         if (it != st.last_fine.end()) prev_fine = it->second;
+        auto dt = st.deferred.find(s_main);
+        if (dt != st.deferred.end()) kept = &st.slots[dt->second];
     }
     // a slot comes round again after kSlots frames: its previous frame must have left the GPU before its events are re-recorded
     // (normally long done -- a pipeline keeps a few frames in flight --, then this returns at once)
@@ -179,6 +244,19 @@ extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_
     float* mk3d = F(L->result + 16 + 8 * (size_t)cap);
     float* mk2d = F(L->result + 16 + 20 * (size_t)cap);
     unsigned char* gt_mask = reinterpret_cast<unsigned char*>(blob + L->gt_mask);
+    if (kept) {
+        // the similarity tiles first, alone (matrix-bound like the fine stage: side by side the two only stretch each other -- 292 + 291 us
+        // against 80 + 236 us apart, rocprof trace); then the previous frame's fine stage, BESIDE this frame's HBM-bound half (statistics
+        // merge, conf_kernel, selection: ~120 us that need no matrix pipe)
+        FR_CHECK(ophip_coarse_match_masked(x3, x2, kpts, kpts_bs, B, N, M, d->wc, d->temperature, d->thr, d->border_rm, d->scale_c, conf, cws,
+                                           b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count,
+                                           3 | OPHIP_COARSE_PLANES_READY, 4, nullptr, nullptr, s_main));
+        FR_HIP(hipEventRecord(slot->enc_done, s_main), "hipEventRecord(similarity)");
+        FR_CHECK(launch_fine_job(dev, *kept, slot->enc_done));
+        FR_CHECK(ophip_coarse_match_masked(x3, x2, kpts, kpts_bs, B, N, M, d->wc, d->temperature, d->thr, d->border_rm, d->scale_c, conf, cws,
+                                           b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count,
+                                           3 | OPHIP_COARSE_PLANES_READY, 8, nullptr, nullptr, s_main));
+    } else
     FR_CHECK(ophip_coarse_match_conf(x3, x2, kpts, kpts_bs, B, N, M, d->wc, d->temperature, d->thr, d->border_rm, d->scale_c, conf, cws,
                                      b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count,
                                      3 | OPHIP_COARSE_PLANES_READY, s_main));
@@ -186,7 +264,30 @@ extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_
     // (the next encoder waits for it anyway), so selection + fine stage stay in order on the compute stream: a dependent kernel
     // on the same queue starts ~2 us after its producer, one behind a cross-stream event 10-17 us after (rocprof trace).
     // (1265 against 1239 frames/s over three runs each at c2)
-    if (s_prep) s_fine = s_main;
+    if (s_prep && !defer) s_fine = s_main;
+    if (defer) {
+        // selection stays in order behind conf_kernel on the compute stream (a dependent kernel on the same queue starts ~2 us after its
+        // producer); the fine stage is kept back for the next call
+        FR_CHECK(ophip_coarse_match_select(x3, x2, kpts, kpts_bs, B, N, M, d->wc, d->temperature, d->thr, d->border_rm, d->scale_c, conf, cws,
+                                           b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count, 3, s_main));
+        FR_HIP(hipEventRecord(slot->coarse_done, s_main), "hipEventRecord(coarse)");
+        FineJob& j = slot->job;
+        j.s_main = s_main; j.s_fine = s_fine; j.s_copy = s_copy;
+        j.ff = ff; j.fs_b = fs_b; j.fs_c = fs_c; j.fs_y = fs_y; j.fs_x = fs_x; j.hf = d->hf; j.wf = d->wf;
+        j.desc_f = desc_f; j.desc_f_bs = desc_f_bs; j.desc_f_cs = desc_f_cs;
+        j.b_ids = b_ids; j.i_ids = I64(L->i_ids); j.j_ids = I64(L->j_ids); j.count = count; j.cap = cap;
+        j.mkc = F(L->mkc); j.w_fine = d->w_fine; j.n_fine = d->n_fine; j.fine_cross_bits = d->fine_cross_bits; j.fine_encoder_enable = d->fine_encoder_enable;
+        j.wc = d->wc; j.stride = d->hf / d->hc; j.fine_scale = d->fine_scale;
+        j.expec = F(L->expec); j.mk2d = mk2d;
+        j.host_dst = host_dst; j.result_src = blob + L->result; j.host_bytes = host_bytes;
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            j.pending = true;
+            g_dev[dev].deferred[s_main] = idx;
+        }
+        *slot_out = gen * kSlots + idx;
+        return 0;
+    }
     if (s_fine != s_main) {
         FR_HIP(hipEventRecord(slot->coarse_done, s_main), "hipEventRecord(coarse)");
         FR_HIP(hipStreamWaitEvent(s_fine, slot->coarse_done, 0), "hipStreamWaitEvent(coarse)");
@@ -222,10 +323,18 @@ extern "C" int ophip_frame_wait(int ticket) {
     int dev = 0;
     FR_HIP(hipGetDevice(&dev), "hipGetDevice");
     hipEvent_t ev;
+    Slot* kept = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        Slot& s = g_dev[dev].slots[slot];
+        if (s.gen > gen) return 0;                          // the slot was handed out again: enqueue waited for this frame before that
+        if (s.gen == gen && s.job.pending) kept = &s;       // no later frame on its stream yet: its fine stage goes out now
+    }
+    if (kept) FR_CHECK(launch_fine_job(dev, *kept, kept->coarse_done));
     {
         std::lock_guard<std::mutex> lk(g_mu);
         const Slot& s = g_dev[dev].slots[slot];
-        if (s.gen > gen) return 0;                          // the slot was handed out again: enqueue waited for this frame before that
+        if (s.gen > gen) return 0;
         if (s.gen < gen || !s.recorded) return ophip_bad_arg(__func__, "ticket of a frame that was never (completely) enqueued on this device");
         ev = s.ready;
     }
@@ -237,6 +346,14 @@ extern "C" int ophip_frame_order_after_fine(void* compute_stream) {
     int dev = 0;
     FR_HIP(hipGetDevice(&dev), "hipGetDevice");
     hipEvent_t ev = nullptr;
+    Slot* kept = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        DevState& st = g_dev[dev];
+        auto dt = st.deferred.find((hipStream_t)compute_stream);
+        if (dt != st.deferred.end()) kept = &st.slots[dt->second];
+    }
+    if (kept) FR_CHECK(launch_fine_job(dev, *kept, kept->coarse_done));      // a kept-back fine stage goes out first
     {
         std::lock_guard<std::mutex> lk(g_mu);
         auto& m = g_dev[dev].last_fine;

@@ -867,6 +867,61 @@ def test_frame_call_equals_the_stage_by_stage_path(sd, cfg, dev):
     assert fast._frame_plans and not slow._frame_plans
 
 
+def test_deferred_fine_stage_is_bit_identical_to_the_in_order_frame(sd, cfg, dev):
+    """ophip_frame_enqueue keeps frame t's fine stage back until frame t + 1's encoder and similarity tiles are queued (it then runs
+    beside frame t + 1's HBM-bound confidence pass); OPHIP_FRAME_DEFER_FINE=0 launches it behind its own selection.  Both orders, a
+    pipeline three frames deep with the input kernels on their side stream, a frame finished with no successor and one dropped
+    unfinished: every output bit for bit the same."""
+    import subprocess, sys, json
+    code = r'''
+import os, sys, torch, hashlib, json
+sys.path.insert(0, os.getcwd())
+from onepose_st_amd.config import default_config
+from onepose_st_amd.model import OnePosePlus_model
+from onepose_st_amd.synthetic import make_synthetic_inputs, make_synthetic_state_dict
+cfg = default_config(); sd = make_synthetic_state_dict(0, cfg); dev = torch.device("cuda:0")
+m = OnePosePlus_model(cfg).eval(); m.load_state_dict(sd, strict=True); m.to(dev)
+frames = [make_synthetic_inputs(sd, n_points=1500, image_hw=(160, 224), n_plant=500, seed=21, config=cfg, frame=f) for f in range(4)]
+obj = {k: frames[0][k].to(dev) for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db")}
+feats = [(f["feat_c"].to(dev), f["feat_f"].to(dev)) for f in frames]
+keys = ("i_ids", "j_ids", "mconf", "mkpts_query_c", "mkpts_query_f", "expec_f", "mkpts_3d_db")
+torch.cuda.synchronize()
+out = []
+def digest(d, p):
+    h = hashlib.sha256()
+    for k in keys:
+        h.update(d[k].cpu().numpy().tobytes())
+    h.update(p.host["mkpts_2d"].tobytes())
+    return h.hexdigest()
+st = torch.cuda.Stream(device=dev)
+with torch.cuda.stream(st):
+    inflight = []
+    for i in range(10):
+        d = dict(obj)
+        inflight.append((d, m.enqueue_features(d, *feats[i % 4], frames[0]["image_hw"], host_copy=True, inputs_ready=True)))
+        if i == 5:
+            inflight.pop()                       # dropped unfinished (its fine stage is still kept back at this point)
+        if len(inflight) >= 3:
+            d0, p0 = inflight.pop(0); p0.finish(); out.append(digest(d0, p0))
+    while inflight:
+        d0, p0 = inflight.pop(0); p0.finish(); out.append(digest(d0, p0))
+    d = dict(obj)
+    p = m.enqueue_features(d, *feats[2], frames[0]["image_hw"], host_copy=True)       # alone: finished with no successor
+    p.finish(); out.append(digest(d, p))
+torch.cuda.synchronize()
+print(json.dumps(out))
+'''
+    res = {}
+    for mode in ("1", "0"):
+        env = dict(os.environ, OPHIP_FRAME_DEFER_FINE=mode)
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                           cwd=os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+        assert p.returncode == 0, p.stderr[-3000:]
+        res[mode] = json.loads(p.stdout.strip().splitlines()[-1])
+    assert len(res["1"]) == 10 and len(set(res["1"])) == 4          # four distinct frames, cycled
+    assert res["1"] == res["0"]
+
+
 def test_object_cache_is_bit_identical(sd, cfg, dev):
     """config["hip_cache_object"]: the keypoint encoding (rows a2 + a3) of a resident object block is computed once and re-used
     by the following frames -- same results bit for bit as the uncached model; a changed block (or an in-place edit) re-encodes."""
