@@ -216,8 +216,14 @@ int ophip_fine_refine_bf16_scaled(const float* feat_f, long long fs_b, long long
  *   that held it, and ophip_frame_wait() of a ticket whose set has been handed out again returns at once (that frame is done).
  * Result block at offset `result`: int32 count @0, int64 b_ids[cap] @16, float mkpts3d[cap][3], float mkpts_query_f[cap][2],
  *   cap = B * N; the other outputs (conf_matrix, i_ids, j_ids, m_bids, gt_mask, mconf, mkpts_query_c, expec_f) at their offsets.
- * ophip_frame_order_after_fine(stream): makes `stream` wait for the fine stage of the last frame enqueued on it through this
- *   entry point (for callers that mix it with stage-by-stage calls and want attn_apply never to share the chip with it). */
+ *   Pipelining: when s_fine is a stream of its own, the fine stage (a9-a11) and the read-back of frame t are kept back and
+ *   launched by the NEXT ophip_frame_enqueue() on the same s_main, behind that frame's similarity tiles -- they then run beside its
+ *   HBM-bound confidence pass instead of in front of it (OPHIP_FRAME_DEFER_FINE=0: every frame in order).  A
+ *   frame with no successor is completed by ophip_frame_wait() on its ticket.  A throughput pipeline therefore keeps three frames in
+ *   flight: enqueue t + 2, then wait for t.
+ * ophip_frame_order_after_fine(stream): completes a kept-back fine stage of `stream` and makes `stream` wait for the fine stage of
+ *   the last frame enqueued on it through this entry point (for callers that mix it with stage-by-stage calls and want attn_apply
+ *   never to share the chip with it). */
 typedef struct ophip_frame_desc {
     int B, N, M, hc, wc, hf, wf, cf;             /* cf: channels of the fine map (128) */
     int lazy_conf;                                /* 1: conf_matrix is not materialised (layout.conf = 0; result block int32 @4 = "re-run eagerly" flag) */
