@@ -676,7 +676,9 @@ __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
                 const int jq = jb + 4 * tid + 1024 * u;
                 if (VEC) {
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (jq < je) v = *reinterpret_cast<const f32x4*>(row + jq);
+                    // streamed once in, once out: non-temporal, so that the pass does not wash the L2 of what runs beside it (the previous
+                    // frame's fine stage re-reads its 1.3 MB of weights per match pair: 1403 against 1363 frames/s at c2)
+                    if (jq < je) v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + jq));
                     dst[q][u][0] = v[0]; dst[q][u][1] = v[1]; dst[q][u][2] = v[2]; dst[q][u][3] = v[3];
                 } else {
 #pragma unroll
@@ -714,7 +716,7 @@ __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
                         }
                         if (VEC) {
                             f32x4 v = {cur[q][u][0], cur[q][u][1], cur[q][u][2], cur[q][u][3]};
-                            *reinterpret_cast<f32x4*>(row + jq) = v;
+                            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(row + jq));
                         } else {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) if (jq + e < je) row[jq + e] = cur[q][u][e];

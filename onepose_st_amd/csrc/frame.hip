@@ -69,14 +69,16 @@ int make_events(Slot& s, int dev) {
     } while (0)
 
 namespace {
-// fine stage (a9-a11) + read-back of slot `s` on its side streams, ordered behind `after` (an event of its compute stream)
-int launch_fine_job(int dev, Slot& s, hipEvent_t after) {
+// fine stage (a9-a11) + read-back of slot `s` on its side streams, behind `after` (an event of its compute stream later than its own
+// selection; NULL: that selection's event)
+int launch_fine_job(int dev, Slot& s, hipEvent_t after = nullptr) {
     FineJob& j = s.job;
-    if (j.s_fine != j.s_main) FR_HIP(hipStreamWaitEvent(j.s_fine, after, 0), "hipStreamWaitEvent(fine job)");
+    const hipStream_t on = j.s_fine;
+    FR_HIP(hipStreamWaitEvent(on, after ? after : s.coarse_done, 0), "hipStreamWaitEvent(fine job)");
     FR_CHECK(ophip_fine_refine_bf16(j.ff, j.fs_b, j.fs_c, j.fs_y, j.fs_x, j.hf, j.wf, j.desc_f, j.desc_f_bs, j.desc_f_cs, j.b_ids, j.i_ids, j.j_ids,
                                     j.count, j.cap, j.mkc, j.w_fine, j.n_fine, j.fine_cross_bits, j.fine_encoder_enable, 3, j.wc, j.stride,
-                                    j.fine_scale, j.expec, j.mk2d, nullptr, nullptr, j.s_fine));
-    FR_HIP(hipEventRecord(s.fine_done, j.s_fine), "hipEventRecord(fine)");
+                                    j.fine_scale, j.expec, j.mk2d, nullptr, nullptr, on));
+    FR_HIP(hipEventRecord(s.fine_done, on), "hipEventRecord(fine)");
     // ---- read-back of the result block (count | b_ids | 3D points | refined 2D points) behind the fine stage ---------------------
     FR_HIP(hipStreamWaitEvent(j.s_copy, s.fine_done, 0), "hipStreamWaitEvent(fine)");
     FR_HIP(hipMemcpyAsync(j.host_dst, j.result_src, j.host_bytes, hipMemcpyDeviceToHost, j.s_copy), "hipMemcpyAsync(result block)");
@@ -152,8 +154,8 @@ extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_
     //     s_main:  encoder(t+1) | similarity(t+1) | statistics merge, confidence, selection (t+1) ...... | encoder(t+2) ...
     //     s_fine:                                 | fine stage(t)  ------------------------------------>|
     // Frame t's fine stage is kept back until frame t + 1's encoder and similarity tiles are queued and runs BESIDE the HBM-bound half
-    // of frame t + 1's coarse matching (conf_kernel streams 269 MB and needs no matrix pipe; the fine stage is matrix-bound and moves
-    // little).  The encoder's 150 KB workgroups leave no LDS for a second kernel on a CU (it never shares the chip with a fine stage, as
+    // of frame t + 1's coarse matching (conf_kernel streams 269 MB, with non-temporal accesses so that it does not evict the fine
+    // stage's weights from L2, and needs no matrix pipe; the fine stage is matrix-bound and moves little).  The encoder's 150 KB workgroups leave no LDS for a second kernel on a CU (it never shares the chip with a fine stage, as
     // before).  A frame with no successor is completed by ophip_frame_wait() (or ophip_frame_order_after_fine()).
     const bool defer = defer_fine_enabled() && s_fine != s_main;
     Slot* slot;
@@ -171,7 +173,7 @@ extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_
         stale_job = slot->job.pending;
     }
     // (a slot that comes round with its fine stage still kept back -- its stream saw no further frame --: complete that frame first)
-    if (stale_job) FR_CHECK(launch_fine_job(dev, *slot, slot->coarse_done));
+    if (stale_job) FR_CHECK(launch_fine_job(dev, *slot));
     {
         std::lock_guard<std::mutex> lk(g_mu);
         DevState& st = g_dev[dev];
@@ -244,19 +246,7 @@ extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_
     float* mk3d = F(L->result + 16 + 8 * (size_t)cap);
     float* mk2d = F(L->result + 16 + 20 * (size_t)cap);
     unsigned char* gt_mask = reinterpret_cast<unsigned char*>(blob + L->gt_mask);
-    if (kept) {
-        // the similarity tiles first, alone (matrix-bound like the fine stage: side by side the two only stretch each other -- 292 + 291 us
-        // against 80 + 236 us apart, rocprof trace); then the previous frame's fine stage, BESIDE this frame's HBM-bound half (statistics
-        // merge, conf_kernel, selection: ~120 us that need no matrix pipe)
-        FR_CHECK(ophip_coarse_match_masked(x3, x2, kpts, kpts_bs, B, N, M, d->wc, d->temperature, d->thr, d->border_rm, d->scale_c, conf, cws,
-                                           b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count,
-                                           3 | OPHIP_COARSE_PLANES_READY, 4, nullptr, nullptr, s_main));
-        FR_HIP(hipEventRecord(slot->enc_done, s_main), "hipEventRecord(similarity)");
-        FR_CHECK(launch_fine_job(dev, *kept, slot->enc_done));
-        FR_CHECK(ophip_coarse_match_masked(x3, x2, kpts, kpts_bs, B, N, M, d->wc, d->temperature, d->thr, d->border_rm, d->scale_c, conf, cws,
-                                           b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count,
-                                           3 | OPHIP_COARSE_PLANES_READY, 8, nullptr, nullptr, s_main));
-    } else
+    if (!defer)
     FR_CHECK(ophip_coarse_match_conf(x3, x2, kpts, kpts_bs, B, N, M, d->wc, d->temperature, d->thr, d->border_rm, d->scale_c, conf, cws,
                                      b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count,
                                      3 | OPHIP_COARSE_PLANES_READY, s_main));
@@ -266,10 +256,19 @@ extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_
     // (1265 against 1239 frames/s over three runs each at c2)
     if (s_prep && !defer) s_fine = s_main;
     if (defer) {
-        // selection stays in order behind conf_kernel on the compute stream (a dependent kernel on the same queue starts ~2 us after its
-        // producer); the fine stage is kept back for the next call
-        FR_CHECK(ophip_coarse_match_select(x3, x2, kpts, kpts_bs, B, N, M, d->wc, d->temperature, d->thr, d->border_rm, d->scale_c, conf, cws,
-                                           b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count, 3, s_main));
+        // The similarity tiles first, alone: matrix-bound like the fine stage, and two matrix-bound kernels side by side only stretch
+        // each other (292 + 291 us together against 80 + 236 us apart, rocprof trace).  Then the previous frame's fine stage on the side
+        // stream, BESIDE this frame's HBM-bound half (statistics merge, conf_kernel, selection: ~120 us that need no matrix pipe).
+        // (Fine stage on the compute stream and the HBM-bound half on the side stream instead: the same within noise.)
+        FR_CHECK(ophip_coarse_match_masked(x3, x2, kpts, kpts_bs, B, N, M, d->wc, d->temperature, d->thr, d->border_rm, d->scale_c, conf, cws,
+                                           b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count,
+                                           3 | OPHIP_COARSE_PLANES_READY, 4, nullptr, nullptr, s_main));
+        FR_HIP(hipEventRecord(slot->enc_done, s_main), "hipEventRecord(similarity)");
+        // the kept-back fine stage of the previous frame: on the side stream, behind this frame's similarity tiles, beside the rest
+        if (kept) FR_CHECK(launch_fine_job(dev, *kept, slot->enc_done));
+        FR_CHECK(ophip_coarse_match_masked(x3, x2, kpts, kpts_bs, B, N, M, d->wc, d->temperature, d->thr, d->border_rm, d->scale_c, conf, cws,
+                                           b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count,
+                                           3 | OPHIP_COARSE_PLANES_READY, 8 | 2, nullptr, nullptr, s_main));
         FR_HIP(hipEventRecord(slot->coarse_done, s_main), "hipEventRecord(coarse)");
         FineJob& j = slot->job;
         j.s_main = s_main; j.s_fine = s_fine; j.s_copy = s_copy;
@@ -330,7 +329,7 @@ extern "C" int ophip_frame_wait(int ticket) {
         if (s.gen > gen) return 0;                          // the slot was handed out again: enqueue waited for this frame before that
         if (s.gen == gen && s.job.pending) kept = &s;       // no later frame on its stream yet: its fine stage goes out now
     }
-    if (kept) FR_CHECK(launch_fine_job(dev, *kept, kept->coarse_done));
+    if (kept) FR_CHECK(launch_fine_job(dev, *kept));
     {
         std::lock_guard<std::mutex> lk(g_mu);
         const Slot& s = g_dev[dev].slots[slot];
@@ -353,7 +352,7 @@ extern "C" int ophip_frame_order_after_fine(void* compute_stream) {
         auto dt = st.deferred.find((hipStream_t)compute_stream);
         if (dt != st.deferred.end()) kept = &st.slots[dt->second];
     }
-    if (kept) FR_CHECK(launch_fine_job(dev, *kept, kept->coarse_done));      // a kept-back fine stage goes out first
+    if (kept) FR_CHECK(launch_fine_job(dev, *kept));      // a kept-back fine stage goes out first
     {
         std::lock_guard<std::mutex> lk(g_mu);
         auto& m = g_dev[dev].last_fine;
