@@ -81,7 +81,6 @@ __global__ __launch_bounds__(KS_THREADS) void kpt_stats_kernel(const float* __re
 // ---------------------------------------------------------------------------------------------
 constexpr int KD = 256;                    // descriptor_dim
 constexpr int L0 = 8 + OPHIP_PAD, L1 = 32 + OPHIP_PAD, L2 = 64 + OPHIP_PAD, L3 = 128 + OPHIP_PAD, LO = KD + OPHIP_PAD;
-constexpr int LD_D = 33;
 
 struct KptArgs {
     const float* kpts; long long kbs;     // [B][N][3]
@@ -99,8 +98,7 @@ __global__ __launch_bounds__(256) void kpt_encode_kernel(KptArgs p) {
     float* A1 = A0 + 32 * L0;               // [32][L1]
     float* A2 = A1 + 32 * L1;               // [32][L2]
     float* A3 = A2 + 32 * L2;               // [32][L3]
-    float* Dt = A3 + 32 * L3;               // [256][33] descriptor tile, channel-major
-    float* Ot = Dt + KD * LD_D;             // [32][LO]
+    float* Ot = A3 + 32 * L3;               // [32][LO] descriptor tile, point-major; the MLP's output is added in place
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.x * 32, b = blockIdx.y;
@@ -112,11 +110,12 @@ __global__ __launch_bounds__(256) void kpt_encode_kernel(KptArgs p) {
         if (d < 3 && n0 + row < p.N) v = (p.kpts[(size_t)b * p.kbs + (size_t)(n0 + row) * 3 + d] - p.stats[4 * b + d]) / scaling;
         A0[row * L0 + d] = v;
     }
-    // descriptor tile: coalesced along n
+    // descriptor tile: read coalesced along n, written transposed (one tile instead of a channel-major and a point-major one: 65 KB
+    // of LDS per workgroup instead of 99, so that the kernel fits beside a fine-stage workgroup on a CU)
     const float* dsc = p.desc + (size_t)b * p.dbs;
     for (int i = tid; i < KD * 32; i += 256) {
         const int c = i >> 5, n = i & 31;
-        Dt[c * LD_D + n] = (n0 + n < p.N) ? dsc[(size_t)c * p.N + n0 + n] : 0.f;
+        Ot[n * LO + c] = (n0 + n < p.N) ? dsc[(size_t)c * p.N + n0 + n] : 0.f;
     }
     __syncthreads();
     // 3 -> 32
@@ -166,7 +165,7 @@ __global__ __launch_bounds__(256) void kpt_encode_kernel(KptArgs p) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int row = acc_row(reg, h);
-                Ot[row * LO + c] = Dt[c * LD_D + row] + (acc[t][reg] + bias);
+                Ot[row * LO + c] = Ot[row * LO + c] + (acc[t][reg] + bias);
             }
         }
     }
@@ -296,7 +295,7 @@ extern "C" int ophip_kpt_encode(const float* keypoints3d, long long kpts_bstride
     a.w4 = reinterpret_cast<const f32x4*>(w); w += 256 * 128;
     a.b1 = w; a.b2 = w + 32; a.b3 = w + 96; a.b4 = w + 224;
     a.out = out_bnc; a.B = B; a.N = N;
-    const size_t lds = (size_t)(32 * (L0 + L1 + L2 + L3 + LO) + KD * LD_D) * sizeof(float);
+    const size_t lds = (size_t)(32 * (L0 + L1 + L2 + L3 + LO)) * sizeof(float);
     if (int rc = ophip_lds_attr(reinterpret_cast<const void*>(kpt_encode_kernel), lds, "hipFuncSetAttribute(kpt_encode)")) return rc;
     OPHIP_LAUNCH("kpt_encode", stream, kpt_encode_kernel, dim3((N + 31) / 32, B), dim3(256), lds, stream, a);
     OPHIP_CHECK_LAUNCH();
