@@ -262,13 +262,13 @@ extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_
         // (Fine stage on the compute stream and the HBM-bound half on the side stream instead: the same within noise.)
         FR_CHECK(ophip_coarse_match_masked(x3, x2, kpts, kpts_bs, B, N, M, d->wc, d->temperature, d->thr, d->border_rm, d->scale_c, conf, cws,
                                            b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count,
-                                           3 | OPHIP_COARSE_PLANES_READY, 4, nullptr, nullptr, s_main));
+                                           3 | OPHIP_COARSE_PLANES_READY, d->lazy_conf ? 1 : 4, nullptr, nullptr, s_main));      // (lazy form: its candidate pass is a second matrix-bound tile pass)
         FR_HIP(hipEventRecord(slot->enc_done, s_main), "hipEventRecord(similarity)");
         // the kept-back fine stage of the previous frame: on the side stream, behind this frame's similarity tiles, beside the rest
         if (kept) FR_CHECK(launch_fine_job(dev, *kept, slot->enc_done));
         FR_CHECK(ophip_coarse_match_masked(x3, x2, kpts, kpts_bs, B, N, M, d->wc, d->temperature, d->thr, d->border_rm, d->scale_c, conf, cws,
                                            b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count,
-                                           3 | OPHIP_COARSE_PLANES_READY, 8 | 2, nullptr, nullptr, s_main));
+                                           3 | OPHIP_COARSE_PLANES_READY, d->lazy_conf ? 2 : (8 | 2), nullptr, nullptr, s_main));
         FR_HIP(hipEventRecord(slot->coarse_done, s_main), "hipEventRecord(coarse)");
         FineJob& j = slot->job;
         j.s_main = s_main; j.s_fine = s_fine; j.s_copy = s_copy;

@@ -116,6 +116,7 @@ class OnePosePlus_model(nn.Module):
             raise ValueError(f"hip_precision {self.precision!r}: expected 'f32', 'bf16x3' or 'bf16'")
         # backbone on the HIP convolution kernels (bf16 pipe modes only; exact-f32 mode keeps MIOpen's fp32 convolutions)
         self.hip_backbone = bool(config.get("hip_backbone", True)) and self.precision != "f32"
+        self.lazy_reruns = 0          # lazy conf_matrix: frames re-run eagerly because of an exact row tie (PendingFrame.finish)
         self._packed = None          # (key, dict of device weight blocks)
         self._packed_bb = None       # (key, backbone conv blocks)
         # fine stage (+ result read-back) on a second HIP stream: frame t's refinement then overlaps frame t + 1's input
@@ -810,6 +811,7 @@ class PendingFrame:
             # takes next can only be read from the stored row -> this frame again, eagerly (identical arithmetic, conf_matrix stored)
             self._release_pin()
             self.done = True
+            self.model.lazy_reruns += 1
             again = self._rerun()
             again.finish()
             self.host = again.host

@@ -13,6 +13,8 @@ cat $O/bench.json
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench20.json 2> $O/bench20.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --main-region-only > $O/bench_under_rocprof.json 2> $O/prof.err
 echo stats done
+python3 tools/timeline.py $O/stats 2 > $O/timeline.txt 2>&1 || true
+tail -12 $O/timeline.txt
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-pnp --main-region-only > /dev/null 2> $O/pmc_f.err
 echo fetch done
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-pnp --main-region-only > /dev/null 2> $O/pmc_w.err
@@ -33,3 +35,7 @@ python3 tools/time_coarse.py > $O/time_coarse.txt 2>&1
 # the N > 1 code path on this one-GPU box: two gloo ranks sharing the device (pinned CPU slices, per-rank PnP pools, broadcast)
 python3 bench.py --gpus 2 --share-device --dist-backend gloo --steps 40 --warmup 5 --no-cpu-baseline > $O/bench_2ranks_gloo_shared.json 2> $O/bench_2ranks.err || echo "2-rank rehearsal failed"
 tail -c 1200 $O/bench_2ranks_gloo_shared.json
+# the RCCL code path itself (process group on the device, broadcast of weights + object block, barriers, max / min over ranks) with ONE rank
+OPHIP_BENCH_FORCE_DIST=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 100 --warmup 10 --no-cpu-baseline --main-region-only > $O/bench_rccl_1rank.json 2> $O/bench_rccl_1rank.err || echo "RCCL rehearsal failed"
+tail -c 400 $O/bench_rccl_1rank.json
+find $O -name "*.csv" -size +3M -delete
