@@ -252,6 +252,9 @@ def main():
 
     def drain():
         last_data = None
+        for i, st in enumerate(streams):                  # no further frame on these streams: the last frame's kept-back fine stage goes out now
+            with torch.cuda.stream(st):
+                model.flush()
         while inflight:
             last_data = complete(inflight.pop(0))
         return last_data

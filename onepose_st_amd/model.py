@@ -520,6 +520,16 @@ class OnePosePlus_model(nn.Module):
         return pend
 
 
+    def flush(self):
+        """End of a sequence: no further frame is coming on the current stream, so the last frame's kept-back fine stage (it would otherwise
+        go out with the next ``enqueue`` or at its ``finish()``) is launched now, behind its own selection.  Optional -- ``finish()`` does it
+        as well, only later (after the frames before it have been waited for)."""
+        dev = torch.cuda.current_device()
+        main = torch.cuda.current_stream()
+        fkey = (str(torch.device("cuda", dev)), main.cuda_stream)
+        if fkey in self._frame_call_pending:
+            hip.call("ophip_frame_order_after_fine", ctypes.c_void_p(main.cuda_stream))
+
     def _side_stream(self, table, fkey, dev):
         st = table.get(fkey)
         if st is None:
