@@ -749,6 +749,11 @@ void refine_lm(const Problem& P, const unsigned char* mask, double* pose, int it
 namespace {
 
 constexpr int CH = 256;
+// Chunk 0 is the serial head of a frame's RANSAC (its best float score bounds every other chunk, so they wait for it): it is short.
+// A frame's pose latency is head + (floor - CH0) / threads + tail + refinement; with 256 trials the head was a quarter of it.
+constexpr int CH0 = 64;
+inline int chunk_len(int c) { return c == 0 ? CH0 : CH; }
+inline long long chunk_start(int c) { return c == 0 ? 0 : CH0 + (long long)(c - 1) * CH; }
 
 struct FloatBound {
     int cnt = 0;
@@ -797,7 +802,10 @@ struct Ransac {
         }
         thr2 = reproj * reproj; confidence = conf; min_iters = min_it; max_iters = max_it; seed = seed_;
     }
-    int full_chunks() const { return (min_iters < max_iters ? min_iters : max_iters) / CH; }
+    int full_chunks() const {
+        const int floor_ = min_iters < max_iters ? min_iters : max_iters;
+        return floor_ < CH0 ? 0 : 1 + (floor_ - CH0) / CH;
+    }
 
     // The scorer drops a hypothesis as soon as it can no longer beat the best one, and a hypothesis that is about as good as the
     // best can only be dropped once it has met the outliers (its count can then no longer exceed the best's and the cost decides).
@@ -826,7 +834,7 @@ struct Ransac {
         float& best_cost_f = bound.cost;
         int needed = best.cnt > 0 ? needed_for(best.cnt) : max_iters;
         int it = 0;
-        auto wanted = [&](int i) { return i < limit && (i < floor_in_chunk || (long long)chunk * CH + i < needed); };
+        auto wanted = [&](int i) { return i < limit && (i < floor_in_chunk || chunk_start(chunk) + i < needed); };
         // one hypothesis: float score with early rejection against the bound; a new float best is re-scored exactly (double)
         auto consider = [&](double* pose) {
             float kp[12];
@@ -929,10 +937,10 @@ struct Ransac {
     // chunks after the unconditional ones, one at a time, until the confidence criterion or max_iters stops them
     void run_tail(Candidate& best, FloatBound bound, int* iters_run) const {
         int c = full_chunks();
-        long long total = (long long)c * CH;
-        const int rem = (min_iters < max_iters ? min_iters : max_iters) - c * CH;
+        long long total = chunk_start(c);
+        const int rem = (int)((min_iters < max_iters ? min_iters : max_iters) - total);
         while (total < max_iters) {
-            const int limit = (int)((max_iters - total) < CH ? (max_iters - total) : CH);
+            const int limit = (int)((max_iters - total) < chunk_len(c) ? (max_iters - total) : chunk_len(c));
             const int ran = run_chunk(c, limit, c == full_chunks() ? rem : 0, best, bound);
             total += ran;
             if (ran < limit) break;
@@ -1000,7 +1008,7 @@ extern "C" int oppnp_ransac(const double* K, const float* pts2d, const float* pt
     for (int c = 0; c < R.full_chunks(); ++c) {
         Candidate local;
         FloatBound b = b0;
-        R.run_chunk(c, CH, CH, local, c == 0 ? b0 : b);
+        R.run_chunk(c, chunk_len(c), chunk_len(c), local, c == 0 ? b0 : b);
         if (c == 0) R.reorder_after_chunk0(local);
         if (local.better_than(best)) best = std::move(local);
     }
@@ -1075,7 +1083,7 @@ struct Pool {
             Job& job = *task.first;
             if (task.second < 0) { finish_job(job); continue; }
             if (task.second == 0) {                  // chunk 0 first, alone: its float best then bounds the others, which start now
-                job.R.run_chunk(0, CH, CH, job.chunk_best[0], job.b0);
+                job.R.run_chunk(0, CH0, CH0, job.chunk_best[0], job.b0);
                 job.R.reorder_after_chunk0(job.chunk_best[0]);          // before any other chunk of this job exists
                 const int nfull = (int)job.chunk_best.size();
                 if (nfull > 1) {
