@@ -39,7 +39,8 @@ struct DevState {
     std::unordered_map<hipStream_t, hipEvent_t> last_fine;      // compute stream -> fine_done of the last fine stage LAUNCHED for it
     std::unordered_map<hipStream_t, int> deferred;              // compute stream -> slot whose fine stage is still kept back
 };
-std::mutex g_mu;
+std::mutex g_mu;                      // the tables below
+std::mutex g_launch_mu;               // one thread at a time enqueues a frame or launches a kept-back fine stage (held around g_mu, never inside it)
 std::unordered_map<int, DevState> g_dev;
 
 size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -158,6 +159,7 @@ extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_
     // stage's weights from L2, and needs no matrix pipe; the fine stage is matrix-bound and moves little).  The encoder's 150 KB workgroups leave no LDS for a second kernel on a CU (it never shares the chip with a fine stage, as
     // before).  A frame with no successor is completed by ophip_frame_wait() (or ophip_frame_order_after_fine()).
     const bool defer = defer_fine_enabled() && s_fine != s_main;
+    std::lock_guard<std::mutex> launch_lock(g_launch_mu);
     Slot* slot;
     Slot* kept = nullptr;             // the previous frame of this compute stream whose fine stage is still kept back
     int idx, gen;
@@ -322,14 +324,17 @@ extern "C" int ophip_frame_wait(int ticket) {
     int dev = 0;
     FR_HIP(hipGetDevice(&dev), "hipGetDevice");
     hipEvent_t ev;
-    Slot* kept = nullptr;
     {
-        std::lock_guard<std::mutex> lk(g_mu);
-        Slot& s = g_dev[dev].slots[slot];
-        if (s.gen > gen) return 0;                          // the slot was handed out again: enqueue waited for this frame before that
-        if (s.gen == gen && s.job.pending) kept = &s;       // no later frame on its stream yet: its fine stage goes out now
+        std::lock_guard<std::mutex> launch_lock(g_launch_mu);
+        Slot* kept = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            Slot& s = g_dev[dev].slots[slot];
+            if (s.gen > gen) return 0;                      // the slot was handed out again: enqueue waited for this frame before that
+            if (s.gen == gen && s.job.pending) kept = &s;   // no later frame on its stream yet: its fine stage goes out now
+        }
+        if (kept) FR_CHECK(launch_fine_job(dev, *kept));
     }
-    if (kept) FR_CHECK(launch_fine_job(dev, *kept));
     {
         std::lock_guard<std::mutex> lk(g_mu);
         const Slot& s = g_dev[dev].slots[slot];
@@ -345,6 +350,7 @@ extern "C" int ophip_frame_order_after_fine(void* compute_stream) {
     int dev = 0;
     FR_HIP(hipGetDevice(&dev), "hipGetDevice");
     hipEvent_t ev = nullptr;
+    std::lock_guard<std::mutex> launch_lock(g_launch_mu);
     Slot* kept = nullptr;
     {
         std::lock_guard<std::mutex> lk(g_mu);

@@ -870,8 +870,8 @@ def test_frame_call_equals_the_stage_by_stage_path(sd, cfg, dev):
 def test_deferred_fine_stage_is_bit_identical_to_the_in_order_frame(sd, cfg, dev):
     """ophip_frame_enqueue keeps frame t's fine stage back until frame t + 1's encoder and similarity tiles are queued (it then runs
     beside frame t + 1's HBM-bound confidence pass); OPHIP_FRAME_DEFER_FINE=0 launches it behind its own selection.  Both orders, a
-    pipeline three frames deep with the input kernels on their side stream, a frame finished with no successor and one dropped
-    unfinished: every output bit for bit the same."""
+    pipeline three frames deep with the input kernels on their side stream (40 frames: the ring of 16 event sets comes round twice), a
+    frame finished with no successor and three dropped unfinished: every output bit for bit the same."""
     import subprocess, sys, json
     code = r'''
 import os, sys, torch, hashlib, json
@@ -896,10 +896,10 @@ def digest(d, p):
 st = torch.cuda.Stream(device=dev)
 with torch.cuda.stream(st):
     inflight = []
-    for i in range(10):
+    for i in range(40):                          # crosses the ring of 16 event sets twice
         d = dict(obj)
         inflight.append((d, m.enqueue_features(d, *feats[i % 4], frames[0]["image_hw"], host_copy=True, inputs_ready=True)))
-        if i == 5:
+        if i in (5, 21, 22):
             inflight.pop()                       # dropped unfinished (its fine stage is still kept back at this point)
         if len(inflight) >= 3:
             d0, p0 = inflight.pop(0); p0.finish(); out.append(digest(d0, p0))
@@ -918,7 +918,7 @@ print(json.dumps(out))
                            cwd=os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
         assert p.returncode == 0, p.stderr[-3000:]
         res[mode] = json.loads(p.stdout.strip().splitlines()[-1])
-    assert len(res["1"]) == 10 and len(set(res["1"])) == 4          # four distinct frames, cycled
+    assert len(res["1"]) == 38 and len(set(res["1"])) == 4          # four distinct frames, cycled
     assert res["1"] == res["0"]
 
 
