@@ -42,6 +42,86 @@ struct FineBArgs {
     unsigned long long* stamps;
 };
 
+// One match's attention in the fine stage.  Tokens 0..24 = the 5 x 5 window, 25 = the 3D point (rows 26..31: padding).  A token attends to
+// exactly one source set by layer kind -- "self": window -> window, 3D -> itself; "cross": window -> 3D, 3D -> window
+// (transformer.py:148-159 on the fine streams) -- and `qt` (Q of feature tile ft as D[feature][token]), `kt`, `vt` (K, V as D[token][feature])
+// are this wave's accumulators.  Returns the message tile D[feature][token] (linear_attention.py:29-61, v_length 25 resp. 1).
+//   window set: phi(K)^T V and Ksum tiles (two 16-wide heads per 32-wide tile, block-diagonal) and phi(Q) KV on the matrix pipe, split-bf16;
+//   3D set: ONE source token, so KV = phi(k3)^T v3 has rank one and the message is v3 * a / (a + eps) with a[token][head] = phi(q) . phi(k3):
+//   16 multiply-adds per lane in f32 (k3, v3 = row 25 of the K / V tiles, handed from their lanes to every lane through a 256-byte LDS
+//   strip of this wave) instead of two more KV tiles, their fragment conversions and 18 matrix instructions per match and layer.
+template <int NS>
+__device__ __forceinline__ f32x16 attend_match(f32x16& qt, const f32x16& kt, const f32x16& vt, bool cross, float* strip, int lane,
+                                               const bf16x8& ones, const bf16x8& zeros) {
+    const int r = lane & 31, h = lane >> 5;
+    const bool is3d = r == TOK3D;                 // on the token (lane) axis of D[feature][token] tiles
+    const bool use_w = cross ? is3d : !is3d;      // this token attends to the window set (else: the 3D token)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) qt[reg] = elu_plus_one_fast(qt[reg]);
+    // row 25 of the K / V tiles: register 13 of lanes 0..31 (acc_row(13, 0) == 25), one feature per lane
+    static_assert(acc_row(13, 0) == TOK3D, "the 3D token's row of a D[token][feature] tile");
+    if (h == 0) {
+        strip[r] = elu_plus_one_fast(kt[13]);
+        strip[32 + r] = vt[13];
+    }
+    // window set on the matrix pipe
+    auto f_kw = [&](int reg, float v) { return acc_row(reg, h) < WIN ? elu_plus_one_fast(v) : 0.f; };
+    auto f_vw = [&](int reg, float v) { return acc_row(reg, h) < WIN ? v * 0.04f : 0.f; };      // values / v_length (25)
+    const auto block_diag = [&](f32x16& t) {          // two 16-wide heads per 32-wide tile
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            if ((acc_row(reg, h) >> 4) != (r >> 4)) t[reg] = 0.f;
+    };
+    f32x16 num = zero16(), den = zero16();
+    {
+        f32x16 kvw = zero16(), ksw = zero16();
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            bf16x8 wh, wl2, vh, vl;
+            acc_frag_map<NS>(kt, st, f_kw, wh, wl2);
+            acc_frag_map<NS>(vt, st, f_vw, vh, vl);
+            kvw = mma_bf16<NS>(wh, wl2, vh, vl, kvw);
+            ksw = mma_bf16<NS>(wh, wl2, ones, zeros, ksw);
+        }
+        block_diag(kvw);
+        block_diag(ksw);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            bf16x8 qh, ql, ah, al;
+            acc_frag<NS>(qt, st, qh, ql);
+            acc_frag<NS>(kvw, st, ah, al); num = mma_bf16<NS>(ah, al, qh, ql, num);
+            acc_frag<NS>(ksw, st, ah, al); den = mma_bf16<NS>(ah, al, qh, ql, den);
+        }
+    }
+    // 3D set: this lane's 16 features of phi(k3) and v3 (features acc_row(reg, h) = 8 (reg >> 2) + 4 h + (reg & 3): four 16-byte reads each)
+    __builtin_amdgcn_wave_barrier();              // (LDS operations of one wave complete in order: only the compiler needs the fence)
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 k3 = *reinterpret_cast<const f32x4*>(strip + 8 * g + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (g < 2) a0 += qt[4 * g + j] * k3[j];           // features 0..15 of the tile: its first head
+            else a1 += qt[4 * g + j] * k3[j];
+        }
+    }
+    a0 += __shfl_xor(a0, 32, 64);
+    a1 += __shfl_xor(a1, 32, 64);
+    const float z0 = a0 * rcp_fast(a0 + 1e-6f), z1 = a1 * rcp_fast(a1 + 1e-6f);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 v3 = *reinterpret_cast<const f32x4*>(strip + 32 + 8 * g + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int reg = 4 * g + j;
+            const float m3 = v3[j] * (g < 2 ? z0 : z1);
+            num[reg] = use_w ? num[reg] * rcp_fast(den[reg] + 1e-6f) * 25.0f : m3;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();              // the strip is rewritten by this wave's next match
+    return num;
+}
+
 // f32 staging image [64][128], 16-byte chunks swizzled like the planes (32 chunks per row)
 __device__ __forceinline__ int stage_off(int row, int chunk) { return row * (CF * 4) + ((chunk ^ (row & 15)) << 4); }
 
@@ -232,70 +312,9 @@ __global__ __launch_bounds__(NM * 256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_refi
         OPHIP_STAMP(p.stamps, blockIdx.x, 2 + 8 * l);
         WRing<1, 2, NS> rm;                      // merge weights: in flight during the register-only attention below
         rm.fill(w_hi + OM + (size_t)ft * TS + lane, w_lo + OM + (size_t)ft * TS + lane, TS);
-        // ---- KV / Ksum of the two source sets and phi(Q) KV, all in registers -------------------------------
+        // ---- KV / Ksum of the window set, the 3D token's rank-one message, phi(Q) KV: all in registers (attend_match) ------
         {
-            const bool is3d = r == TOK3D;                 // on the token (lane) axis of D[feature][token] tiles
-            const bool use_w = cross ? is3d : !is3d;      // this token attends to the window set (else: the 3D token)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) q[0][0][reg] = elu_plus_one_fast(q[0][0][reg]);
-            // masked phi(K) / scaled V fragments straight from the accumulators (rows = tokens of this match)
-            auto f_kw = [&](int reg, float v) { return acc_row(reg, h) < WIN ? elu_plus_one_fast(v) : 0.f; };
-            auto f_k3 = [&](int reg, float v) { return acc_row(reg, h) == TOK3D ? elu_plus_one_fast(v) : 0.f; };
-            auto f_vs = [&](int reg, float v) {       // values / v_length of the stream the token belongs to (25 | 1)
-                const int row = acc_row(reg, h);
-                return row < WIN ? v * 0.04f : (row == TOK3D ? v : 0.f);
-            };
-            // a token attends to exactly one source set: phi(Q) is masked per set on the token (lane) axis and both sets
-            // accumulate into one num / den tile.  Window set first, then the 3D token (row 25 = k-step 1 only: k-step 0
-            // of that set is all zeros), so that only two KV tiles are live at a time.
-            const auto block_diag = [&](f32x16& t) {          // two 16-wide heads per 32-wide tile
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg)
-                    if ((acc_row(reg, h) >> 4) != (r >> 4)) t[reg] = 0.f;
-            };
-            f32x16 num = zero16(), den = zero16();
-            {
-                f32x16 kvw = zero16(), ksw = zero16();
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    bf16x8 wh, wl2, vh, vl;
-                    acc_frag_map<NS>(kv_[0][0], st, f_kw, wh, wl2);
-                    acc_frag_map<NS>(kv_[1][0], st, f_vs, vh, vl);
-                    kvw = mma_bf16<NS>(wh, wl2, vh, vl, kvw);
-                    ksw = mma_bf16<NS>(wh, wl2, ones, zeros, ksw);
-                }
-                block_diag(kvw);
-                block_diag(ksw);
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    bf16x8 qh, ql, ah, al;
-                    acc_frag<NS>(q[0][0], st, qh, ql);
-                    const bf16x8 qwh = select_frag(use_w, qh, zeros), qwl = select_frag(use_w, ql, zeros);
-                    acc_frag<NS>(kvw, st, ah, al); num = mma_bf16<NS>(ah, al, qwh, qwl, num);
-                    acc_frag<NS>(ksw, st, ah, al); den = mma_bf16<NS>(ah, al, qwh, qwl, den);
-                }
-            }
-            {
-                f32x16 kv3 = zero16(), ks3 = zero16();
-                bf16x8 th, tl, vh, vl;
-                acc_frag_map<NS>(kv_[0][0], 1, f_k3, th, tl);
-                acc_frag_map<NS>(kv_[1][0], 1, f_vs, vh, vl);
-                kv3 = mma_bf16<NS>(th, tl, vh, vl, kv3);
-                ks3 = mma_bf16<NS>(th, tl, ones, zeros, ks3);
-                block_diag(kv3);
-                block_diag(ks3);
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    bf16x8 qh, ql, ah, al;
-                    acc_frag<NS>(q[0][0], st, qh, ql);
-                    const bf16x8 q3h = select_frag(!use_w, qh, zeros), q3l = select_frag(!use_w, ql, zeros);
-                    acc_frag<NS>(kv3, st, ah, al); num = mma_bf16<NS>(ah, al, q3h, q3l, num);
-                    acc_frag<NS>(ks3, st, ah, al); den = mma_bf16<NS>(ah, al, q3h, q3l, den);
-                }
-            }
-            const float S = use_w ? 25.0f : 1.0f;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) num[reg] = num[reg] * rcp_fast(den[reg] + 1e-6f) * S;
+            f32x16 num = attend_match<NS>(q[0][0], kv_[0][0], kv_[1][0], cross, scratch + 64 * (4 * tt + ft), lane, ones, zeros);
             store_featrow_acc<NS>(num, YH, YL, ROWB, 32 * ft, 32 * tt, lane);
         }
         __syncthreads();
@@ -609,20 +628,7 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_pair_kern
             gemm_bf16_ring<1, 2, NS, true, KB, 2>(q, rq, w_hi + OQ + (size_t)ft * TS + ln_, w_lo + OQ + (size_t)ft * TS + ln_, TS, XH, XL, ROWB, 0, lane);
         }
         OPHIP_STAMP(p.stamps, blockIdx.x, 2 + 8 * l);
-        // ---- KV / Ksum of the two source sets and phi(Q) KV per match, all in registers -----------------------------------
-        const bool is3d = r == TOK3D;                 // on the token (lane) axis of D[feature][token] tiles
-        const bool use_w = cross ? is3d : !is3d;      // this token attends to the window set (else: the 3D token)
-        auto f_kw = [&](int reg, float v) { return acc_row(reg, h) < WIN ? elu_plus_one_fast(v) : 0.f; };
-        auto f_k3 = [&](int reg, float v) { return acc_row(reg, h) == TOK3D ? elu_plus_one_fast(v) : 0.f; };
-        auto f_vs = [&](int reg, float v) {
-            const int row = acc_row(reg, h);
-            return row < WIN ? v * 0.04f : (row == TOK3D ? v : 0.f);
-        };
-        const auto block_diag = [&](f32x16& t) {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg)
-                if ((acc_row(reg, h) >> 4) != (r >> 4)) t[reg] = 0.f;
-        };
+        // ---- per match: K|V projection, then the attention in registers (attend_match) ---------------------------------------
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             f32x16 kv_[2][1] = {{zero16()}, {zero16()}};
@@ -630,51 +636,7 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_pair_kern
             gemm_bf16_ring<2, 1, NS, false, KB, 2>(kv_, rkv, w_hi + OKV + (size_t)(2 * ft) * TS + lk_, w_lo + OKV + (size_t)(2 * ft) * TS + lk_, TS,
                                                    XH + 32 * tt * ROWB, XL + 32 * tt * ROWB, ROWB, 0, lane);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) q[0][tt][reg] = elu_plus_one_fast(q[0][tt][reg]);
-            f32x16 num = zero16(), den = zero16();
-            {
-                f32x16 kvw = zero16(), ksw = zero16();
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    bf16x8 wh, wl2, vh, vl;
-                    acc_frag_map<NS>(kv_[0][0], st, f_kw, wh, wl2);
-                    acc_frag_map<NS>(kv_[1][0], st, f_vs, vh, vl);
-                    kvw = mma_bf16<NS>(wh, wl2, vh, vl, kvw);
-                    ksw = mma_bf16<NS>(wh, wl2, ones, zeros, ksw);
-                }
-                block_diag(kvw);
-                block_diag(ksw);
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    bf16x8 qh, ql, ah, al;
-                    acc_frag<NS>(q[0][tt], st, qh, ql);
-                    const bf16x8 qwh = select_frag(use_w, qh, zeros), qwl = select_frag(use_w, ql, zeros);
-                    acc_frag<NS>(kvw, st, ah, al); num = mma_bf16<NS>(ah, al, qwh, qwl, num);
-                    acc_frag<NS>(ksw, st, ah, al); den = mma_bf16<NS>(ah, al, qwh, qwl, den);
-                }
-            }
-            {
-                f32x16 kv3 = zero16(), ks3 = zero16();
-                bf16x8 th, tl, vh, vl;
-                acc_frag_map<NS>(kv_[0][0], 1, f_k3, th, tl);
-                acc_frag_map<NS>(kv_[1][0], 1, f_vs, vh, vl);
-                kv3 = mma_bf16<NS>(th, tl, vh, vl, kv3);
-                ks3 = mma_bf16<NS>(th, tl, ones, zeros, ks3);
-                block_diag(kv3);
-                block_diag(ks3);
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    bf16x8 qh, ql, ah, al;
-                    acc_frag<NS>(q[0][tt], st, qh, ql);
-                    const bf16x8 q3h = select_frag(!use_w, qh, zeros), q3l = select_frag(!use_w, ql, zeros);
-                    acc_frag<NS>(kv3, st, ah, al); num = mma_bf16<NS>(ah, al, q3h, q3l, num);
-                    acc_frag<NS>(ks3, st, ah, al); den = mma_bf16<NS>(ah, al, q3h, q3l, den);
-                }
-            }
-            const float S = use_w ? 25.0f : 1.0f;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) num[reg] = num[reg] * rcp_fast(den[reg] + 1e-6f) * S;
+            f32x16 num = attend_match<NS>(q[0][tt], kv_[0][0], kv_[1][0], cross, scratch + 64 * ft, lane, ones, zeros);
             store_featrow_acc<NS>(num, YH, YL, ROWB, 32 * ft, 32 * tt, lane);
             __builtin_amdgcn_sched_barrier(0);
             if (tt == 0) rkv.fill(w_hi + OKV + (size_t)(2 * ft) * TS + lk_, w_lo + OKV + (size_t)(2 * ft) * TS + lk_, TS);      // the second match's K|V weights

@@ -1,0 +1,5 @@
+O=gpurun_out/r4f
+mkdir -p $O
+timeout -k 10 120 python tools/stamps_fine.py > $O/stamps.txt 2>&1; grep -E "total cycles|q gemm|kv gemm|gather|mlp0|merge|LN|mlp2|end|H store" $O/stamps.txt
+timeout -k 10 120 python tools/time_fine.py > $O/time_fine.txt 2>&1; tail -2 $O/time_fine.txt
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "fine or c1 or c2 or b2" > $O/tests.log 2>&1; tail -3 $O/tests.log

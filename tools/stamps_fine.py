@@ -7,6 +7,9 @@ from onepose_st_amd.model import OnePosePlus_model
 from onepose_st_amd.synthetic import make_synthetic_inputs, make_synthetic_state_dict
 cfg = default_config(); cfg["hip_precision"] = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
 sd = make_synthetic_state_dict(0, cfg)
+if __import__("os").environ.get("STAMPS_FINE_LAYERS"):          # experiment: another order of the two fine layers (same weights)
+    cfg["loftr_fine"]["layer_names"] = __import__("os").environ["STAMPS_FINE_LAYERS"].split(",")
+    print("fine layers", cfg["loftr_fine"]["layer_names"])
 dev = torch.device("cuda:0")
 m = OnePosePlus_model(cfg).eval(); m.load_state_dict(sd); m.to(dev)
 inp = make_synthetic_inputs(sd, 7000, (480, 640), 3000, seed=1, config=cfg)
