@@ -626,7 +626,14 @@ struct ConfArgs {
 #endif
 constexpr int CONF_ROWS = OPHIP_CONF_ROWS;      // rows per workgroup (measured at c2: 16 -> 106 us, 32 -> 90, 48 -> 114, 64 -> 132: fewer, less contended column atomics vs grid fill)
 constexpr int CONF_RB = 2;         // rows per pipeline stage (two stages in flight)
-constexpr int CONF_U = 3;          // float4 groups per thread per row  => span <= 3072 columns (164 VGPRs, 3 waves per SIMD; 4 -> 212 VGPRs, 2 -> more spans: 87 / 90 / 94 us at c2)
+#ifndef OPHIP_CONF_U
+#define OPHIP_CONF_U 3
+#endif
+// float4 groups per thread per row => a span of <= 1024 CONF_U columns.  Alone at c2: 2 -> 94 us (123 VGPRs), 3 -> 90 us (164), 4 -> 87 us (212).
+// Beside the previous frame's fine stage (whose waves hold 256 registers, two per SIMD: a wave of this pass enters a SIMD in place of one
+// of them) 2 and 3 measure the same within noise (1355 against 1330 frames/s over four runs each, fine stage 292 us in both traces): the
+// bytes a wave keeps in flight per register it holds are the same.
+constexpr int CONF_U = OPHIP_CONF_U;
 
 template <bool VEC, bool FAST>
 __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
@@ -929,7 +936,7 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs p) {
     if (tid == 0 && blockIdx.x == 0) *p.count = base_s;          // (count[1], the lazy form's "needs the eager form" flag, is cleared by the caller's memset / stat pass)
 }
 
-inline int conf_nspan(int M) { return (M + 3071) / 3072; }
+inline int conf_nspan(int M) { return (M + 1024 * CONF_U - 1) / (1024 * CONF_U); }
 inline int conf_spanw(int M) { const int ns = conf_nspan(M); return (((M + ns - 1) / ns) + 3) / 4 * 4; }
 
 // workspace map (floats), shared by the sizing helper, coarse_impl and the fragment-plane accessor
