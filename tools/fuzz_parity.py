@@ -26,6 +26,18 @@ for c in range(cases):
     frames = [make_synthetic_inputs(sd, n_points=N, image_hw=(8 * hc, 8 * wc), n_plant=rng.randint(0, min(N, hc * wc) // 2), seed=seed * 100 + c, config=cfg, frame=f) for f in range(B)]
     inp = {k: torch.cat([f[k] for f in frames]) for k in ("feat_c", "feat_f")}
     obj = {k: frames[0][k].expand(B, *frames[0][k].shape[1:]).contiguous() for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db")}
+    extra = {}
+    if rng.random() < 0.5:          # padded / resized query images: a bottom / right padding band per element and per-image scales
+        mask = torch.ones(B, hc, wc, dtype=torch.bool)
+        for b in range(B):
+            if rng.random() < 0.5:
+                mask[b, hc - rng.randint(1, hc // 3):, :] = False
+            else:
+                mask[b, :, wc - rng.randint(1, wc // 3):] = False
+        extra["query_image_mask"] = mask
+        if rng.random() < 0.7:
+            extra["query_image_scale"] = torch.tensor([[rng.uniform(0.5, 2.0), rng.uniform(0.5, 2.0)] for _ in range(B)], dtype=torch.float32)
+    obj.update(extra)
     with torch.no_grad():
         ref = orc.forward_from_features(sd, cfg, obj, inp["feat_c"], inp["feat_f"], (8 * hc, 8 * wc))
     data = {k: v.to(dev) for k, v in obj.items()}
@@ -35,7 +47,9 @@ for c in range(cases):
     if ok and K:
         ok = bool(torch.allclose(data["mkpts_query_f"].cpu(), ref["mkpts_query_f"], rtol=1e-4, atol=5e-4)) and \
              bool(torch.allclose(data["mconf"].cpu(), ref["mconf"], rtol=5e-4, atol=1e-6))
-    print(f"frame case {c}: B={B} N={N} grid {hc}x{wc} K={K} {'ok' if ok else 'MISMATCH'}", flush=True)
+    if ok and K and "query_image_scale" in extra:
+        ok = bool(torch.equal(data["mkpts_query_c"].cpu(), ref["mkpts_query_c"]))
+    print(f"frame case {c}: B={B} N={N} grid {hc}x{wc} K={K} {'masked ' if extra else ''}{'ok' if ok else 'MISMATCH'}", flush=True)
     bad += not ok
 for c in range(cases * 2):
     cin, cout = rng.choice([8, 32, 40, 100, 128, 196, 256]), rng.choice([8, 36, 64, 128, 196, 256])
