@@ -395,7 +395,7 @@ def main():
     # rocprofv3 --pmc runs, tools/run_profile_r03.sh), not live -- and quoted ONLY when those passes ran on the build that is
     # running now (the pmc file records ophip_build_stamp): a kernel change without a re-profile prints null, never a stale number
     traffic, mfma_busy, pmc_note = None, None, None
-    stem = {"bf16x3": "enc_x3w8_kernel<false>", "bf16": "attn_apply_bf16_kernel<1", "f32": "attn_apply_kernel"}[args.precision]
+    stem = {"bf16x3": "enc_x3w8_kernel<false,", "bf16": "attn_apply_bf16_kernel<1", "f32": "attn_apply_kernel"}[args.precision]
     try:
         pmc_path = sorted(p for p in os.listdir(os.path.join(REPO, "profiles")) if p.endswith("_pmc.json"))[-1]
         pmc_all = json.load(open(os.path.join(REPO, "profiles", pmc_path)))
@@ -457,7 +457,7 @@ def main():
             "host_bound": (pnp_ceiling < (frames_total / dt_matcher if dt_matcher else value)) if pnp_ceiling else None,
         },
         "roofline": {
-            "kernel": {"bf16x3": "enc_x3w8_kernel<false> (attn_apply)", "bf16": "attn_apply_bf16_kernel<1, 1>", "f32": "attn_apply_kernel"}[args.precision]
+            "kernel": {"bf16x3": "enc_x3w8_kernel<false, false> (attn_apply)", "bf16": "attn_apply_bf16_kernel<1, 1, false>", "f32": "attn_apply_kernel"}[args.precision]
                       + " (fused Q-proj + linear attention + merge + MLP + 2 LayerNorms" + (" + next layer's K/V reduce)" if args.precision != "f32" else ")"),
             "bound": "mfma",
             "achieved": achieved,
