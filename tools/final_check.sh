@@ -1,4 +1,4 @@
-O=gpurun_out/r3w
+O=gpurun_out/final_check
 mkdir -p $O
 timeout -k 10 900 python -m pytest tests -m gpu -q > $O/tests.log 2>&1; rc=$?; echo "rc=$rc" >> $O/tests.log; tail -5 $O/tests.log
 [ $rc -eq 0 ] || exit 1
