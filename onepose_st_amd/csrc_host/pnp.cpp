@@ -751,7 +751,9 @@ namespace {
 constexpr int CH = 256;
 // Chunk 0 is the serial head of a frame's RANSAC (its best float score bounds every other chunk, so they wait for it): it is short.
 // A frame's pose latency is head + (floor - CH0) / threads + tail + refinement; with 256 trials the head was a quarter of it.
-constexpr int CH0 = 64;
+// The unconditional floor is rounded UP to whole chunks ("at least min_iters trials", as long as max_iters allows): a partial last
+// chunk would run in the serial tail (208 of 10 000 trials with CH0 = 64: 0.2 ms of the 0.9 ms a frame's pose spends outside the pool's parallel part).
+constexpr int CH0 = 32;
 inline int chunk_len(int c) { return c == 0 ? CH0 : CH; }
 inline long long chunk_start(int c) { return c == 0 ? 0 : CH0 + (long long)(c - 1) * CH; }
 
@@ -802,8 +804,14 @@ struct Ransac {
         }
         thr2 = reproj * reproj; confidence = conf; min_iters = min_it; max_iters = max_it; seed = seed_;
     }
+    int floor_trials() const {                       // unconditional trials: min_iters rounded up to whole chunks when max_iters has room for that
+        const int f = min_iters < max_iters ? min_iters : max_iters;
+        if (f <= 0) return 0;
+        const long long up = f <= CH0 ? CH0 : CH0 + (long long)((f - CH0 + CH - 1) / CH) * CH;
+        return up <= max_iters ? (int)up : f;
+    }
     int full_chunks() const {
-        const int floor_ = min_iters < max_iters ? min_iters : max_iters;
+        const int floor_ = floor_trials();
         return floor_ < CH0 ? 0 : 1 + (floor_ - CH0) / CH;
     }
 
@@ -938,7 +946,7 @@ struct Ransac {
     void run_tail(Candidate& best, FloatBound bound, int* iters_run) const {
         int c = full_chunks();
         long long total = chunk_start(c);
-        const int rem = (int)((min_iters < max_iters ? min_iters : max_iters) - total);
+        const int rem = (int)(floor_trials() - total);
         while (total < max_iters) {
             const int limit = (int)((max_iters - total) < chunk_len(c) ? (max_iters - total) : chunk_len(c));
             const int ran = run_chunk(c, limit, c == full_chunks() ? rem : 0, best, bound);
