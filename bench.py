@@ -28,6 +28,8 @@ Rank 0 prints ONE JSON line with the driver's contract fields plus
 from __future__ import annotations
 
 import argparse
+import contextlib
+import gc
 import json
 import os
 import sys
@@ -118,8 +120,13 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # this rank's slice of the host: pinned before any thread pool exists (PnP workers and torch's intra-op threads inherit it)
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    n_mask = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 0
     my_cpus = hostsize.pin_rank(local % max(local_world, 1), max(local_world, 1))
-    pnp_threads = args.pnp_threads if args.pnp_threads > 0 else hostsize.pnp_threads(len(my_cpus))
+    n_now = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 0
+    pinned = world > 1 and n_now == len(my_cpus)          # exactly this rank's share (the pool's threads then keep off the feeder cores)
+    confined = world == 1 and 0 < n_now < n_mask             # one rank under a CPU quota: kept on a few times the quota's CPUs (hostsize.pin_rank)
+    under_quota = hostsize.quota_limited()
+    pnp_threads = args.pnp_threads if args.pnp_threads > 0 else hostsize.pnp_threads(len(my_cpus), under_quota, max(local_world, 1))
     import torch
     if os.environ.get("OPHIP_BENCH_LAUNCH_PROBE"):
         # launcher rehearsal without a GPU (tests/test_launch.py): rendezvous over gloo, one all-reduce, one JSON line from rank 0
@@ -197,8 +204,18 @@ def main():
 
     # host PnP (metric: "2D-3D match + PnP"): frame t's pose is solved on host threads (C++, GIL released) while the GPU
     # matches frame t + 1; every pose is joined before the clock stops
-    pools = {} if args.no_pnp else {pol: PnPPool(first["K"].numpy(), threads=pnp_threads, pnp_reprojection_error=7, policy=pol)
-                                    for pol in ("reference", "adaptive")}
+    # on a pinned share the pool's threads keep off the feeder cores.  (A one-rank job under a CPU quota is NOT pinned: on a shared host its
+    # threads must be free to leave CPUs a neighbour takes -- pinned to fixed CPUs, 3 of 10 runs lost 30-60 % -- and it keeps below the
+    # quota by running fewer pool threads instead, hostsize.pnp_threads(under_quota=True).)
+    pin_workers = pinned
+    with (hostsize.worker_cpus(my_cpus) if pin_workers else contextlib.nullcontext()):
+        pools = {} if args.no_pnp else {pol: PnPPool(first["K"].numpy(), threads=pnp_threads, pnp_reprojection_error=7, policy=pol)
+                                        for pol in ("reference", "adaptive")}
+    if pinned and pools and len(my_cpus) >= 2 * hostsize.FEEDER_CORES:
+        try:
+            os.sched_setaffinity(0, my_cpus[:hostsize.FEEDER_CORES])          # this thread (it enqueues the frames) stays on the feeder cores
+        except OSError:
+            pass
     pool = pools.get(args.pnp_policy)
     pending = []
     last_host = [None]      # the most recent frame's matches on the host: what the PnP-ceiling measurement replays
@@ -315,6 +332,8 @@ def main():
         sync_all()
         for k in host_t:
             host_t[k] = 0.0
+        gc.collect()
+        gc.disable()                                     # no collector pause of the feeder thread inside the timed steps
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(i)
@@ -323,6 +342,7 @@ def main():
         join_poses()
         sync_all()
         dt_ = time.perf_counter() - t0
+        gc.enable()
         host_t["tail"] = dt_ - (t_gpu - t0)          # after the last frame left the GPU: its pose (and the final barrier)
         if dist_on:
             import torch.distributed as dist
@@ -362,7 +382,41 @@ def main():
     # (coprime with the 6 layers, so every layer is sampled equally) ~2 %, with the same average
     time_every = int(os.environ.get("OPHIP_BENCH_TIME_EVERY", "11"))
     hip.timing_select("attn_apply", every=time_every)
+
+    def throttle_stat():
+        """(nr_throttled, throttled_usec) of this cgroup's CPU quota (cgroup v2 cpu.stat / v1 cpu.stat in ns): a job that asks for more CPU
+        time per period than its quota is stopped -- every thread, the GPU feeder included -- until the next period (tens of ms)"""
+        for path, scale in (("/sys/fs/cgroup/cpu.stat", 1.0), ("/sys/fs/cgroup/cpu/cpu.stat", 1e-3)):
+            try:
+                kv = dict(ln.split()[:2] for ln in open(path).read().splitlines() if len(ln.split()) >= 2)
+                return int(kv.get("nr_throttled", 0)), float(kv.get("throttled_usec", kv.get("throttled_time", 0))) * scale
+            except (OSError, ValueError):
+                continue
+        return None
+    def thread_cpu():
+        """{tid: (comm, cpu seconds)} of this process's threads (OPHIP_BENCH_TRACE: who uses the cgroup's CPU quota)"""
+        out = {}
+        tck = os.sysconf("SC_CLK_TCK")
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                f = open(f"/proc/self/task/{tid}/stat").read()
+                comm = f[f.index("(") + 1:f.rindex(")")]
+                rest = f[f.rindex(")") + 2:].split()
+                out[tid] = (comm, (int(rest[11]) + int(rest[12])) / tck)
+            except (OSError, ValueError, IndexError):
+                pass
+        return out
+    tc0 = thread_cpu() if os.environ.get("OPHIP_BENCH_TRACE") else None
+    t_wall0 = time.perf_counter()
+    thr0 = throttle_stat()
     dt = timed_region(pools.get(args.pnp_policy))
+    thr1 = throttle_stat()
+    if tc0 is not None and rank == 0:
+        tc1, wall = thread_cpu(), time.perf_counter() - t_wall0
+        used = sorted(((tc1[t][1] - tc0.get(t, (None, 0.0))[1], tc1[t][0]) for t in tc1), reverse=True)
+        tot = sum(u for u, _ in used)
+        print(f"cpu over warm-up + timed region ({wall * 1e3:.0f} ms wall, {len(tc1)} threads): {tot / wall:.2f} cores in all; busiest threads "
+              + " ".join(f"{u / wall:.2f}" for u, _ in used[:24]) + f"; threads above 2 %: {sum(1 for u, _ in used if u / wall > 0.02)}", file=sys.stderr)
     if os.environ.get("OPHIP_BENCH_TRACE") and rank == 0:
         print("host us/step: " + ", ".join(f"{k} {1e6 * v / args.steps:.0f}" for k, v in host_t.items() if k != "tail")
               + f"; wall {1e6 * dt / args.steps:.0f}; after the last frame left the GPU {1e6 * host_t.get('tail', 0.0):.0f} us in all", file=sys.stderr)
@@ -451,7 +505,8 @@ def main():
             "parallelism": f"frames sharded over {world} rank(s), one RCCL broadcast of weights + 3D block ({bcast_bytes} B)",
         },
         "host": {
-            "host_cores_per_rank": len(my_cpus), "cpus_of_rank0": [my_cpus[0], my_cpus[-1]], "pinned": world > 1,
+            "cgroup_cpu_throttled_in_timed_region": ({"periods": thr1[0] - thr0[0], "usec": round(thr1[1] - thr0[1])} if thr0 and thr1 else None),
+            "host_cores_per_rank": len(my_cpus), "cpus_of_rank0": [my_cpus[0], my_cpus[-1]], "pinned": pinned, "under_cgroup_cpu_quota": under_quota, "confined_to_cpus": (n_now if confined else None),
             "pnp_threads_per_rank": pnp_threads, "pnp_policy": args.pnp_policy,
             "pnp_ceiling_fps": pnp_ceiling,          # RANSAC pools alone on recorded matches, all ranks at once (min over ranks x N)
             "host_bound": (pnp_ceiling < (frames_total / dt_matcher if dt_matcher else value)) if pnp_ceiling else None,

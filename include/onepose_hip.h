@@ -248,6 +248,15 @@ int ophip_frame_enqueue(const ophip_frame_desc* desc, const ophip_frame_layout_t
                         const float* keypoints3d, long long kpts_bstride, const float* desc3d_c, long long desc_c_bstride,
                         const float* desc3d_f, long long desc_f_bstride, long long desc_f_cstride, const float* x3d_external,
                         void* host_dst, size_t host_bytes, void* s_main, void* s_prep, void* s_fine, void* s_copy, int* slot);
+/* The same frame with the reference's optional inputs of padded / resized query images (see ophip_encoder_layer_x3w8_masked): query_mask
+ * [B][M] bytes (1 = real cell) and / or query_scale [B][2] floats, either NULL; both must stay valid like the other inputs.  With a mask
+ * the last encoder layer does not write the similarity fragments itself (the masked layer has no such form; the similarity stage derives them). */
+int ophip_frame_enqueue_padded(const ophip_frame_desc* desc, const ophip_frame_layout_t* layout, void* block,
+                               const float* feat_c, const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x,
+                               const float* keypoints3d, long long kpts_bstride, const float* desc3d_c, long long desc_c_bstride,
+                               const float* desc3d_f, long long desc_f_bstride, long long desc_f_cstride, const float* x3d_external,
+                               const unsigned char* query_mask, const float* query_scale,
+                               void* host_dst, size_t host_bytes, void* s_main, void* s_prep, void* s_fine, void* s_copy, int* slot);
 int ophip_frame_wait(int ticket);
 int ophip_frame_order_after_fine(void* compute_stream);
 

@@ -24,6 +24,7 @@ struct FineJob {
     const float* mkc = nullptr; const void* w_fine = nullptr; int n_fine = 0; unsigned fine_cross_bits = 0; int fine_encoder_enable = 0;
     int wc = 0, stride = 0; float fine_scale = 0.f;
     float *expec = nullptr, *mk2d = nullptr;
+    const float* qscale = nullptr;          // query_image_scale [B][2] or NULL
     void* host_dst = nullptr; const void* result_src = nullptr; size_t host_bytes = 0;
 };
 struct Slot {
@@ -49,7 +50,9 @@ int make_events(Slot& s, int dev) {
     if (s.ready && s.dev == dev) return 0;
     hipEvent_t* ev[5] = {&s.prep_done, &s.coarse_done, &s.fine_done, &s.ready, &s.enc_done};
     for (auto e : ev) {
-        hipError_t rc = hipEventCreateWithFlags(e, hipEventDisableTiming);
+        // `ready` is the one event the host waits on (ophip_frame_wait): a blocking wait, so that the thread that feeds the GPU sleeps instead
+        // of spinning through its ~0.3 ms of slack per frame (under a cgroup CPU quota every spinning thread is quota the RANSAC pool lacks)
+        hipError_t rc = hipEventCreateWithFlags(e, e == &s.ready ? (hipEventDisableTiming | hipEventBlockingSync) : hipEventDisableTiming);
         if (rc != hipSuccess) return ophip_fail(rc, "hipEventCreateWithFlags(frame)");
     }
     s.dev = dev;
@@ -76,6 +79,11 @@ int launch_fine_job(int dev, Slot& s, hipEvent_t after = nullptr) {
     FineJob& j = s.job;
     const hipStream_t on = j.s_fine;
     FR_HIP(hipStreamWaitEvent(on, after ? after : s.coarse_done, 0), "hipStreamWaitEvent(fine job)");
+    if (j.qscale)
+        FR_CHECK(ophip_fine_refine_bf16_scaled(j.ff, j.fs_b, j.fs_c, j.fs_y, j.fs_x, j.hf, j.wf, j.desc_f, j.desc_f_bs, j.desc_f_cs, j.b_ids, j.i_ids, j.j_ids,
+                                               j.count, j.cap, j.mkc, j.w_fine, j.n_fine, j.fine_cross_bits, j.fine_encoder_enable, 3, j.wc, j.stride,
+                                               j.fine_scale, j.expec, j.mk2d, nullptr, nullptr, j.qscale, on));
+    else
     FR_CHECK(ophip_fine_refine_bf16(j.ff, j.fs_b, j.fs_c, j.fs_y, j.fs_x, j.hf, j.wf, j.desc_f, j.desc_f_bs, j.desc_f_cs, j.b_ids, j.i_ids, j.j_ids,
                                     j.count, j.cap, j.mkc, j.w_fine, j.n_fine, j.fine_cross_bits, j.fine_encoder_enable, 3, j.wc, j.stride,
                                     j.fine_scale, j.expec, j.mk2d, nullptr, nullptr, on));
@@ -136,12 +144,13 @@ extern "C" int ophip_frame_layout(const ophip_frame_desc* d, int transpose_fine,
     return 0;
 }
 
-extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_layout_t* L, void* blob_,
-                                   const float* feat_c, const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x,
-                                   const float* kpts, long long kpts_bs, const float* desc_c, long long desc_c_bs,
-                                   const float* desc_f, long long desc_f_bs, long long desc_f_cs, const float* x3d_external,
-                                   void* host_dst, size_t host_bytes, void* s_main_, void* s_prep_, void* s_fine_, void* s_copy_,
-                                   int* slot_out) {
+extern "C" int ophip_frame_enqueue_padded(const ophip_frame_desc* d, const ophip_frame_layout_t* L, void* blob_,
+                                          const float* feat_c, const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x,
+                                          const float* kpts, long long kpts_bs, const float* desc_c, long long desc_c_bs,
+                                          const float* desc_f, long long desc_f_bs, long long desc_f_cs, const float* x3d_external,
+                                          const unsigned char* qmask, const float* qscale,
+                                          void* host_dst, size_t host_bytes, void* s_main_, void* s_prep_, void* s_fine_, void* s_copy_,
+                                          int* slot_out) {
     if (!d || !L || !blob_ || !feat_c || !feat_f || !kpts || !desc_c || !desc_f || !host_dst || !s_fine_ || !s_copy_ || !slot_out)
         return ophip_bad_arg(__func__, "null pointer");
     if (host_bytes < 16 || host_bytes > L->result_bytes) return ophip_bad_arg(__func__, "host_bytes");
@@ -229,7 +238,10 @@ extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_
     FR_CHECK(ophip_coarse_frag_planes(F(L->cws), B, N, M, &planes3d, &planes2d));
     for (int li = 0; li < d->n_coarse; ++li) {
         const void* nxt = li + 1 < d->n_coarse ? d->w_coarse[li + 1] : nullptr;
-        if (li + 1 == d->n_coarse)
+        if (qmask)      // padded query cells (query_image_mask): the masked layer; the similarity stage then derives its operand fragments itself
+            FR_CHECK(ophip_encoder_layer_x3w8_masked(x3, x2, y3, y2, B, N, M, d->w_coarse[li], nxt, (d->coarse_cross_bits >> li) & 1, li > 0 ? 1 : 0, li & 1,
+                                                     blob + L->enc_ws, qmask, s_main));
+        else if (li + 1 == d->n_coarse)
             FR_CHECK(ophip_encoder_layer_x3w8_frag(x3, x2, y3, y2, B, N, M, d->w_coarse[li], nxt, (d->coarse_cross_bits >> li) & 1, li > 0 ? 1 : 0, li & 1,
                                                    blob + L->enc_ws, planes3d, planes2d, s_main));
         else
@@ -248,10 +260,11 @@ extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_
     float* mk3d = F(L->result + 16 + 8 * (size_t)cap);
     float* mk2d = F(L->result + 16 + 20 * (size_t)cap);
     unsigned char* gt_mask = reinterpret_cast<unsigned char*>(blob + L->gt_mask);
+    const int nsplit_flags = qmask ? 3 : (3 | OPHIP_COARSE_PLANES_READY);
     if (!defer)
-    FR_CHECK(ophip_coarse_match_conf(x3, x2, kpts, kpts_bs, B, N, M, d->wc, d->temperature, d->thr, d->border_rm, d->scale_c, conf, cws,
-                                     b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count,
-                                     3 | OPHIP_COARSE_PLANES_READY, s_main));
+    FR_CHECK(ophip_coarse_match_masked(x3, x2, kpts, kpts_bs, B, N, M, d->wc, d->temperature, d->thr, d->border_rm, d->scale_c, conf, cws,
+                                       b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count,
+                                       nsplit_flags, 1, qmask, qscale, s_main));
     // With the input kernels on their own stream nothing is left on the compute stream that could run beside the fine stage
     // (the next encoder waits for it anyway), so selection + fine stage stay in order on the compute stream: a dependent kernel
     // on the same queue starts ~2 us after its producer, one behind a cross-stream event 10-17 us after (rocprof trace).
@@ -264,13 +277,13 @@ extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_
         // (Fine stage on the compute stream and the HBM-bound half on the side stream instead: the same within noise.)
         FR_CHECK(ophip_coarse_match_masked(x3, x2, kpts, kpts_bs, B, N, M, d->wc, d->temperature, d->thr, d->border_rm, d->scale_c, conf, cws,
                                            b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count,
-                                           3 | OPHIP_COARSE_PLANES_READY, d->lazy_conf ? 1 : 4, nullptr, nullptr, s_main));      // (lazy form: its candidate pass is a second matrix-bound tile pass)
+                                           nsplit_flags, d->lazy_conf ? 1 : 4, qmask, qscale, s_main));      // (lazy form: its candidate pass is a second matrix-bound tile pass)
         FR_HIP(hipEventRecord(slot->enc_done, s_main), "hipEventRecord(similarity)");
         // the kept-back fine stage of the previous frame: on the side stream, behind this frame's similarity tiles, beside the rest
         if (kept) FR_CHECK(launch_fine_job(dev, *kept, slot->enc_done));
         FR_CHECK(ophip_coarse_match_masked(x3, x2, kpts, kpts_bs, B, N, M, d->wc, d->temperature, d->thr, d->border_rm, d->scale_c, conf, cws,
                                            b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count,
-                                           3 | OPHIP_COARSE_PLANES_READY, d->lazy_conf ? 2 : (8 | 2), nullptr, nullptr, s_main));
+                                           nsplit_flags, d->lazy_conf ? 2 : (8 | 2), qmask, qscale, s_main));
         FR_HIP(hipEventRecord(slot->coarse_done, s_main), "hipEventRecord(coarse)");
         FineJob& j = slot->job;
         j.s_main = s_main; j.s_fine = s_fine; j.s_copy = s_copy;
@@ -280,6 +293,7 @@ extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_
         j.mkc = F(L->mkc); j.w_fine = d->w_fine; j.n_fine = d->n_fine; j.fine_cross_bits = d->fine_cross_bits; j.fine_encoder_enable = d->fine_encoder_enable;
         j.wc = d->wc; j.stride = d->hf / d->hc; j.fine_scale = d->fine_scale;
         j.expec = F(L->expec); j.mk2d = mk2d;
+        j.qscale = qscale;
         j.host_dst = host_dst; j.result_src = blob + L->result; j.host_bytes = host_bytes;
         {
             std::lock_guard<std::mutex> lk(g_mu);
@@ -293,9 +307,14 @@ extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_
         FR_HIP(hipEventRecord(slot->coarse_done, s_main), "hipEventRecord(coarse)");
         FR_HIP(hipStreamWaitEvent(s_fine, slot->coarse_done, 0), "hipStreamWaitEvent(coarse)");
     }
-    FR_CHECK(ophip_coarse_match_select(x3, x2, kpts, kpts_bs, B, N, M, d->wc, d->temperature, d->thr, d->border_rm, d->scale_c, conf, cws,
-                                       b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count, 3, s_fine));
+    FR_CHECK(ophip_coarse_match_masked(x3, x2, kpts, kpts_bs, B, N, M, d->wc, d->temperature, d->thr, d->border_rm, d->scale_c, conf, cws,
+                                       b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count, 3, 2, qmask, qscale, s_fine));
     // ---- a9-a11: fine refinement (grid sized by capacity, device-side count) ----------------------------------------------------
+    if (qscale)
+        FR_CHECK(ophip_fine_refine_bf16_scaled(ff, fs_b, fs_c, fs_y, fs_x, d->hf, d->wf, desc_f, desc_f_bs, desc_f_cs, b_ids, I64(L->i_ids), I64(L->j_ids), count, cap,
+                                               F(L->mkc), d->w_fine, d->n_fine, d->fine_cross_bits, d->fine_encoder_enable, 3, d->wc, d->hf / d->hc, d->fine_scale,
+                                               F(L->expec), mk2d, nullptr, nullptr, qscale, s_fine));
+    else
     FR_CHECK(ophip_fine_refine_bf16(ff, fs_b, fs_c, fs_y, fs_x, d->hf, d->wf, desc_f, desc_f_bs, desc_f_cs, b_ids, I64(L->i_ids), I64(L->j_ids), count, cap,
                                     F(L->mkc), d->w_fine, d->n_fine, d->fine_cross_bits, d->fine_encoder_enable, 3, d->wc, d->hf / d->hc, d->fine_scale,
                                     F(L->expec), mk2d, nullptr, nullptr, s_fine));
@@ -316,6 +335,15 @@ extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_
     }
     *slot_out = gen * kSlots + idx;                         // ticket: ophip_frame_wait rejects nothing but knows a reused slot's frame is done
     return 0;
+}
+
+extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_layout_t* L, void* blob,
+                                   const float* feat_c, const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x,
+                                   const float* kpts, long long kpts_bs, const float* desc_c, long long desc_c_bs,
+                                   const float* desc_f, long long desc_f_bs, long long desc_f_cs, const float* x3d_external,
+                                   void* host_dst, size_t host_bytes, void* s_main, void* s_prep, void* s_fine, void* s_copy, int* slot_out) {
+    return ophip_frame_enqueue_padded(d, L, blob, feat_c, feat_f, fs_b, fs_c, fs_y, fs_x, kpts, kpts_bs, desc_c, desc_c_bs, desc_f, desc_f_bs, desc_f_cs,
+                                      x3d_external, nullptr, nullptr, host_dst, host_bytes, s_main, s_prep, s_fine, s_copy, slot_out);
 }
 
 extern "C" int ophip_frame_wait(int ticket) {

@@ -52,6 +52,10 @@ _SIGNATURES = {
                                   c_f, c_f, c_ll, c_ll, c_ll, c_ll, c_f, c_ll, c_f, c_ll, c_f, c_ll, c_ll, c_f,
                                   ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                   ctypes.POINTER(c_i)]),
+    "ophip_frame_enqueue_padded": (c_i, [ctypes.POINTER(FrameDesc), ctypes.POINTER(FrameLayout), ctypes.c_void_p,
+                                         c_f, c_f, c_ll, c_ll, c_ll, c_ll, c_f, c_ll, c_f, c_ll, c_f, c_ll, c_ll, c_f, c_f, c_f,
+                                         ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.POINTER(c_i)]),
     "ophip_frame_wait": (c_i, [c_i]),
     "ophip_frame_order_after_fine": (c_i, [ctypes.c_void_p]),
     "ophip_pe_add_transpose": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_void_p]),

@@ -306,7 +306,7 @@ class OnePosePlus_model(nn.Module):
         if (self.frame_call and self.precision == "bf16x3" and self.overlap_fine and not _pe_applied and not want_fine_debug
                 and not self.debug and isinstance(self.profiler, _NullProfiler) and bool(cfg["fine_matching"]["enable"])
                 and (self.kpt_3d_pos_encoding is not None or B == 1 or desc_in_d.shape[0] == B)
-                and len(self.loftr_coarse.layer_names) <= 16 and qmask is None and qscale is None):
+                and len(self.loftr_coarse.layer_names) <= 16):
             x3d_ext = None
             if self.cache_object:
                 ckey = (str(dev), B, N, kpts_d.data_ptr(), kpts_d._version, desc_in_d.data_ptr(), desc_in_d._version, id(W))
@@ -315,7 +315,7 @@ class OnePosePlus_model(nn.Module):
                     main.wait_event(self._obj_cache[2])
             if not self.cache_object or x3d_ext is not None:          # a cache miss takes the stage-by-stage path below, which fills the cache
                 return self._enqueue_frame_call(data, feat_c, feat_f, kpts_d, desc_in_d, desc_fine_d, x3d_ext, W, dev, main, fkey,
-                                                B, N, M, hc, wc, hf, wf, host_copy, inputs_ready, lazy, rerun)
+                                                B, N, M, hc, wc, hf, wf, host_copy, inputs_ready, lazy, rerun, qmask, qscale)
         if fkey in self._frame_call_pending:                          # order this frame's encoder behind the C path's last fine stage
             self._frame_call_pending.discard(fkey)
             lib_call("ophip_frame_order_after_fine", ctypes.c_void_p(main.cuda_stream))
@@ -539,7 +539,7 @@ class OnePosePlus_model(nn.Module):
         return st
 
     def _enqueue_frame_call(self, data, feat_c, feat_f, kpts_d, desc_in_d, desc_fine_d, x3d_ext, W, dev, main, fkey,
-                            B, N, M, hc, wc, hf, wf, host_copy, inputs_ready, lazy=False, rerun=None):
+                            B, N, M, hc, wc, hf, wf, host_copy, inputs_ready, lazy=False, rerun=None, qmask=None, qscale=None):
         """The whole frame through ``ophip_frame_enqueue`` (csrc/frame.hip): one device block, one C call."""
         cfg = self.config
         fc = feat_c if (feat_c.dtype == torch.float32 and feat_c.is_contiguous()) else feat_c.float().contiguous()
@@ -612,7 +612,7 @@ class OnePosePlus_model(nn.Module):
             # the whole frame through ONE custom op (torch.ops.onepose_hip.frame_enqueue -> ophip_frame_enqueue)
             slot = torch.ops.onepose_hip.frame_enqueue(plan_id, blob, fc, ff, list(fs), kpts_d, desc_in_d, desc_fine_d, x3d_ext, pin, nbytes,
                                                        main.cuda_stream, sprep.cuda_stream if sprep is not None else 0,
-                                                       sfine.cuda_stream, scopy.cuda_stream)
+                                                       sfine.cuda_stream, scopy.cuda_stream, qmask, qscale)
         except Exception:
             # part of the frame may be queued on the side streams already: nothing may touch the block or the pinned buffer again
             # before those streams are idle
@@ -623,10 +623,10 @@ class OnePosePlus_model(nn.Module):
         if lazy:
             f3 = blob[L.feat3d_out:L.feat3d_out + 4 * B * N * 256].view(torch.float32).view(B, N, 256)
             f2 = blob[L.feat2d_out:L.feat2d_out + 4 * B * M * 256].view(torch.float32).view(B, M, 256)
-            data["conf_matrix"] = LazyConfMatrix(f3, f2, float(cm["dual_softmax"]["temperature"]), 3, main)
+            data["conf_matrix"] = LazyConfMatrix(f3, f2, float(cm["dual_softmax"]["temperature"]), 3, main, qmask)
         else:
             data["conf_matrix"] = blob[L.conf:L.conf + 4 * B * N * M].view(torch.float32).view(B, N, M)
-        keep = [fc, ff, kpts_d, desc_in_d, desc_fine_d, x3d_ext, W]
+        keep = [fc, ff, kpts_d, desc_in_d, desc_fine_d, x3d_ext, W, qmask, qscale]
         pend = PendingFrame._from_block(self, data, dev, B, N, M, cap, blob, L, slot, pin, host_copy, keep)
         pend._rerun = rerun
         return pend

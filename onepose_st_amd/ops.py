@@ -42,7 +42,7 @@ _lib.define("fine_refine_bf16(Tensor feat_f_cl, Tensor desc3d_f, Tensor b_ids, T
             "Tensor wpack, int nlayers, int cross_bits, bool encoder_enable, int nsplit, int wc, int stride, float fine_scale) -> (Tensor, Tensor)")
 _lib.define("frame_enqueue(int plan, Tensor(a!) block, Tensor feat_c, Tensor feat_f, int[] fine_strides, Tensor keypoints3d, "
             "Tensor desc3d_c, Tensor desc3d_f, Tensor? x3d_external, Tensor(b!) host_dst, int host_bytes, "
-            "int s_main, int s_prep, int s_fine, int s_copy) -> int")
+            "int s_main, int s_prep, int s_fine, int s_copy, Tensor? query_mask=None, Tensor? query_scale=None) -> int")
 
 
 def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -148,8 +148,9 @@ def drop_frame_plan(pid: int):
 
 
 def _frame_enqueue(plan, block, feat_c, feat_f, fine_strides, keypoints3d, desc3d_c, desc3d_f, x3d_external, host_dst, host_bytes,
-                   s_main, s_prep, s_fine, s_copy):
-    """rows a1-a11 of one frame (``ophip_frame_enqueue``); returns the wait slot (``ophip_frame_wait``)."""
+                   s_main, s_prep, s_fine, s_copy, query_mask=None, query_scale=None):
+    """rows a1-a11 of one frame (``ophip_frame_enqueue_padded``; ``query_mask [B, M]`` uint8 / ``query_scale [B, 2]`` float32: the
+    reference's optional inputs of padded / resized query images); returns the wait ticket (``ophip_frame_wait``)."""
     if plan not in _frame_plans:
         raise ValueError(f"frame plan {plan} is not registered (ops.register_frame_plan)")
     d, L = _frame_plans[plan][:2]
@@ -163,10 +164,14 @@ def _frame_enqueue(plan, block, feat_c, feat_f, fine_strides, keypoints3d, desc3
     slot = ctypes.c_int(-1)
     vp = ctypes.c_void_p
     CALLS["frame_enqueue"] += 1
-    hip.call("ophip_frame_enqueue", ctypes.byref(d), ctypes.byref(L), vp(block.data_ptr()),
+    if query_mask is not None and (query_mask.dtype != torch.uint8 or tuple(query_mask.shape) != (d.B, d.M) or not query_mask.is_contiguous()):
+        raise ValueError("query_mask: contiguous uint8 [B, M]")
+    if query_scale is not None and (query_scale.dtype != torch.float32 or tuple(query_scale.shape) != (d.B, 2) or not query_scale.is_contiguous()):
+        raise ValueError("query_scale: contiguous float32 [B, 2]")
+    hip.call("ophip_frame_enqueue_padded", ctypes.byref(d), ctypes.byref(L), vp(block.data_ptr()),
              hip.ptr(feat_c), hip.ptr(feat_f), fs[0], fs[1], fs[2], fs[3], hip.ptr(keypoints3d), _bstride(keypoints3d),
              hip.ptr(desc3d_c), _bstride(desc3d_c), hip.ptr(desc3d_f), _bstride(desc3d_f), desc3d_f.stride(1), hip.ptr(x3d_external),
-             vp(host_dst.data_ptr()), int(host_bytes), vp(s_main), vp(s_prep) if s_prep else None, vp(s_fine), vp(s_copy), ctypes.byref(slot))
+             hip.ptr(query_mask, torch.uint8), hip.ptr(query_scale), vp(host_dst.data_ptr()), int(host_bytes), vp(s_main), vp(s_prep) if s_prep else None, vp(s_fine), vp(s_copy), ctypes.byref(slot))
     return slot.value
 
 

@@ -170,6 +170,38 @@ def test_b2_masked_scaled_against_reference_golden(model, sd, cfg, dev, golden_d
         model.forward_features(bad, d["feat_c"], d["feat_f"], both["image_hw"])
 
 
+def test_masked_frame_goes_through_the_one_call_path_bit_identically(sd, cfg, dev, golden_dir):
+    """a masked / scaled frame takes the default one-call frame path (ophip_frame_enqueue_padded, kept-back fine stage and all) and gives
+    the stage-by-stage path's outputs bit for bit -- also in a pipeline with unmasked frames before and after it"""
+    import copy
+    from onepose_st_amd import ops
+    g = np.load(os.path.join(golden_dir, "b2_masked_scaled_feature_boundary.npz"))
+    both = _masked_inputs(sd, cfg, g)
+    c = copy.deepcopy(cfg)
+    c["hip_frame_call"] = False
+    staged = _run_masked(_model(sd, c, dev, "bf16x3"), both, dev)
+    m = _model(sd, cfg, dev, "bf16x3")
+    before = ops.CALLS["frame_enqueue"]
+    one = _run_masked(m, both, dev)
+    assert ops.CALLS["frame_enqueue"] == before + 1
+    keys = ("b_ids", "i_ids", "j_ids", "mconf", "mkpts_query_c", "mkpts_query_f", "expec_f", "mkpts_3d_db", "conf_matrix")
+    for k in keys:
+        assert torch.equal(one[k], staged[k]), k
+    # pipeline: unmasked, masked, unmasked in flight together
+    d = to_dev(both, dev)
+    plain = {k: d[k] for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db")}
+    alone = dict(plain)
+    m.forward_features(alone, d["feat_c"], d["feat_f"], both["image_hw"])
+    datas = [dict(plain), {**plain, "query_image_mask": d["query_image_mask"], "query_image_scale": d["query_image_scale"]}, dict(plain)]
+    pend = [m.enqueue_features(x, d["feat_c"], d["feat_f"], both["image_hw"], host_copy=True) for x in datas]
+    for p in (pend[2], pend[0], pend[1]):
+        p.finish()
+    for k in keys[:-1]:
+        assert torch.equal(datas[0][k], alone[k]) and torch.equal(datas[2][k], alone[k]), k
+        assert torch.equal(datas[1][k], one[k]), k
+    assert not torch.equal(alone["j_ids"], one["j_ids"])
+
+
 def test_b2_masked_lazy_and_bf16_modes(sd, cfg, dev, golden_dir):
     """lazy conf_matrix with a mask == the eager form bit for bit; the plain-bf16 mode keeps the match set up to margin-free matches"""
     import copy

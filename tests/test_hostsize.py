@@ -81,3 +81,14 @@ def test_bench_launcher_passes_the_sizing_to_both_gloo_ranks():
     assert rec["pnp_threads"] == [hostsize.pnp_threads(share)] * 2
     if n >= 2:
         assert rec["first_cpu"][0] != rec["first_cpu"][1], "the two ranks must sit on different CPU ranges"
+
+
+def test_pool_stays_below_a_cgroup_cpu_quota():
+    """a CPU-time quota smaller than the mask: the pool leaves the feeder cores AND a margin unused (16 -> 12 threads, what ran without a
+    single throttled period on the GPU box); a mask-limited share keeps the old rule"""
+    assert hostsize.quota_limited(affinity=list(range(256)), quota=16)
+    assert not hostsize.quota_limited(affinity=list(range(16)), quota=16) and not hostsize.quota_limited(affinity=list(range(64)), quota=None)
+    assert hostsize.pnp_threads(16, under_quota=True) == 12 and hostsize.pnp_threads(16) == 14
+    assert hostsize.pnp_threads(8, under_quota=True, world=2) == 5          # two ranks share the margin
+    assert hostsize.pnp_threads(4, under_quota=True) == 2 and hostsize.pnp_threads(2, under_quota=True) == 1
+
