@@ -121,11 +121,11 @@ def main():
     # this rank's slice of the host: pinned before any thread pool exists (PnP workers and torch's intra-op threads inherit it)
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
     n_mask = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 0
+    under_quota = hostsize.quota_limited()               # asked BEFORE this rank narrows its own mask
     my_cpus = hostsize.pin_rank(local % max(local_world, 1), max(local_world, 1))
     n_now = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 0
     pinned = world > 1 and n_now == len(my_cpus)          # exactly this rank's share (the pool's threads then keep off the feeder cores)
     confined = world == 1 and 0 < n_now < n_mask             # one rank under a CPU quota: kept on a few times the quota's CPUs (hostsize.pin_rank)
-    under_quota = hostsize.quota_limited()
     pnp_threads = args.pnp_threads if args.pnp_threads > 0 else hostsize.pnp_threads(len(my_cpus), under_quota, max(local_world, 1))
     import torch
     if os.environ.get("OPHIP_BENCH_LAUNCH_PROBE"):
