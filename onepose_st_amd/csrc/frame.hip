@@ -279,12 +279,16 @@ extern "C" int ophip_frame_enqueue_padded(const ophip_frame_desc* d, const ophip
                                            b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count,
                                            nsplit_flags, d->lazy_conf ? 1 : 4, qmask, qscale, s_main));      // (lazy form: its candidate pass is a second matrix-bound tile pass)
         FR_HIP(hipEventRecord(slot->enc_done, s_main), "hipEventRecord(similarity)");
-        // the kept-back fine stage of the previous frame: on the side stream, behind this frame's similarity tiles, beside the rest
-        if (kept) FR_CHECK(launch_fine_job(dev, *kept, slot->enc_done));
         FR_CHECK(ophip_coarse_match_masked(x3, x2, kpts, kpts_bs, B, N, M, d->wc, d->temperature, d->thr, d->border_rm, d->scale_c, conf, cws,
                                            b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count,
                                            nsplit_flags, d->lazy_conf ? 2 : (8 | 2), qmask, qscale, s_main));
         FR_HIP(hipEventRecord(slot->coarse_done, s_main), "hipEventRecord(coarse)");
+        // the kept-back fine stage of the previous frame: on the side stream, behind this frame's similarity tiles, beside the rest.
+        // Submitted AFTER this frame's confidence pass and selection, so that those are in their hardware queue first (HIP maps streams
+        // onto a few hardware queues; the read-back stream's wait for that fine stage may share one with another stream of the frame).
+        // (Frames alternating between the two streams -- t + 2 right behind fine(t) on one queue, one cross-stream edge per frame instead
+        // of two -- was built and measured: 1 429 against 1 470 frames/s; the read-back's packets then sit between fine(t) and encoder(t + 2).)
+        if (kept) FR_CHECK(launch_fine_job(dev, *kept, slot->enc_done));
         FineJob& j = slot->job;
         j.s_main = s_main; j.s_fine = s_fine; j.s_copy = s_copy;
         j.ff = ff; j.fs_b = fs_b; j.fs_c = fs_c; j.fs_y = fs_y; j.fs_x = fs_x; j.hf = d->hf; j.wf = d->wf;
