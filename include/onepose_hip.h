@@ -21,6 +21,11 @@
 extern "C" {
 #endif
 
+/* Version of THIS header's structs and signatures; ophip_abi_version() returns the value the library was built with and a caller
+ * compares the two before its first call.  History: 1 = rounds 1-2; 2 = round 3 (lazy_conf inside ophip_frame_desc, the extended
+ * ophip_frame_layout_t, ophip_frame_wait takes the TICKET ophip_frame_enqueue returned (generation * 16 + slot, never below 16),
+ * ophip_encoder_layer_x3 / ophip_fine_refine_x3 removed). */
+#define OPHIP_ABI_VERSION 2
 int ophip_abi_version(void);
 /* host string: 16 hex digits of the sha256 over the sources this library was built from (the profiles/ pmc summaries record it;
  * bench.py quotes committed counter values only when they were taken on the running build) */

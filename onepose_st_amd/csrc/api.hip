@@ -1,5 +1,6 @@
 // C-ABI plumbing: version, error reporting, device queries.  See include/onepose_hip.h.
 #include "tile.h"
+#include "onepose_hip.h"
 #include <stdio.h>
 #include <string.h>
 
@@ -107,7 +108,7 @@ namespace { unsigned long long* g_stamps = nullptr; }
 extern "C" unsigned long long* ophip_stamp_buffer(void) { return g_stamps; }
 extern "C" int ophip_debug_stamps(void* device_buffer) { g_stamps = reinterpret_cast<unsigned long long*>(device_buffer); return 0; }
 
-extern "C" int ophip_abi_version(void) { return 1; }
+extern "C" int ophip_abi_version(void) { return OPHIP_ABI_VERSION; }
 
 #include "build/src_hash.h"
 // 16 hex digits of the sha256 over the library's sources (csrc/Makefile): which build produced a measurement

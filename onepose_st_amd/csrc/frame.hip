@@ -202,6 +202,20 @@ extern "C" int ophip_frame_enqueue_padded(const ophip_frame_desc* d, const ophip
         slot->recorded = false;
         gen = ++slot->gen;
     }
+    // From here on the slot belongs to this frame.  If any of the ~20 launches below fails, the frame is abandoned half queued: the guard
+    // then waits until nothing of it is left on the four streams (so no event of the slot is pending and no kernel still reads the
+    // caller's block) and hands the slot back clean -- not recorded, no kept-back fine stage -- before the error is returned; the previous
+    // frame of the stream keeps its own kept-back fine stage (ophip_frame_wait / the next enqueue launch it as usual).
+    struct AbandonGuard {
+        Slot* slot; hipStream_t st[4]; bool armed = true;
+        ~AbandonGuard() {
+            if (!armed) return;
+            for (hipStream_t s : st) if (s) (void)hipStreamSynchronize(s);
+            std::lock_guard<std::mutex> lk(g_mu);
+            slot->recorded = false;
+            slot->job.pending = false;
+        }
+    } abandon{slot, {s_main, s_prep, s_fine, s_copy}};
     auto F = [&](size_t off) { return reinterpret_cast<float*>(blob + off); };
     auto I64 = [&](size_t off) { return reinterpret_cast<long long*>(blob + off); };
 
@@ -304,6 +318,7 @@ extern "C" int ophip_frame_enqueue_padded(const ophip_frame_desc* d, const ophip
             j.pending = true;
             g_dev[dev].deferred[s_main] = idx;
         }
+        abandon.armed = false;
         *slot_out = gen * kSlots + idx;
         return 0;
     }
@@ -337,6 +352,7 @@ extern "C" int ophip_frame_enqueue_padded(const ophip_frame_desc* d, const ophip
         std::lock_guard<std::mutex> lk(g_mu);
         slot->recorded = true;
     }
+    abandon.armed = false;
     *slot_out = gen * kSlots + idx;                         // ticket: ophip_frame_wait rejects nothing but knows a reused slot's frame is done
     return 0;
 }

@@ -959,18 +959,19 @@ struct Ransac {
 
     // local optimisation of the winner: LM on the inliers, re-evaluate the inlier set, LM again
     int finish(Candidate& best, double* pose_out, unsigned char* inlier_mask, int* n_inliers) {
-        if (best.cnt < 6) return 1;
+        const int need = solver == 1 ? 4 : 6;              // inliers a pose must keep: the sample and, for P3P, the point that picked the root
+        if (best.cnt < need) return 1;
         std::vector<unsigned char> mask;
         for (int round = 0; round < 2; ++round) {
             refine_lm(P, best.mask.data(), best.pose, 20);
             mask = best.mask;
             best.cnt = count_inliers(P, best.pose, thr2, best.mask.data(), nullptr);
-            if (best.cnt < 6 || mask == best.mask) break;     // same inlier set: the pose is already its optimum
+            if (best.cnt < need || mask == best.mask) break;  // same inlier set: the pose is already its optimum
         }
         std::memcpy(pose_out, best.pose, sizeof(best.pose));
         if (inlier_mask) std::memcpy(inlier_mask, best.mask.data(), (size_t)n);
         if (n_inliers) *n_inliers = best.cnt;
-        return best.cnt >= 6 ? 0 : 1;
+        return best.cnt >= need ? 0 : 1;
     }
 };
 
@@ -993,6 +994,10 @@ const double kIdentPose[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
 
 extern "C" int oppnp_abi_version(void) { return 2; }
 
+// Fewest correspondences that give a pose: the 6-point DLT needs its sample; P3P + RANSAC (the pycolmap branch, metric_utils.py:155-165)
+// needs the three of a sample and ONE more point to pick the root, so frames with 4 or 5 matches still get a pose there.
+static int min_points(int solver) { return solver == 1 ? 4 : 6; }
+
 // minimal solver alone (tests): rays = three normalised image points, X = three world points -> up to four poses [R | t]
 extern "C" int oppnp_p3p(const double* rays3x2, const double* X3x3, double* poses4x12) {
     if (!rays3x2 || !X3x3 || !poses4x12) return -1;
@@ -1008,7 +1013,7 @@ extern "C" int oppnp_ransac(const double* K, const float* pts2d, const float* pt
     if (inlier_mask && n > 0) std::memset(inlier_mask, 0, (size_t)n);
     if (n_inliers) *n_inliers = 0;
     if (iters_run) *iters_run = 0;
-    if (n < 6) return 1;                                  // too few correspondences: identity pose, no inliers
+    if (n < min_points(solver)) return 1;                 // too few correspondences: identity pose, no inliers
     Ransac R;
     R.setup(K, pts2d, pts3d, n, reproj_err_px, confidence, min_iters, max_iters, seed, solver);
     Candidate best;
@@ -1129,7 +1134,7 @@ extern "C" long long oppnp_pool_submit(void* pool_, const double* K, const float
     Pool* pool = reinterpret_cast<Pool*>(pool_);
     if (!pool || !K || n < 0 || (n > 0 && (!pts2d || !pts3d)) || max_iters < 1 || min_iters < 0 || (solver != 0 && solver != 1)) return -1;
     long long ticket;
-    if (n < 6) {                                          // no pose: identity, recorded at once
+    if (n < min_points(solver)) {                         // no pose: identity, recorded at once
         Result r;
         std::memcpy(r.pose, kIdentPose, sizeof(kIdentPose));
         r.n_inliers = 0; r.rc = 1;

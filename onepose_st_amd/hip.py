@@ -14,6 +14,7 @@ import torch
 
 _LIB_PATH = os.environ.get("OPHIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libonepose_hip.so")   # OPHIP_LIB: A/B builds
 _lib = None
+ABI_VERSION = 2         # include/onepose_hip.h OPHIP_ABI_VERSION: what FrameDesc / FrameLayout / _SIGNATURES below are written for
 
 c_f = ctypes.c_void_p      # device float*
 c_i = ctypes.c_int
@@ -130,8 +131,9 @@ def load():
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.ophip_abi_version() != 1:
-        raise HipLibraryError("libonepose_hip.so ABI version mismatch")
+    if lib.ophip_abi_version() != ABI_VERSION:
+        raise HipLibraryError(f"libonepose_hip.so ABI version {lib.ophip_abi_version()}, this binding is written for {ABI_VERSION} "
+                              "(include/onepose_hip.h OPHIP_ABI_VERSION): rebuild with __graft_entry__.build()")
     _lib = lib
     return lib
 

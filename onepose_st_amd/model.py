@@ -24,6 +24,7 @@ import contextlib
 import ctypes
 import math
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -142,6 +143,9 @@ class OnePosePlus_model(nn.Module):
         # ~27 ctypes calls + ~20 allocations + ~10 stream / event operations from Python: 0.39 -> ~0.1 ms of host time per frame
         self.frame_call = bool(config.get("hip_frame_call", os.environ.get("OPHIP_FRAME_CALL", "1") != "0"))
         self._frame_plans = {}
+        # ids this model holds in ops._frame_plans (whose entries keep the packed weight blocks alive): released when the model is collected
+        self._plan_ids = set()
+        weakref.finalize(self, ops.drop_frame_plans, self._plan_ids)
         self._frame_call_pending = set()     # compute streams whose last frame went through the C entry point
 
         pretrained = config["loftr_backbone"]["pretrained"]
@@ -573,9 +577,13 @@ class OnePosePlus_model(nn.Module):
             L = hip.FrameLayout()
             hip.call("ophip_frame_layout", ctypes.byref(d), 1 if transpose_fine else 0, 1 if x3d_ext is not None else 0, ctypes.byref(L))
             if len(self._frame_plans) >= 8:
-                ops.drop_frame_plan(self._frame_plans.pop(next(iter(self._frame_plans)))[2])
-            plan = self._frame_plans[pkey] = (d, L, ops.register_frame_plan(d, L, keep_alive=(W, pe)))      # W and the table stay alive with the pointers
-        d, L, plan_id = plan
+                old_id = self._frame_plans.pop(next(iter(self._frame_plans)))[2]
+                self._plan_ids.discard(old_id)
+                ops.drop_frame_plan(old_id)
+            pid = ops.register_frame_plan(d, L, keep_alive=(W, pe))
+            self._plan_ids.add(pid)
+            plan = self._frame_plans[pkey] = (d, L, pid, (W, pe))      # W and the table stay alive with the pointers, here and in the registry
+        d, L, plan_id = plan[:3]
 
         prev = self._fine_streams.get(fkey)
         if prev is not None and prev[1] is not None:                      # a stage-by-stage frame before this one: order behind its fine stage

@@ -23,6 +23,7 @@ Reference: ``loftr_module/transformer.py:65-171``, ``utils/coarse_matching.py:76
 from __future__ import annotations
 
 import ctypes
+import itertools
 
 import torch
 
@@ -133,18 +134,26 @@ def _fine_refine_bf16(feat_f_cl, desc3d_f, b_ids, i_ids, j_ids, count, mkpts_c, 
 CALLS = {"frame_enqueue": 0}          # how many frames went through the op (tests assert the model's default path uses it)
 
 # frame plans: the (ophip_frame_desc, ophip_frame_layout_t) pair of a model + input shape, registered by the model once and named
-# by an integer in the op call (an op schema cannot carry a C struct)
+# by an integer in the op call (an op schema cannot carry a C struct).  Ids come from a counter that never goes back: a dropped plan's
+# id is never handed out again, so a stale id can only raise, never launch a frame with another plan's sizes and offsets.
 _frame_plans = {}
+_plan_ids = itertools.count(1)
 
 
 def register_frame_plan(desc: "hip.FrameDesc", layout: "hip.FrameLayout", keep_alive=()) -> int:
-    pid = len(_frame_plans) + 1
+    pid = next(_plan_ids)
     _frame_plans[pid] = (desc, layout, keep_alive)
     return pid
 
 
 def drop_frame_plan(pid: int):
     _frame_plans.pop(pid, None)
+
+
+def drop_frame_plans(pids):
+    """release every plan of ``pids`` (a model's finalizer: its packed weight blocks leave HBM with it)"""
+    for pid in list(pids):
+        _frame_plans.pop(pid, None)
 
 
 def _frame_enqueue(plan, block, feat_c, feat_f, fine_strides, keypoints3d, desc3d_c, desc3d_f, x3d_external, host_dst, host_bytes,

@@ -54,7 +54,9 @@ def test_cabi_exports_every_declared_symbol():
     lib = ctypes.CDLL(hip.library_path())
     for name in declared:
         assert hasattr(lib, name), name
-    assert hip.load().ophip_abi_version() == 1
+    assert hip.load().ophip_abi_version() == hip.ABI_VERSION == 2
+    header = open(os.path.join(REPO, "include", "onepose_hip.h")).read()
+    assert "#define OPHIP_ABI_VERSION 2" in header          # header, library and binding carry the same number
     assert hip.load().ophip_encoder_workspace_floats(1, 7000, 4800) == (219 + 150 + 2) * 8448
 
 
@@ -93,6 +95,39 @@ def test_custom_ops_are_registered_without_a_cpu_implementation():
         torch.ops.onepose_hip.pe_add_transpose(torch.zeros(1, 256, 2, 2), None, torch.zeros(1, 4, 256))
     with pytest.raises(NotImplementedError):
         torch.ops.onepose_hip.coarse_match(torch.zeros(1, 8, 256), torch.zeros(1, 4, 256), torch.zeros(1, 8, 3), 2, 0.08, 0.1, 2, 8.0, 3)
+
+
+def test_frame_plan_ids_are_never_reused():
+    """ops.register_frame_plan: a model drops its oldest plan once it holds more than eight input shapes; the id of a dropped plan must
+    never come back while other plans are live (it used to be len(dict) + 1: register 8, drop #1, register -> a second #8 that replaced
+    the live plan 8, and the next frame of that shape was launched with another shape's sizes and offsets)."""
+    import gc
+    from onepose_st_amd import ops
+    made = []
+    for k in range(8):
+        d, L = hip.FrameDesc(), hip.FrameLayout()
+        d.N = 100 + k
+        made.append((ops.register_frame_plan(d, L, keep_alive=(k,)), d))
+    ops.drop_frame_plan(made[0][0])
+    d9, L9 = hip.FrameDesc(), hip.FrameLayout()
+    d9.N = 999
+    pid9 = ops.register_frame_plan(d9, L9)
+    ids = [p for p, _ in made] + [pid9]
+    assert len(set(ids)) == 9 and pid9 > max(p for p, _ in made)
+    for pid, d in made[1:]:
+        assert ops._frame_plans[pid][0] is d and ops._frame_plans[pid][0].N == d.N        # plan 8 (and every other live plan) untouched
+    assert made[0][0] not in ops._frame_plans
+    with pytest.raises(ValueError):                                                        # a stale id raises, it cannot launch anything
+        ops._frame_enqueue(made[0][0], None, None, None, [0, 0, 0, 0], None, None, None, None, None, 0, 0, 0, 0, 0)
+    ops.drop_frame_plans(ids)
+    # a collected model releases its plans (and with them the packed weight blocks the registry kept alive)
+    m = OnePosePlus_model(default_config())
+    keep = m._plan_ids
+    pid = ops.register_frame_plan(hip.FrameDesc(), hip.FrameLayout(), keep_alive=("weights",))
+    keep.add(pid)
+    del m
+    gc.collect()
+    assert pid not in ops._frame_plans
 
 
 def test_frame_layout_is_aligned_and_disjoint():

@@ -1102,3 +1102,51 @@ def test_model_default_path_dispatches_through_the_frame_op(sd, cfg, dev):
         assert data["i_ids"].numel() > 20
     assert len(ops._frame_plans) == n_plans + 1               # one plan per (model, input shape), registered once
     assert ops.CALLS["frame_enqueue"] == n_calls + 3           # one op call per frame
+
+
+@pytest.mark.gpu
+def test_more_than_eight_input_shapes_through_one_model(sd, cfg, dev):
+    """A model keeps at most eight frame plans and drops the oldest; plan ids are never reused (ops.register_frame_plan), so cycling ten
+    shapes and coming back to the first and to the one registered eighth gives the same bits as a fresh model on each shape."""
+    from onepose_st_amd import ops
+    m = _model(sd, cfg, dev, "bf16x3")
+    shapes = [(200 + 16 * k, (64, 96 + 8 * k)) for k in range(10)]
+    inputs = [make_synthetic_inputs(sd, n_points=n, image_hw=hw, n_plant=60, seed=20 + k, config=cfg) for k, (n, hw) in enumerate(shapes)]
+    first = [_run_features(m, inp, dev) for inp in inputs]
+    assert len(m._frame_plans) == 8 and len(m._plan_ids) == 8 and m._plan_ids <= set(ops._frame_plans)
+    for k in (0, 7, 9, 1):                                       # 0 and 1 were dropped and come back under new ids; 7 and 9 are still resident
+        again = _run_features(m, inputs[k], dev)
+        fresh = _run_features(_model(sd, cfg, dev, "bf16x3"), inputs[k], dev)
+        for key in ("i_ids", "j_ids", "mconf", "mkpts_query_f", "expec_f"):
+            assert torch.equal(again[key], first[k][key]) and torch.equal(again[key], fresh[key]), (k, key)
+        assert again["i_ids"].numel() > 20
+
+
+@pytest.mark.gpu
+def test_a_failed_enqueue_leaves_the_pipeline_usable(sd, cfg, dev):
+    """ophip_frame_enqueue fails in the middle of a frame (a NULL weight block for coarse layer 3: the input kernels and three encoder
+    layers are already queued): the call returns the error, the slot goes back clean, and twenty more frames through the same streams
+    -- pipelined, three in flight -- give the bits of the frames before the failure."""
+    from onepose_st_amd import ops
+    m = _model(sd, cfg, dev, "bf16x3")
+    inp = make_synthetic_inputs(sd, n_points=500, image_hw=(96, 128), n_plant=150, seed=31, config=cfg)
+    d = to_dev(inp, dev)
+    obj = {k: d[k] for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db")}
+    want = _run_features(m, inp, dev)
+    pend = [m.enqueue_features(dict(obj), d["feat_c"], d["feat_f"], inp["image_hw"]) for _ in range(2)]      # two frames in flight
+    (plan,) = [p for p in m._frame_plans.values()]
+    desc = plan[0]
+    saved = desc.w_coarse[3]
+    desc.w_coarse[3] = None
+    with pytest.raises(ValueError):
+        m.enqueue_features(dict(obj), d["feat_c"], d["feat_f"], inp["image_hw"])
+    desc.w_coarse[3] = saved
+    for _ in range(20):
+        pend.append(m.enqueue_features(dict(obj), d["feat_c"], d["feat_f"], inp["image_hw"]))
+        if len(pend) >= 3:
+            got = pend.pop(0).finish()
+            for key in ("i_ids", "j_ids", "mconf", "mkpts_query_f"):
+                assert torch.equal(got[key], want[key]), key
+    while pend:
+        got = pend.pop(0).finish()
+        assert torch.equal(got["i_ids"], want["i_ids"]) and torch.equal(got["mkpts_query_f"], want["mkpts_query_f"])

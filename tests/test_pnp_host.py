@@ -55,6 +55,25 @@ def test_scale_argument_and_degenerate_inputs():
         ransac_PnP(K, uv[:10], X[:9])
 
 
+@pytest.mark.parametrize("n", [4, 5])
+def test_p3p_branch_gives_a_pose_from_four_or_five_matches(n):
+    """pycolmap's P3P + RANSAC needs a sample of three and one more point to pick the root, so the pycolmap branch
+    (use_pycolmap_ransac=True, what inference.py:181-189 passes) returns a pose for 4 and 5 matches; the 6-point branch cannot."""
+    K, uv, X, R, t, _ = _scene(40, 5)
+    pose, homo, inl = ransac_PnP(K, uv[:n], X[:n], pnp_reprojection_error=7, use_pycolmap_ransac=True)
+    assert len(inl) == n
+    assert _rot_err(pose[:, :3], R) < 1e-2 and np.linalg.norm(pose[:, 3] - t) / np.linalg.norm(t) < 1e-3
+    pool = PnPPool(K, threads=2, policy="reference")
+    tk = pool.submit(uv[:n], X[:n])
+    pool.wait_all()
+    pp, n_in, rc = pool.result(tk)
+    assert rc == 0 and n_in == n and np.allclose(pp, pose, atol=1e-9)
+    pose6, _, inl6 = ransac_PnP(K, uv[:n], X[:n], use_pycolmap_ransac=False)          # 6-point DLT branch: identity, no inliers
+    assert np.array_equal(pose6, np.eye(4)[:3]) and len(inl6) == 0
+    pose3, _, inl3 = ransac_PnP(K, uv[:3], X[:3], use_pycolmap_ransac=True)           # three points: no way to pick a root
+    assert np.array_equal(pose3, np.eye(4)[:3]) and len(inl3) == 0
+
+
 def test_pose_is_insensitive_at_matcher_noise_level():
     """1e-4 px perturbations of the 2D keypoints (the HIP path's deviation from the oracle) move the pose by < 1e-6 rel."""
     K, uv, X, R, t, _ = _scene(2800, 3, noise_px=0.7)
