@@ -41,7 +41,7 @@ sys.path.insert(0, REPO)
 from onepose_st_amd import hostsize  # noqa: E402        (pure host logic; torch and the HIP binding are imported inside main(),
 from onepose_st_amd.launch import launched_by_torchrun, spawn_ranks, visible_gpu_count  # noqa: E402   after the launcher branch)
 
-WORKLOADS = ("c1", "c2", "c4")
+WORKLOADS = ("c1", "c2", "c4", "c1_hard", "c2_hard")          # *_hard: low-margin / outlier variants (synthetic.HARD_PROFILE), not BASELINE configs
 
 # MI355X_MICROARCH.md dense matrix peaks: f32 (v_mfma_f32_32x32x2_f32) 157.3 TFLOP/s; bf16 (v_mfma_f32_32x32x16_bf16) 2.5 PFLOP/s.
 # Split-bf16 issues 3 bf16 MFMAs per algorithmic product and is priced against the bf16 peak with 1x algorithmic FLOPs.
@@ -62,6 +62,25 @@ def attn_apply_flops(n_tokens: int, fused_kv: bool, n_layers: int = 6, C: int = 
     if fused_kv:
         per_tok += (n_layers - 1) / n_layers * (4.0 * C * C + 2.0 * C * D)
     return float(n_tokens) * per_tok
+
+
+def rank_report(rows, world: int, frames_expected: int) -> dict:
+    """What rank 0 prints about EVERY rank, so that a --gpus N line checks itself: `rows` = the all-gathered per-rank records
+    [rank, frames finished, own seconds of the timed region, own PnP ceiling in frames/s, local rank / device index].  `reporting` must
+    equal `expected` and every rank must have finished its frames; `value_sum_of_ranks` (each rank's own rate, summed) against the
+    line's `value` (all frames / slowest rank's time) shows how uneven the ranks were.  Reference pattern: the driver-side fan-out and
+    gather of inference_OnePosePlus.py:81-98."""
+    per = []
+    for r in rows:
+        rk, frames, secs, ceil_, dev_ix = (float(x) for x in r[:5])
+        per.append({"rank": int(rk), "device": int(dev_ix), "frames": int(frames), "seconds": secs,
+                    "value": (frames / secs) if secs > 0 else None, "pnp_ceiling_fps": ceil_ if ceil_ > 0 else None})
+    per.sort(key=lambda d: d["rank"])
+    ok = (len(per) == world and [d["rank"] for d in per] == list(range(world)) and all(d["frames"] == frames_expected for d in per))
+    vals = [d["value"] for d in per if d["value"]]
+    return {"expected": world, "reporting": len(per), "all_frames_done": bool(ok),
+            "value_sum_of_ranks": sum(vals) if vals else None,
+            "slowest_over_fastest": (min(vals) / max(vals)) if vals else None, "per_rank": per}
 
 
 def main():
@@ -101,6 +120,11 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses cuda:0 (one-GPU box, with --dist-backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-kernel", default="attn_apply", choices=["attn_apply", "conf"],
+                    help="which kernel carries the start / stop events inside the timed region and fills `roofline`: attn_apply (MFMA-bound, the "
+                         "headline's) or conf (HBM-bound: the dual-softmax product pass over the N x M matrix; what the c4 side leg reports)")
+    ap.add_argument("--no-side-legs", action="store_true",
+                    help="skip the BASELINE config 3 (32 frames per step) and config 4 (15k x 19 200) side legs that a default c2 run appends to its line")
     ap.add_argument("--cpu-seconds", type=float, default=40.0, help="budget of the CPU baseline leg (all-core, full-forward and single-thread samples)")
     args = ap.parse_args()
 
@@ -137,15 +161,20 @@ def main():
         if world > 1:
             dist.all_reduce(seen)
         sizes = torch.tensor([float(len(my_cpus)), float(pnp_threads), float(my_cpus[0])])
+        # the per-rank report of the real line (rank_report below), filled with stand-in numbers: frames done, own seconds, own PnP ceiling
+        mine = torch.tensor([float(rank), float(args.steps * args.batch), 1.0 + 0.01 * rank, 1000.0 + rank, float(local)], dtype=torch.float64)
         if world > 1:
             gathered = [torch.zeros(3) for _ in range(world)]
             dist.all_gather(gathered, sizes)
+            reports = [torch.zeros(5, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(reports, mine)
         else:
-            gathered = [sizes]
+            gathered, reports = [sizes], [mine]
         if rank == 0:
             print(json.dumps({"probe": True, "n_gpus": world, "rank_sum": float(seen.item()), "local_rank": local,
                               "host_cores": [int(g[0]) for g in gathered], "pnp_threads": [int(g[1]) for g in gathered],
-                              "first_cpu": [int(g[2]) for g in gathered]}))
+                              "first_cpu": [int(g[2]) for g in gathered],
+                              "ranks": rank_report(reports, world, args.steps * args.batch)}))
         if world > 1:
             dist.destroy_process_group()
         return
@@ -154,7 +183,7 @@ def main():
     from onepose_st_amd.model import OnePosePlus_model
     from onepose_st_amd.pnp import PnPPool
     from onepose_st_amd.sharding import OBJECT_KEYS as OBJ_KEYS, broadcast_object_block, frame_chunk
-    from onepose_st_amd.synthetic import CONFIG_SIZES, make_synthetic_inputs, make_synthetic_state_dict
+    from onepose_st_amd.synthetic import CONFIG_SIZES, make_synthetic_inputs, make_synthetic_state_dict, workload_kwargs
     if args.share_device:
         local = 0
     torch.cuda.set_device(local)
@@ -181,10 +210,18 @@ def main():
 
     # ---- weights + the shared 3D object block: built on rank 0, broadcast once ----------------------
     sd = make_synthetic_state_dict(0, cfg)
-    first = make_synthetic_inputs(sd, n_points, image_hw, n_plant, seed=1, config=cfg, frame=0)
-    bcast_bytes = 0
+    wkw = workload_kwargs(args.workload)
+    first = make_synthetic_inputs(sd, n_points, image_hw, n_plant, seed=1, config=cfg, frame=0, **wkw)
+    bcast_bytes, bcast_ms = 0, None
     if dist_on:
+        import torch.distributed as dist
+        dist.barrier()
+        torch.cuda.synchronize()
+        t_b = time.perf_counter()
         sd, obj, bcast_bytes = broadcast_object_block(sd, first, dev)
+        torch.cuda.synchronize()
+        dist.barrier()
+        bcast_ms = (time.perf_counter() - t_b) * 1e3          # rank 0's view, barrier to barrier: the one collective of the job (first use: includes RCCL's ring set-up)
     else:
         obj = {k: first[k].to(dev) for k in OBJ_KEYS}
     model = OnePosePlus_model(cfg).eval()
@@ -194,7 +231,7 @@ def main():
     # ---- this rank's frames (frame ids are disjoint across ranks) --------------------------------
     frames = []
     for fid in frame_chunk(world * args.frames, rank, world):
-        inp = first if fid == 0 else make_synthetic_inputs(sd, n_points, image_hw, n_plant, seed=1, config=cfg, frame=fid)
+        inp = first if fid == 0 else make_synthetic_inputs(sd, n_points, image_hw, n_plant, seed=1, config=cfg, frame=fid, **wkw)
         frames.append((inp["feat_c"].to(dev), inp["feat_f"].to(dev)))
     batches = []
     for s in range(args.frames):
@@ -248,7 +285,7 @@ def main():
 
     # frames alternate over `--streams` HIP streams: consecutive frames are independent, so the single-workgroup
     # kernels and launch tails of one frame (select, kpt_stats, kv_sum ...) overlap the wide kernels of the next
-    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
+    streams = [torch.cuda.Stream(device=dev, priority=int(os.environ.get("OPHIP_MAIN_PRIO", "0"))) for _ in range(max(1, args.streams))]
     depth = args.depth if args.depth > 0 else len(streams) + (1 if os.environ.get("OPHIP_FRAME_DEFER_FINE", "1") == "0" else 2)
 
     image = torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(7)).to(dev) if args.with_backbone else None
@@ -319,6 +356,8 @@ def main():
     poses = join_poses()
     n_inliers = int(poses[-1][1]) if poses else -1
 
+    own_dt = [0.0]          # this rank's own seconds of the last timed region (before the max over ranks)
+
     def timed_region(active_pool):
         """W warm-up + exactly K timed steps with `active_pool` solving the poses (None: matcher only); returns seconds (max over ranks)"""
         nonlocal pool
@@ -344,6 +383,7 @@ def main():
         dt_ = time.perf_counter() - t0
         gc.enable()
         host_t["tail"] = dt_ - (t_gpu - t0)          # after the last frame left the GPU: its pose (and the final barrier)
+        own_dt[0] = dt_
         if dist_on:
             import torch.distributed as dist
             tt = torch.tensor([dt_], device=dev, dtype=torch.float64)
@@ -380,8 +420,8 @@ def main():
     # the timed launches carry a start / stop event pair filled with the dispatch's own timestamps (hipExtLaunchKernelGGL); such a launch
     # costs the stream a few us more than a plain one: timing all 6 launches of every frame took 9 % off `value`, every 11th launch
     # (coprime with the 6 layers, so every layer is sampled equally) ~2 %, with the same average
-    time_every = int(os.environ.get("OPHIP_BENCH_TIME_EVERY", "11"))
-    hip.timing_select("attn_apply", every=time_every)
+    time_every = int(os.environ.get("OPHIP_BENCH_TIME_EVERY", "11" if args.roofline_kernel == "attn_apply" else "1"))
+    hip.timing_select(args.roofline_kernel, every=time_every)
 
     def throttle_stat():
         """(nr_throttled, throttled_usec) of this cgroup's CPU quota (cgroup v2 cpu.stat / v1 cpu.stat in ns): a job that asks for more CPU
@@ -410,6 +450,7 @@ def main():
     t_wall0 = time.perf_counter()
     thr0 = throttle_stat()
     dt = timed_region(pools.get(args.pnp_policy))
+    dt_own = own_dt[0]
     thr1 = throttle_stat()
     if tc0 is not None and rank == 0:
         tc1, wall = thread_cpu(), time.perf_counter() - t_wall0
@@ -426,6 +467,7 @@ def main():
     # what the host side can sustain by itself: this rank's pool alone on recorded matches, every rank at once (they share the host);
     # when that ceiling is below the matcher's rate, `value` is a host number and the line says so ("host_bound")
     pnp_ceiling = None
+    own_rate = 0.0
     if pools and last_host[0] is not None and last_host[0]["K"] > 0:
         pl, hst = pools[args.pnp_policy], last_host[0]
         sel = slice(None) if B == 1 else (hst["b_ids"] == 0)
@@ -438,6 +480,7 @@ def main():
         for tk in tickets:
             pl.result(tk)
         rate = n_rep / (time.perf_counter() - t0)
+        own_rate = rate
         if dist_on:
             import torch.distributed as dist
             tt = torch.tensor([rate], device=dev, dtype=torch.float64)
@@ -463,6 +506,19 @@ def main():
                 pmc_note = f"profiles/{pmc_path} (build {hip.build_stamp()})"
     except (OSError, KeyError, ValueError, IndexError):
         pass
+
+    # every rank's own record travels to rank 0: the line then says how many ranks reported, what each did, and what the broadcast cost
+    mine = torch.tensor([float(rank), float(args.steps * B), float(dt_own), float(own_rate), float(local)], dtype=torch.float64, device=dev)
+    if dist_on:
+        import torch.distributed as dist
+        rows = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(rows, mine)
+        rows = [r.cpu().tolist() for r in rows]
+    else:
+        rows = [mine.cpu().tolist()]
+    ranks = rank_report(rows, world, args.steps * B)
+    if rank == 0 and not ranks["all_frames_done"]:
+        raise SystemExit(f"--gpus {world}: {ranks['reporting']} of {ranks['expected']} ranks reported / not every rank finished its frames: {ranks}")
 
     frames_total = world * args.steps * B
     value = frames_total / dt
@@ -491,7 +547,8 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"{args.workload}: {n_points} 3D points x {M} 2D cells ({H}x{W} image), d256 coarse / d128 fine, "
-                        f"{n_plant} planted matches per frame, {B} frame(s) per step, feature-boundary inputs resident in HBM",
+                        f"{n_plant} planted matches per frame" + (f" (low-margin / outlier profile {wkw})" if wkw else "")
+                        + f", {B} frame(s) per step, feature-boundary inputs resident in HBM",
             "frames_per_step": B,
             "matches_per_frame": n_matches // max(B, 1),
             "timed_region": "rows a1-a11 (PE, keypoint encoding, 6-layer coarse encoder, dual-softmax + mutual-NN incl. the "
@@ -504,6 +561,9 @@ def main():
             "streams": len(streams), "frames_in_flight": depth,
             "parallelism": f"frames sharded over {world} rank(s), one RCCL broadcast of weights + 3D block ({bcast_bytes} B)",
         },
+        "ranks": ranks,
+        "broadcast": {"bytes": bcast_bytes, "ms": bcast_ms, "backend": (args.dist_backend if dist_on else None),
+                      "gb_per_s": (bcast_bytes / bcast_ms / 1e6) if bcast_ms else None},
         "host": {
             "cgroup_cpu_throttled_in_timed_region": ({"periods": thr1[0] - thr0[0], "usec": round(thr1[1] - thr0[1])} if thr0 and thr1 else None),
             "host_cores_per_rank": len(my_cpus), "cpus_of_rank0": [my_cpus[0], my_cpus[-1]], "pinned": pinned, "under_cgroup_cpu_quota": under_quota, "confined_to_cpus": (n_now if confined else None),
@@ -533,6 +593,56 @@ def main():
             "flops_per_launch": flops,
         },
     }
+    if args.roofline_kernel == "conf":
+        # the HBM-bound kernel of the path (dual softmax + mutual-NN): conf_kernel reads the stored similarity once and writes
+        # conf_matrix once -- 2 x 4 B per (i, j) pair.  The STAGE's algorithmic traffic (inputs once + ONE f32 write of the matrix) is
+        # printed beside it: the similarity kernel's store of S is the pass the fused design would not need.
+        kbytes = 2.0 * 4.0 * B * n_points * M
+        gbs = kbytes / (avg_ms * 1e-3) / 1e9 if launches else 0.0
+        result["roofline"] = {
+            "kernel": "conf_kernel<true, true> (dual-softmax product in log form + candidate tracking: reads S, writes conf_matrix)",
+            "bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+            "frac_of_measured_copy_rate": gbs / 6290.0,          # MI355X_MICROARCH.md: 6.29 TB/s float4 copy
+            "traffic": None, "bytes_per_launch": kbytes,
+            "stage_algorithmic_bytes": float(B) * ((n_points + M) * 256 * 2 + 4.0 * n_points * M),
+            "launches": launches, "launches_sampled_every": time_every, "avg_launch_ms": avg_ms, "library_build_stamp": hip.build_stamp(),
+        }
+
+    # ---- side legs: BASELINE configs 3 and 4 on this GPU, each in a child process of its own (same script, its own sizes), untimed by the
+    #      headline: `value` above is config 2's and is final before they start ----------------------------------------------------------
+    if rank == 0 and world == 1 and not args.main_region_only and not args.no_side_legs and args.workload == "c2" and B == 1:
+        import subprocess
+
+        def side_leg(extra, timeout=240):
+            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-cpu-baseline", "--main-region-only", "--no-side-legs",
+                   "--precision", args.precision] + extra
+            try:
+                p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+                line = [ln for ln in p.stdout.splitlines() if ln.lstrip().startswith("{")]
+                if p.returncode != 0 or not line:
+                    return {"error": (p.stderr or p.stdout)[-400:]}
+                return json.loads(line[-1])
+            except (subprocess.TimeoutExpired, OSError, ValueError) as e:
+                return {"error": repr(e)[:400]}
+        torch.cuda.empty_cache()
+        c3 = side_leg(["--workload", "c2", "--batch", "32", "--steps", "6", "--warmup", "2"])
+        c4 = side_leg(["--workload", "c4", "--steps", "16", "--warmup", "4", "--roofline-kernel", "conf"])
+        # the low-margin / outlier variant of c2 (synthetic.HARD_PROFILE: confidences all over (0, 1), ~40 % of the matches wrong): what
+        # the matcher and -- above all -- the reference-policy RANSAC cost when frames are not clean (pose parity on it: tests/test_gpu_parity.py)
+        ch = side_leg(["--workload", "c2_hard", "--steps", "40", "--warmup", "5"])
+        result["value_c3_b32"] = c3.get("value")
+        result["value_c4"] = c4.get("value")
+        result["value_c2_hard"] = ch.get("value")
+        result["side_legs"] = {
+            "c2_hard": {k: ch.get(k) for k in ("value", "ms_per_step", "steps", "error") if k in ch}
+                       | {"workload": (ch.get("config") or {}).get("workload"), "matches_per_frame": (ch.get("config") or {}).get("matches_per_frame"),
+                          "pnp_inliers_per_frame": (ch.get("config") or {}).get("pnp_inliers_per_frame"),
+                          "pnp_ceiling_fps": (ch.get("host") or {}).get("pnp_ceiling_fps"), "host_bound": (ch.get("host") or {}).get("host_bound"),
+                          "pnp_threads": (ch.get("host") or {}).get("pnp_threads_per_rank")},
+            "c3": {k: c3.get(k) for k in ("value", "ms_per_step", "steps", "error") if k in c3} | {"workload": (c3.get("config") or {}).get("workload")},
+            "c4": {k: c4.get(k) for k in ("value", "ms_per_step", "steps", "error") if k in c4} | {"workload": (c4.get("config") or {}).get("workload"),
+                                                                                                     "conf_kernel": c4.get("roofline")},
+        }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import onepose_oracle as orc          # cpu_baseline leg only

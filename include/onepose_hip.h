@@ -24,8 +24,9 @@ extern "C" {
 /* Version of THIS header's structs and signatures; ophip_abi_version() returns the value the library was built with and a caller
  * compares the two before its first call.  History: 1 = rounds 1-2; 2 = round 3 (lazy_conf inside ophip_frame_desc, the extended
  * ophip_frame_layout_t, ophip_frame_wait takes the TICKET ophip_frame_enqueue returned (generation * 16 + slot, never below 16),
- * ophip_encoder_layer_x3 / ophip_fine_refine_x3 removed). */
-#define OPHIP_ABI_VERSION 2
+ * ophip_encoder_layer_x3 / ophip_fine_refine_x3 removed); 3 = round 4 (ophip_encoder_kv_first_x3w8 added, kv_from_prev = 2 accepted by the
+ * x3w8 layer entry points: additive, but a binding that names the new symbol needs a library that has it). */
+#define OPHIP_ABI_VERSION 3
 int ophip_abi_version(void);
 /* host string: 16 hex digits of the sha256 over the sources this library was built from (the profiles/ pmc summaries record it;
  * bench.py quotes committed counter values only when they were taken on the running build) */
@@ -101,6 +102,13 @@ int ophip_encoder_layer_x3w8_frag(const float* x3d, const float* x2d, float* y3d
 int ophip_encoder_layer_x3w8(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
                              const void* wpack, const void* wpack_next, int is_cross, int kv_from_prev, int slot,
                              void* workspace, void* stream);
+/* The K / V half of a layer that projects its own K, V (the FIRST layer of a frame; transformer.py:65-94 k_proj / v_proj +
+ * linear_attention.py:49-57): K, V projections of both streams -> phi(K)^T V / Ksum slabs -> their fixed-order sum into the workspace.
+ * It reads the layer's input rows only, so a frame pipeline issues it as soon as those exist -- beside whatever the previous frame
+ * still runs -- and then calls ophip_encoder_layer_x3w8{,_frag,_masked} with kv_from_prev = 2 ("the summed block is there": same wpack,
+ * slot, workspace).  mask2d: NULL, or the layer's query mask.  Bit-identical to the one-call layer (same kernels in the same order). */
+int ophip_encoder_kv_first_x3w8(const float* x3d, const float* x2d, int B, int L3d, int L2d, const void* wpack, int slot,
+                                void* workspace, const unsigned char* mask2d, void* stream);
 
 /* a7 + a8 -- CoarseMatching.forward + get_coarse_match, inference branch
  * (utils/coarse_matching.py:76-123, :125-242, mask_border :10-20).

@@ -451,13 +451,17 @@ extern "C" size_t ophip_encoder_x3w8_workspace_bytes(int B, int L3d, int L2d) {
 extern "C" size_t ophip_encoder_x3w8_wpack_bytes(void) { return (size_t)NW * (MAIN_FRAGS + KV_FRAGS) * 1024 + 4 * C * 4; }
 
 namespace {
+// kv_mode: 0 = this call projects its own K, V (kv_reduce), sums the slabs (kv_sum) and applies; 1 = the slabs are there (the previous
+// layer's fused tail wrote them): kv_sum + apply; 2 = the summed K^T V / Ksum block is there (ophip_encoder_kv_first_x3w8 ran): apply only.
+// only_kv: stop after kv_reduce + kv_sum (the body of ophip_encoder_kv_first_x3w8; y3d / y2d / wpack_next unused).
 int layer_x3w8(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
-               const void* wpack, const void* wpack_next, int is_cross, int kv_from_prev, int slot,
-               void* workspace, void* stream_, void* frag3d, void* frag2d, const unsigned char* mask2d = nullptr) {
-    if (!x3d || !x2d || !y3d || !y2d || !wpack || !workspace) return ophip_bad_arg(__func__, "null pointer");
+               const void* wpack, const void* wpack_next, int is_cross, int kv_mode, int slot,
+               void* workspace, void* stream_, void* frag3d, void* frag2d, const unsigned char* mask2d = nullptr, bool only_kv = false) {
+    if (!x3d || !x2d || !wpack || !workspace || (!only_kv && (!y3d || !y2d))) return ophip_bad_arg(__func__, "null pointer");
     if (B < 1 || L3d < 1 || L2d < 1) return ophip_bad_arg(__func__, "B, L3d, L2d must be >= 1");
     if (slot != 0 && slot != 1) return ophip_bad_arg(__func__, "slot must be 0 or 1");
-    if (x3d == y3d || x2d == y2d) return ophip_bad_arg(__func__, "in-place layer is not supported (cross layers read the pre-update streams)");
+    if (kv_mode < 0 || kv_mode > 2) return ophip_bad_arg(__func__, "kv_from_prev must be 0, 1 or 2");
+    if (!only_kv && (x3d == y3d || x2d == y2d)) return ophip_bad_arg(__func__, "in-place layer is not supported (cross layers read the pre-update streams)");
     if (reinterpret_cast<uintptr_t>(wpack) & 15) return ophip_bad_arg(__func__, "wpack must be 16-byte aligned");
     hipStream_t stream = (hipStream_t)stream_;
     const int t3 = (L3d + TOK - 1) / TOK, t2 = (L2d + TOK - 1) / TOK;
@@ -489,7 +493,7 @@ int layer_x3w8(const float* x3d, const float* x2d, float* y3d, float* y2d, int B
     aa.frag[0] = static_cast<char*>(frag3d); aa.frag[1] = static_cast<char*>(frag2d);
     aa.frag_rows[0] = (L3d + 127) / 128 * 128; aa.frag_rows[1] = (L2d + 127) / 128 * 128;
     aa.mask2d = mask2d;
-    if (!kv_from_prev) {
+    if (kv_mode == 0) {
         EncW8Args ka = aa;
         ka.kv[0] = ka.kv[1] = nullptr;
         ka.frag[0] = ka.frag[1] = nullptr;
@@ -500,11 +504,14 @@ int layer_x3w8(const float* x3d, const float* x2d, float* y3d, float* y2d, int B
         else { OPHIP_LAUNCH("kv_reduce", stream, enc_x3w8_kernel<true>, dim3(t3 + t2, B), dim3(512), LDS_BYTES, stream, ka); }
         OPHIP_CHECK_LAUNCH();
     }
-    KvSumArgs sa;
-    sa.partial = partial; sa.kv = kv; sa.tiles[0] = t3; sa.tiles[1] = t2;
-    static_assert(KV_PART_FLOATS % (4 * KVS_L) == 0, "a slab is a whole number of 64-float chunks");
-    OPHIP_LAUNCH("kv_sum", stream, kv_sum_w8_kernel, dim3(KV_PART_FLOATS / (4 * KVS_L), 2 * B), dim3(KVS_G * KVS_L), 0, stream, sa);
-    OPHIP_CHECK_LAUNCH();
+    if (kv_mode != 2) {
+        KvSumArgs sa;
+        sa.partial = partial; sa.kv = kv; sa.tiles[0] = t3; sa.tiles[1] = t2;
+        static_assert(KV_PART_FLOATS % (4 * KVS_L) == 0, "a slab is a whole number of 64-float chunks");
+        OPHIP_LAUNCH("kv_sum", stream, kv_sum_w8_kernel, dim3(KV_PART_FLOATS / (4 * KVS_L), 2 * B), dim3(KVS_G * KVS_L), 0, stream, sa);
+        OPHIP_CHECK_LAUNCH();
+    }
+    if (only_kv) return 0;
     aa.kv[0] = kv + (is_cross ? KV_BLOCK_BYTES : 0);
     aa.kv[1] = kv + (is_cross ? 0 : KV_BLOCK_BYTES);
     aa.wkv = nullptr;
@@ -540,4 +547,14 @@ extern "C" int ophip_encoder_layer_x3w8_masked(const float* x3d, const float* x2
                                                void* workspace, const unsigned char* mask2d, void* stream) {
     if (!mask2d) return ophip_bad_arg(__func__, "null mask (use ophip_encoder_layer_x3w8)");
     return layer_x3w8(x3d, x2d, y3d, y2d, B, L3d, L2d, wpack, wpack_next, is_cross, kv_from_prev, slot, workspace, stream, nullptr, nullptr, mask2d);
+}
+
+// The K / V half of a layer that projects its own K, V (the first layer of a frame: nothing wrote its slabs): K, V projections of both
+// streams -> phi(K)^T V / Ksum slabs (kv_reduce) -> their fixed-order sum (kv_sum) into the workspace's K^T V block.  It reads the layer's
+// INPUT rows only, so a pipeline may issue it as soon as those exist -- before, and beside, whatever the previous frame still runs --
+// and then call ophip_encoder_layer_x3w8{,_frag,_masked} with kv_from_prev = 2 (same wpack, slot, workspace; mask2d NULL or the layer's mask).
+// Bit-identical to the one-call layer (same kernels, same order).  Reference: transformer.py:65-94 (k_proj, v_proj), linear_attention.py:49-57.
+extern "C" int ophip_encoder_kv_first_x3w8(const float* x3d, const float* x2d, int B, int L3d, int L2d, const void* wpack, int slot,
+                                           void* workspace, const unsigned char* mask2d, void* stream) {
+    return layer_x3w8(x3d, x2d, nullptr, nullptr, B, L3d, L2d, wpack, nullptr, 0, 0, slot, workspace, stream, nullptr, nullptr, mask2d, true);
 }

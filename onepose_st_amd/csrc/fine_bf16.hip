@@ -46,117 +46,144 @@ struct FineBArgs {
 // exactly one source set by layer kind -- "self": window -> window, 3D -> itself; "cross": window -> 3D, 3D -> window
 // (transformer.py:148-159 on the fine streams) -- and `qt` (Q of feature tile ft as D[feature][token]), `kt`, `vt` (K, V as D[token][feature])
 // are this wave's accumulators.  Returns the message tile D[feature][token] (linear_attention.py:29-61, v_length 25 resp. 1).
-//   window set: phi(K)^T V and Ksum tiles (two 16-wide heads per 32-wide tile, block-diagonal) and phi(Q) KV on the matrix pipe, split-bf16;
-//   3D set: ONE source token, so KV = phi(k3)^T v3 has rank one and the message is v3 * a / (a + eps) with a[token][head] = phi(q) . phi(k3):
-//   16 multiply-adds per lane in f32 (k3, v3 = row 25 of the K / V tiles, handed from their lanes to every lane through a 256-byte LDS
-//   strip of this wave) instead of two more KV tiles, their fragment conversions and 18 matrix instructions per match and layer.
+//
+// Round 4: the two small products of the window set run on the EXACT-f32 matrix instruction (v_mfma_f32_32x32x2_f32: one f32 register per
+// operand and lane, k = 2 per instruction) straight from the accumulators -- register t of a D[token][feature] tile holds token
+// acc_row(t, h) of feature r, which is exactly A[i = r][k = h] / B[k = h][j = r] of that instruction, so
+//     KV[f'][f]     = sum_t mfma(phi(K)[t], V[t])          (13 instructions: tokens 0 .. 24; rows 25 .. 31 never enter)
+//     num[f][tok]   = sum_t mfma(KV[t], phi(Q)[t])         (t < 8: rows f' of the tile's first head, t >= 8: of its second)
+// need no bf16 split, no fragment conversion and no block-diagonal mask: the two heads of a 32-wide tile go to two accumulators and the
+// message takes registers 0..7 (rows f < 16) from the first and 8..15 from the second.  The kernel is bound by vector-ALU issue
+// (profiles/r03_stamps_fine_pair.txt, DESIGN.md section 4: ~640 vector instructions per attention block, 232 of them conversions and
+// masks), the matrix pipe is half idle: 29 f32 instructions (1 856 pipe cycles) replace 36 bf16 ones (1 152) and ~400 vector instructions.
+// The denominator phi(Q).Ksum is 16 f32 multiply-adds per lane (Ksum = column sums of phi(K), handed to every lane through the wave's LDS
+// strip like k3 / v3 below) -- one reciprocal per head and token instead of one per element.  The reference's v / v_length ... * v_length
+// (an fp16 overflow guard, linear_attention.py:52,59) cancels in f32 and is not applied.
+//   3D set: ONE source token, so KV = phi(k3)^T v3 has rank one and the message is v3 * a / (a + eps) with a[token][head] = phi(q) . phi(k3).
 template <int NS>
 __device__ __forceinline__ f32x16 attend_match(f32x16& qt, const f32x16& kt, const f32x16& vt, bool cross, float* strip, int lane,
-                                               const bf16x8& ones, const bf16x8& zeros) {
+                                               const bf16x8&, const bf16x8&) {
+#pragma clang fp contract(off)                    // every fused multiply-add below is written out: the one-match and the pair kernel stay bit-identical
     const int r = lane & 31, h = lane >> 5;
     const bool is3d = r == TOK3D;                 // on the token (lane) axis of D[feature][token] tiles
     const bool use_w = cross ? is3d : !is3d;      // this token attends to the window set (else: the 3D token)
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) qt[reg] = elu_plus_one_fast(qt[reg]);
-    // row 25 of the K / V tiles: register 13 of lanes 0..31 (acc_row(13, 0) == 25), one feature per lane
-    static_assert(acc_row(13, 0) == TOK3D, "the 3D token's row of a D[token][feature] tile");
+    // phi(K) of the window rows: registers 0..11 hold rows <= 23 in both lane halves, register 12 holds row 24 (h = 0) / 28 (h = 1)
+    static_assert(acc_row(11, 1) == 23 && acc_row(12, 0) == 24 && acc_row(13, 0) == TOK3D, "token rows of a D[token][feature] tile");
+    float kw[13];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) kw[t] = elu_plus_one_fast(kt[t]);
+    kw[12] = h == 0 ? elu_plus_one_fast(kt[12]) : 0.f;
+    // strip (96 floats of this wave): [0, 32) phi(k3), [32, 64) v3 (row 25 = register 13 of lanes 0..31, one feature per lane), [64, 96) Ksum
     if (h == 0) {
         strip[r] = elu_plus_one_fast(kt[13]);
         strip[32 + r] = vt[13];
     }
-    // window set on the matrix pipe
-    auto f_kw = [&](int reg, float v) { return acc_row(reg, h) < WIN ? elu_plus_one_fast(v) : 0.f; };
-    auto f_vw = [&](int reg, float v) { return acc_row(reg, h) < WIN ? v * 0.04f : 0.f; };      // values / v_length (25)
-    const auto block_diag = [&](f32x16& t) {          // two 16-wide heads per 32-wide tile
+    f32x16 kvw = zero16();
+    float ks = 0.f;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg)
-            if ((acc_row(reg, h) >> 4) != (r >> 4)) t[reg] = 0.f;
-    };
-    f32x16 num = zero16(), den = zero16();
-    {
-        f32x16 kvw = zero16(), ksw = zero16();
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            bf16x8 wh, wl2, vh, vl;
-            acc_frag_map<NS>(kt, st, f_kw, wh, wl2);
-            acc_frag_map<NS>(vt, st, f_vw, vh, vl);
-            kvw = mma_bf16<NS>(wh, wl2, vh, vl, kvw);
-            ksw = mma_bf16<NS>(wh, wl2, ones, zeros, ksw);
-        }
-        block_diag(kvw);
-        block_diag(ksw);
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            bf16x8 qh, ql, ah, al;
-            acc_frag<NS>(qt, st, qh, ql);
-            acc_frag<NS>(kvw, st, ah, al); num = mma_bf16<NS>(ah, al, qh, ql, num);
-            acc_frag<NS>(ksw, st, ah, al); den = mma_bf16<NS>(ah, al, qh, ql, den);
-        }
+    for (int t = 0; t < 13; ++t) {
+        kvw = __builtin_amdgcn_mfma_f32_32x32x2f32(kw[t], vt[t], kvw, 0, 0, 0);
+        ks += kw[t];
     }
-    // 3D set: this lane's 16 features of phi(k3) and v3 (features acc_row(reg, h) = 8 (reg >> 2) + 4 h + (reg & 3): four 16-byte reads each)
+    ks += __shfl_xor(ks, 32, 64);
+    if (h == 0) strip[64 + r] = ks;
+    f32x16 n0 = zero16(), n1 = zero16();
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {                 // (two independent chains: the second head's instruction issues behind the first's)
+        n0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kvw[t], qt[t], n0, 0, 0, 0);
+        n1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kvw[8 + t], qt[8 + t], n1, 0, 0, 0);
+    }
+    // this lane's 16 features (acc_row(reg, h) = 8 (reg >> 2) + 4 h + (reg & 3): four 16-byte reads per table) of Ksum, phi(k3), v3
     __builtin_amdgcn_wave_barrier();              // (LDS operations of one wave complete in order: only the compiler needs the fence)
-    float a0 = 0.f, a1 = 0.f;
+    float d0 = 0.f, d1 = 0.f, a0 = 0.f, a1 = 0.f;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const f32x4 k3 = *reinterpret_cast<const f32x4*>(strip + 8 * g + 4 * h);
+        const f32x4 kq = *reinterpret_cast<const f32x4*>(strip + 64 + 8 * g + 4 * h);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (g < 2) a0 += qt[4 * g + j] * k3[j];           // features 0..15 of the tile: its first head
-            else a1 += qt[4 * g + j] * k3[j];
+            if (g < 2) { a0 = __builtin_fmaf(qt[4 * g + j], k3[j], a0); d0 = __builtin_fmaf(qt[4 * g + j], kq[j], d0); }      // features 0..15 of the tile: its first head
+            else { a1 = __builtin_fmaf(qt[4 * g + j], k3[j], a1); d1 = __builtin_fmaf(qt[4 * g + j], kq[j], d1); }
         }
     }
     a0 += __shfl_xor(a0, 32, 64);
     a1 += __shfl_xor(a1, 32, 64);
-    const float z0 = a0 * rcp_fast(a0 + 1e-6f), z1 = a1 * rcp_fast(a1 + 1e-6f);
+    d0 += __shfl_xor(d0, 32, 64);
+    d1 += __shfl_xor(d1, 32, 64);
+    // per token and head: Z of the set this token attends to (use_w: 1 / (phi(q).Ksum + eps) on the matrix result; else a / (a + eps) on v3)
+    const float z0 = use_w ? rcp_fast(d0 + 1e-6f) : a0 * rcp_fast(a0 + 1e-6f);
+    const float z1 = use_w ? rcp_fast(d1 + 1e-6f) : a1 * rcp_fast(a1 + 1e-6f);
+    f32x16 out;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const f32x4 v3 = *reinterpret_cast<const f32x4*>(strip + 32 + 8 * g + 4 * h);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int reg = 4 * g + j;
-            const float m3 = v3[j] * (g < 2 ? z0 : z1);
-            num[reg] = use_w ? num[reg] * rcp_fast(den[reg] + 1e-6f) * 25.0f : m3;
+            const float nm = g < 2 ? n0[reg] : n1[reg];
+            out[reg] = (use_w ? nm : v3[j]) * (g < 2 ? z0 : z1);
         }
     }
     __builtin_amdgcn_wave_barrier();              // the strip is rewritten by this wave's next match
-    return num;
+    return out;
 }
 
 // f32 staging image [64][128], 16-byte chunks swizzled like the planes (32 chunks per row)
 __device__ __forceinline__ int stage_off(int row, int chunk) { return row * (CF * 4) + ((chunk ^ (row & 15)) << 4); }
 
 // LayerNorm over the 128 features of a token, spread over the 4 feature-tile waves of its match (wave (tt, ft) holds
-// features 32 ft .. 32 ft + 31 of tokens 32 tt .. 32 tt + 31 as a D[feature][token] accumulator).  Two-pass; partial
-// sums cross waves through `scratch` ([2][4][64] floats).  Contains 2 workgroup barriers.
+// features 32 ft .. 32 ft + 31 of tokens 32 tt .. 32 tt + 31 as a D[feature][token] accumulator).  ONE workgroup barrier: every wave
+// takes the two-pass moments of its own 32 features (sum, then squared deviations from ITS mean), the four (sum, M2) pairs cross waves
+// through `scratch` ([2][4][64] floats) and are merged by Chan's formula -- the accuracy of the two-pass form without its second exchange.
+__device__ __forceinline__ void ln_local_moments(const f32x16& m, float& s, float& q) {
+#pragma clang fp contract(off)
+    s = 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) s += m[reg];
+    s += __shfl_xor(s, 32, 64);
+    const float mw = s * (1.0f / 32.0f);
+    q = 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const float d = m[reg] - mw;
+        q = __builtin_fmaf(d, d, q);
+    }
+    q += __shfl_xor(q, 32, 64);
+}
+__device__ __forceinline__ float ln_apply(float x, float mean, float rstd, float g, float b) {
+#pragma clang fp contract(off)
+    return __builtin_fmaf((x - mean) * rstd, g, b);
+}
+// merged mean and 1 / sqrt(var + eps) of token `tok` from the four waves' (sum, M2) in scratch
+__device__ __forceinline__ void ln_merge(const float* scratch, int tok, float& mean, float& rstd) {
+#pragma clang fp contract(off)
+    const float s0 = scratch[tok], s1 = scratch[64 + tok], s2 = scratch[128 + tok], s3 = scratch[192 + tok];
+    mean = ((s0 + s1) + (s2 + s3)) * (1.0f / CF);
+    const float e0 = __builtin_fmaf(s0, 1.0f / 32.0f, -mean), e1 = __builtin_fmaf(s1, 1.0f / 32.0f, -mean);
+    const float e2 = __builtin_fmaf(s2, 1.0f / 32.0f, -mean), e3 = __builtin_fmaf(s3, 1.0f / 32.0f, -mean);
+    const float dev2 = __builtin_fmaf(e0, e0, e1 * e1) + __builtin_fmaf(e2, e2, e3 * e3);
+    const float m2 = __builtin_fmaf(32.0f, dev2, (scratch[256 + tok] + scratch[320 + tok]) + (scratch[384 + tok] + scratch[448 + tok]));
+    rstd = 1.0f / sqrtf(__builtin_fmaf(m2, 1.0f / CF, 1e-5f));
+}
 __device__ __forceinline__ void layernorm_featrow128(f32x16& m, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* scratch, int ft, int tt, int lane) {
     const int r = lane & 31, h = lane >> 5;
     const int tok = 32 * tt + r;
-    float s = 0.f;
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) s += m[reg];
-    s += __shfl_xor(s, 32, 64);
-    if (h == 0) scratch[ft * 64 + tok] = s;
+    float s, q;
+    ln_local_moments(m, s, q);
+    if (h == 0) { scratch[ft * 64 + tok] = s; scratch[256 + ft * 64 + tok] = q; }
     __syncthreads();
-    const float mean = ((scratch[tok] + scratch[64 + tok]) + (scratch[128 + tok] + scratch[192 + tok])) * (1.0f / CF);
-    float q = 0.f;
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const float d = m[reg] - mean;
-        q += d * d;
-    }
-    q += __shfl_xor(q, 32, 64);
-    if (h == 0) scratch[256 + ft * 64 + tok] = q;
-    __syncthreads();
-    const float var = ((scratch[256 + tok] + scratch[320 + tok]) + (scratch[384 + tok] + scratch[448 + tok])) * (1.0f / CF);
-    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    float mean, rstd;
+    ln_merge(scratch, tok, mean, rstd);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int f0 = 32 * ft + 8 * g + 4 * h;
         const f32x4 gv = *reinterpret_cast<const f32x4*>(gamma + f0);
         const f32x4 bv = *reinterpret_cast<const f32x4*>(beta + f0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) m[4 * g + j] = (m[4 * g + j] - mean) * rstd * gv[j] + bv[j];
+        for (int j = 0; j < 4; ++j) m[4 * g + j] = ln_apply(m[4 * g + j], mean, rstd, gv[j], bv[j]);
     }
 }
 
@@ -314,7 +341,7 @@ __global__ __launch_bounds__(NM * 256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_refi
         rm.fill(w_hi + OM + (size_t)ft * TS + lane, w_lo + OM + (size_t)ft * TS + lane, TS);
         // ---- KV / Ksum of the window set, the 3D token's rank-one message, phi(Q) KV: all in registers (attend_match) ------
         {
-            f32x16 num = attend_match<NS>(q[0][0], kv_[0][0], kv_[1][0], cross, scratch + 64 * (4 * tt + ft), lane, ones, zeros);
+            f32x16 num = attend_match<NS>(q[0][0], kv_[0][0], kv_[1][0], cross, scratch + 96 * (4 * tt + ft), lane, ones, zeros);
             store_featrow_acc<NS>(num, YH, YL, ROWB, 32 * ft, 32 * tt, lane);
         }
         __syncthreads();
@@ -425,32 +452,16 @@ __device__ __forceinline__ int opaque(int v) {
 }
 
 // LayerNorm over the 128 features of the tokens of BOTH matches of a pair workgroup (wave ft holds features 32 ft .. 32 ft + 31
-// of tokens 0 .. 63 as two D[feature][token] accumulators).  Two-pass; `scratch` = [2][4][64] floats of its own.  2 barriers.
+// of tokens 0 .. 63 as two D[feature][token] accumulators).  Same arithmetic as layernorm_featrow128 (the two kernels stay
+// bit-identical), `scratch` = [2][4][64] floats of its own.  1 barrier.
 __device__ __forceinline__ void layernorm_pair(f32x16 (&m)[1][2], const float* __restrict__ gamma, const float* __restrict__ beta,
                                                float* scratch, int ft, int lane) {
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
-        float s = 0.f;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) s += m[0][tt][reg];
-        s += __shfl_xor(s, 32, 64);
-        if (h == 0) scratch[ft * 64 + 32 * tt + r] = s;
-    }
-    __syncthreads();
-    float mean[2];
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-        const int tok = 32 * tt + r;
-        mean[tt] = ((scratch[tok] + scratch[64 + tok]) + (scratch[128 + tok] + scratch[192 + tok])) * (1.0f / CF);
-        float q = 0.f;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const float d = m[0][tt][reg] - mean[tt];
-            q += d * d;
-        }
-        q += __shfl_xor(q, 32, 64);
-        if (h == 0) scratch[256 + ft * 64 + tok] = q;
+        float s, q;
+        ln_local_moments(m[0][tt], s, q);
+        if (h == 0) { scratch[ft * 64 + 32 * tt + r] = s; scratch[256 + ft * 64 + 32 * tt + r] = q; }
     }
     __syncthreads();
     f32x4 gv[4], bv[4];
@@ -462,13 +473,12 @@ __device__ __forceinline__ void layernorm_pair(f32x16 (&m)[1][2], const float* _
     }
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
-        const int tok = 32 * tt + r;
-        const float var = ((scratch[256 + tok] + scratch[320 + tok]) + (scratch[384 + tok] + scratch[448 + tok])) * (1.0f / CF);
-        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        float mean, rstd;
+        ln_merge(scratch, 32 * tt + r, mean, rstd);
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) m[0][tt][4 * g + j] = (m[0][tt][4 * g + j] - mean[tt]) * rstd * gv[g][j] + bv[g][j];
+            for (int j = 0; j < 4; ++j) m[0][tt][4 * g + j] = ln_apply(m[0][tt][4 * g + j], mean, rstd, gv[g][j], bv[g][j]);
     }
 }
 
@@ -636,7 +646,7 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_pair_kern
             gemm_bf16_ring<2, 1, NS, false, KB, 2>(kv_, rkv, w_hi + OKV + (size_t)(2 * ft) * TS + lk_, w_lo + OKV + (size_t)(2 * ft) * TS + lk_, TS,
                                                    XH + 32 * tt * ROWB, XL + 32 * tt * ROWB, ROWB, 0, lane);
             __builtin_amdgcn_sched_barrier(0);
-            f32x16 num = attend_match<NS>(q[0][tt], kv_[0][0], kv_[1][0], cross, scratch + 64 * ft, lane, ones, zeros);
+            f32x16 num = attend_match<NS>(q[0][tt], kv_[0][0], kv_[1][0], cross, scratch + 96 * ft, lane, ones, zeros);
             store_featrow_acc<NS>(num, YH, YL, ROWB, 32 * ft, 32 * tt, lane);
             __builtin_amdgcn_sched_barrier(0);
             if (tt == 0) rkv.fill(w_hi + OKV + (size_t)(2 * ft) * TS + lk_, w_lo + OKV + (size_t)(2 * ft) * TS + lk_, TS);      // the second match's K|V weights

@@ -104,6 +104,18 @@ int launch_fine_job(int dev, Slot& s, hipEvent_t after = nullptr) {
 }
 
 // OPHIP_FRAME_DEFER_FINE=0: the fine stage follows its own frame's selection at once (the round-2 order)
+// OPHIP_FRAME_KV_FIRST: where the first encoder layer's K / V half is issued (see ophip_frame_enqueue_padded): "prep" (1), "main" (2, default), "off" (0)
+int kv_first_mode() {
+    static const int mode = [] {
+        const char* e = getenv("OPHIP_FRAME_KV_FIRST");
+        if (!e || !e[0]) return 2;
+        if (e[0] == 'p' || e[0] == '1') return 1;
+        if (e[0] == 'm' || e[0] == '2') return 2;
+        return 0;
+    }();
+    return mode;
+}
+
 bool defer_fine_enabled() {
     static const bool on = [] { const char* e = getenv("OPHIP_FRAME_DEFER_FINE"); return !(e && e[0] == '0'); }();
     return on;
@@ -237,10 +249,20 @@ extern "C" int ophip_frame_enqueue_padded(const ophip_frame_desc* d, const ophip
             FR_CHECK(ophip_transpose_cl(desc_c, x3d, B, 256, N, sin));
         }
     }
+    // The first encoder layer's K / V half (kv_reduce + kv_sum: ~20 us of the frame at c2) reads this frame's input rows only.  It used to
+    // be the first thing BEHIND the wait for the previous frame's fine stage, i.e. on the critical path of every frame; it now goes out
+    // ahead of that wait: "prep" = behind the input kernels on their stream (beside whatever runs when they run), "main" = on the
+    // compute stream in front of the wait (in the tail of the previous fine stage), "off" = inside the layer call as before.
+    const int kv_first = kv_first_mode();
+    const bool kv_hoisted = kv_first != 0 && d->n_coarse > 0;
+    if (kv_hoisted && kv_first == 1 && s_prep)
+        FR_CHECK(ophip_encoder_kv_first_x3w8(x3d, x2d, B, N, M, d->w_coarse[0], 0, blob + L->enc_ws, qmask, s_prep));
     if (s_prep) {
         FR_HIP(hipEventRecord(slot->prep_done, s_prep), "hipEventRecord(prep)");
         FR_HIP(hipStreamWaitEvent(s_main, slot->prep_done, 0), "hipStreamWaitEvent(prep)");
     }
+    if (kv_hoisted && !(kv_first == 1 && s_prep))
+        FR_CHECK(ophip_encoder_kv_first_x3w8(x3d, x2d, B, N, M, d->w_coarse[0], 0, blob + L->enc_ws, qmask, s_main));
     // ---- a4-a6: coarse encoder; attn_apply never shares the chip with the previous frame's fine stage -------------------------
     if (prev_fine) FR_HIP(hipStreamWaitEvent(s_main, prev_fine, 0), "hipStreamWaitEvent(previous fine)");      // (a no-op when it ran on s_main)
     float *y3d = F(L->y3d), *y2d = F(L->y2d), *y2 = y2d, *x2 = x2d;
@@ -253,13 +275,13 @@ extern "C" int ophip_frame_enqueue_padded(const ophip_frame_desc* d, const ophip
     for (int li = 0; li < d->n_coarse; ++li) {
         const void* nxt = li + 1 < d->n_coarse ? d->w_coarse[li + 1] : nullptr;
         if (qmask)      // padded query cells (query_image_mask): the masked layer; the similarity stage then derives its operand fragments itself
-            FR_CHECK(ophip_encoder_layer_x3w8_masked(x3, x2, y3, y2, B, N, M, d->w_coarse[li], nxt, (d->coarse_cross_bits >> li) & 1, li > 0 ? 1 : 0, li & 1,
+            FR_CHECK(ophip_encoder_layer_x3w8_masked(x3, x2, y3, y2, B, N, M, d->w_coarse[li], nxt, (d->coarse_cross_bits >> li) & 1, li > 0 ? 1 : (kv_hoisted ? 2 : 0), li & 1,
                                                      blob + L->enc_ws, qmask, s_main));
         else if (li + 1 == d->n_coarse)
-            FR_CHECK(ophip_encoder_layer_x3w8_frag(x3, x2, y3, y2, B, N, M, d->w_coarse[li], nxt, (d->coarse_cross_bits >> li) & 1, li > 0 ? 1 : 0, li & 1,
+            FR_CHECK(ophip_encoder_layer_x3w8_frag(x3, x2, y3, y2, B, N, M, d->w_coarse[li], nxt, (d->coarse_cross_bits >> li) & 1, li > 0 ? 1 : (kv_hoisted ? 2 : 0), li & 1,
                                                    blob + L->enc_ws, planes3d, planes2d, s_main));
         else
-        FR_CHECK(ophip_encoder_layer_x3w8(x3, x2, y3, y2, B, N, M, d->w_coarse[li], nxt, (d->coarse_cross_bits >> li) & 1, li > 0 ? 1 : 0, li & 1,
+        FR_CHECK(ophip_encoder_layer_x3w8(x3, x2, y3, y2, B, N, M, d->w_coarse[li], nxt, (d->coarse_cross_bits >> li) & 1, li > 0 ? 1 : (kv_hoisted ? 2 : 0), li & 1,
                                           blob + L->enc_ws, s_main));
         float* nx3 = y3;
         y3 = li == 0 ? z3d : x3;

@@ -112,10 +112,17 @@ __global__ __launch_bounds__(256) void kpt_encode_kernel(KptArgs p) {
     }
     // descriptor tile: read coalesced along n, written transposed (one tile instead of a channel-major and a point-major one: 65 KB
     // of LDS per workgroup instead of 99, so that the kernel fits beside a fine-stage workgroup on a CU)
+    // (all 32 loads of a thread are issued before the first LDS write: as a rolled loop the compiler waited for each load in turn --
+    //  32 dependent HBM round trips, 25 of the kernel's 31 us at c2)
     const float* dsc = p.desc + (size_t)b * p.dbs;
-    for (int i = tid; i < KD * 32; i += 256) {
-        const int c = i >> 5, n = i & 31;
-        Ot[n * LO + c] = (n0 + n < p.N) ? dsc[(size_t)c * p.N + n0 + n] : 0.f;
+    {
+        float dv[KD * 32 / 256];
+        const int n = tid & 31, cb = tid >> 5;
+        const bool live = n0 + n < p.N;
+#pragma unroll
+        for (int k = 0; k < KD * 32 / 256; ++k) dv[k] = live ? dsc[(size_t)(cb + 8 * k) * p.N + n0 + n] : 0.f;
+#pragma unroll
+        for (int k = 0; k < KD * 32 / 256; ++k) Ot[n * LO + cb + 8 * k] = dv[k];
     }
     __syncthreads();
     // 3 -> 32

@@ -19,6 +19,20 @@
 #pragma once
 #include "tile.h"
 
+// Wave priority around the matrix loops of the ring GEMMs (OPHIP_GEMM_PRIO=1): two independent workgroups share every SIMD of a CU in the
+// fine stage; with the GEMM wave preferred by the issue arbiter its matrix instructions go out back to back and the partner's vector
+// work fills the issue slots between them, instead of the older wave winning whatever it runs.
+#ifndef OPHIP_GEMM_PRIO
+#define OPHIP_GEMM_PRIO 0
+#endif
+#if OPHIP_GEMM_PRIO
+#define OPHIP_GEMM_PRIO_UP() __builtin_amdgcn_s_setprio(OPHIP_GEMM_PRIO)
+#define OPHIP_GEMM_PRIO_DOWN() __builtin_amdgcn_s_setprio(0)
+#else
+#define OPHIP_GEMM_PRIO_UP() do {} while (0)
+#define OPHIP_GEMM_PRIO_DOWN() do {} while (0)
+#endif
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -128,6 +142,7 @@ __device__ __forceinline__ void gemm_bf16_ring(f32x16 (&acc)[NT][TT], WRing<NT, 
         }
     };
     read_x(0, 0);
+    OPHIP_GEMM_PRIO_UP();
     for (int kb0 = 0; kb0 < KBLOCKS; kb0 += PD) {
 #pragma unroll
         for (int p = 0; p < PD; ++p) {
@@ -151,6 +166,7 @@ __device__ __forceinline__ void gemm_bf16_ring(f32x16 (&acc)[NT][TT], WRing<NT, 
             __builtin_amdgcn_sched_barrier(0);      // keep the refill here (see tile.h)
         }
     }
+    OPHIP_GEMM_PRIO_DOWN();
 }
 
 // Same, with the K range split in two halves read from two plane pairs (the [x, msg] concatenation feeding the MLP):
@@ -177,6 +193,7 @@ __device__ __forceinline__ void gemm_bf16_ring_cat(f32x16 (&acc)[NT][TT], WRing<
         }
     };
     read_x(0, 0);
+    OPHIP_GEMM_PRIO_UP();
     for (int kb0 = 0; kb0 < KBLOCKS; kb0 += PD) {
 #pragma unroll
         for (int p = 0; p < PD; ++p) {
@@ -197,6 +214,7 @@ __device__ __forceinline__ void gemm_bf16_ring_cat(f32x16 (&acc)[NT][TT], WRing<
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    OPHIP_GEMM_PRIO_DOWN();
 }
 
 template <int NT, int TT, int NS, bool W_IS_A, int KBLOCKS, int PD>

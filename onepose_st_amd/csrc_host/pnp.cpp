@@ -826,7 +826,12 @@ struct Ransac {
     int needed_for(int cnt) const {
         const double w = (double)cnt / n, pw = std::pow(w, (double)sample_size());
         if (pw > 1.0 - 1e-12) return 1;
-        if (pw > 1e-12) return (int)std::ceil(std::log(1.0 - confidence) / std::log(1.0 - pw));
+        if (pw > 1e-12) {
+            // (clamped BEFORE the conversion: a first hypothesis with a handful of inliers asks for billions of trials, which as an int was
+            //  negative -- the adaptive branch then stopped at once and a frame with 40 % outliers came back without a pose)
+            const double nd = std::ceil(std::log(1.0 - confidence) / std::log(1.0 - pw));
+            return nd < (double)max_iters ? (int)nd : max_iters;
+        }
         return max_iters;
     }
 
@@ -1238,7 +1243,11 @@ extern "C" int oppnp_estimate_affine2d(const float* src, const float* dst, int n
             best = cnt;
             best_mask = mask;
             const double w = (double)cnt / n, pw = w * w * w;
-            needed = pw > 1.0 - 1e-12 ? 1 : (pw > 1e-12 ? (int)std::ceil(std::log(1.0 - confidence) / std::log(1.0 - pw)) : max_iters);
+            if (pw > 1.0 - 1e-12) needed = 1;
+            else if (pw > 1e-12) {
+                const double nd = std::ceil(std::log(1.0 - confidence) / std::log(1.0 - pw));      // clamped before the conversion (see Ransac::needed_for)
+                needed = nd < (double)max_iters ? (int)nd : max_iters;
+            } else needed = max_iters;
         }
     }
     if (best < 3) return 1;

@@ -592,7 +592,7 @@ class OnePosePlus_model(nn.Module):
         if fkey not in self._fine_streams:
             if len(self._fine_streams) >= 16:
                 self._fine_streams.pop(next(iter(self._fine_streams)))
-            self._fine_streams[fkey] = [torch.cuda.Stream(device=dev), None]
+            self._fine_streams[fkey] = [torch.cuda.Stream(device=dev, priority=int(os.environ.get("OPHIP_FINE_PRIO", "0"))), None]
         sfine = self._fine_streams[fkey][0]
         sprep = self._side_stream(self._prep_streams, fkey, dev) if inputs_ready else None
         scopy = self._side_stream(PendingFrame._copy_streams, (dev, main.cuda_stream), dev)

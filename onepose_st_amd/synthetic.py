@@ -112,7 +112,8 @@ def _rotation(gen):
 
 
 def make_synthetic_inputs(state_dict: dict, n_points: int = 1000, image_hw=(240, 320), n_plant: int = 600,
-                          seed: int = 1, config: dict | None = None, noise: float = 0.1, frame: int = 0) -> dict:
+                          seed: int = 1, config: dict | None = None, noise: float = 0.1, frame: int = 0,
+                          noise_hi: float | None = None, wrong_frac: float = 0.0) -> dict:
     """Feature-boundary inputs for one frame (B=1).
 
     Returns a dict with the model inputs ``keypoints3d [1,N,3]``, ``descriptors3d_db
@@ -126,6 +127,12 @@ def make_synthetic_inputs(state_dict: dict, n_points: int = 1000, image_hw=(240,
     ``feat_c = q2d - PE`` (``OnePosePlusModel.py:135-154``).  ``frame`` reseeds only the
     per-frame part (pose, cell permutation, 2D maps); the 3D object block depends on
     ``seed`` alone, as in a sequence of the demo (``inference.py:102-112``).
+
+    Low-margin / outlier frames (``HARD_PROFILE``): ``noise_hi`` draws every planted pair's descriptor noise from
+    U(noise, noise_hi) -- the reference's confidences then populate the whole (0, 1) range, with tens to hundreds of row maxima
+    around the 0.1 threshold instead of all at ~1.0 -- and ``wrong_frac`` of the pairs are planted in a cell that is NOT the
+    point's projection (a confident match that is geometrically wrong: a PnP outlier; returned as ``wrong_i`` / ``wrong_j``).
+    The defaults consume exactly the random numbers they always did: every committed fixture stays valid.
     """
     cfg = config or default_config()
     H, W = image_hw
@@ -171,13 +178,27 @@ def make_synthetic_inputs(state_dict: dict, n_points: int = 1000, image_hw=(240,
         taken[j] = True
         taken_f.add((fy, fx))
         pi.append(i), pj.append(j), pdx.append(dx), pdy.append(dy)
+    n_wrong = int(wrong_frac * len(pi)) if wrong_frac > 0 else 0
+    wi, wj = [], []
+    if n_wrong:
+        # the first n_wrong pairs (the list is in random order) move to free cells drawn at random: the descriptor match stays, the geometry goes
+        free = torch.nonzero(~taken).flatten()
+        free = free[torch.randperm(len(free), generator=g_frm)][:n_wrong].tolist()
+        for k, jn in enumerate(free):
+            taken[pj[k]] = False
+            wi.append(pi[k]), wj.append(jn)
+            pj[k], pdx[k], pdy[k] = jn, 0, 0
+            taken[jn] = True
     pi_t, pj_t = torch.tensor(pi, dtype=torch.long), torch.tensor(pj, dtype=torch.long)
+    sig = None
+    if noise_hi is not None and pi:          # per-pair noise level
+        sig = noise + (noise_hi - noise) * torch.rand(len(pi), generator=g_frm)
 
     # 3D descriptors after the keypoint encoding, 2D sequence after the sinusoid
     kn = host_math.normalize_keypoints3d(kpts[None])
     enc3d = desc_c + host_math.keypoint_mlp(state_dict, kn).transpose(1, 2)      # [1,C,N]
     q2d = torch.randn(hc * wc, C, generator=g_frm)
-    q2d[pj_t] = enc3d[0, :, pi_t].T + noise * torch.randn(len(pi), C, generator=g_frm)
+    q2d[pj_t] = enc3d[0, :, pi_t].T + (noise if sig is None else sig[:, None]) * torch.randn(len(pi), C, generator=g_frm)
     pe = host_math.sinusoid_table(C, hc, wc)                                     # [C,hc,wc]
     feat_c = (q2d.T.reshape(C, hc, wc) - pe)[None].contiguous()
 
@@ -185,7 +206,7 @@ def make_synthetic_inputs(state_dict: dict, n_points: int = 1000, image_hw=(240,
     if pi:
         fy = 4 * (pj_t // wc) + torch.tensor(pdy)
         fx = 4 * (pj_t % wc) + torch.tensor(pdx)
-        feat_f[0, :, fy, fx] = desc_f[0, :, pi_t] + noise * torch.randn(Cf, len(pi), generator=g_frm)
+        feat_f[0, :, fy, fx] = desc_f[0, :, pi_t] + (noise if sig is None else sig[None, :]) * torch.randn(Cf, len(pi), generator=g_frm)
 
     return {
         "keypoints3d": kpts[None].contiguous(),
@@ -196,8 +217,10 @@ def make_synthetic_inputs(state_dict: dict, n_points: int = 1000, image_hw=(240,
         "image_hw": (H, W),
         "K": K,
         "pose_gt": torch.cat([R, t[:, None]], dim=1),
-        "planted_i": pi_t,
-        "planted_j": pj_t,
+        "planted_i": pi_t[len(wi):],          # geometrically correct pairs
+        "planted_j": pj_t[len(wi):],
+        "wrong_i": torch.tensor(wi, dtype=torch.long),
+        "wrong_j": torch.tensor(wj, dtype=torch.long),
     }
 
 
@@ -206,4 +229,16 @@ CONFIG_SIZES = {
     "c1": (1000, (240, 320), 600),
     "c2": (7000, (480, 640), 3000),
     "c4": (15000, (960, 1280), 6000),
+    # low-margin / outlier variants of c1 and c2 (HARD_PROFILE below; not a BASELINE config: the parity and PnP stress case)
+    "c1_hard": (1000, (240, 320), 600),
+    "c2_hard": (7000, (480, 640), 3000),
 }
+
+# make_synthetic_inputs keyword arguments of the "*_hard" workloads: per-pair descriptor noise U(0.1, 4.0) (reference confidences spread
+# over (0, 1), many around the 0.1 threshold of coarse_matching.py:145) and 35 % of the pairs planted away from their projection
+# (confident but wrong: what ransac_PnP, metric_utils.py:155-165, has to reject)
+HARD_PROFILE = dict(noise=0.1, noise_hi=4.0, wrong_frac=0.35)
+
+
+def workload_kwargs(name: str) -> dict:
+    return dict(HARD_PROFILE) if name.endswith("_hard") else {}

@@ -62,3 +62,40 @@ def test_bench_self_launch_probe_world2():
     assert len(lines) == 1, p.stdout                                     # banners of rank 0 went to stderr
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["rank_sum"] == 3.0 and rec["probe"] is True
+
+
+def test_bench_self_launch_probe_world8_reports_every_rank():
+    """The 8-GPU run is the driver's; what can be checked here is that `python bench.py --gpus 8` fans out eight ranks, every one of them
+    reports (frames done, own seconds, own PnP ceiling), and rank 0's ONE line says so: `ranks.reporting == ranks.expected == 8`,
+    `all_frames_done`, per-rank records in rank order with distinct host slices."""
+    env = dict(os.environ, OPHIP_BENCH_LAUNCH_PROBE="1", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--share-device", "--dist-backend", "gloo",
+                        "--steps", "3", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = p.stdout.splitlines()
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["rank_sum"] == 36.0
+    rk = rec["ranks"]
+    assert rk["expected"] == 8 and rk["reporting"] == 8 and rk["all_frames_done"] is True
+    assert [d["rank"] for d in rk["per_rank"]] == list(range(8)) and [d["device"] for d in rk["per_rank"]] == list(range(8))
+    assert all(d["frames"] == 3 and d["value"] > 0 and d["pnp_ceiling_fps"] > 0 for d in rk["per_rank"])
+    assert abs(rk["value_sum_of_ranks"] - sum(3 / (1.0 + 0.01 * r) for r in range(8))) < 1e-9
+    assert len(rec["host_cores"]) == 8 and len(set(rec["first_cpu"])) >= 1
+
+
+def test_rank_report_flags_a_missing_or_short_rank():
+    sys.path.insert(0, REPO)
+    import bench
+    full = [[r, 20, 0.017, 1900.0, r] for r in range(4)]
+    ok = bench.rank_report(full, 4, 20)
+    assert ok["all_frames_done"] and ok["reporting"] == 4 and abs(ok["value_sum_of_ranks"] - 4 * 20 / 0.017) < 1e-6
+    assert not bench.rank_report(full[:3], 4, 20)["all_frames_done"]                      # a rank did not report
+    short = [list(r) for r in full]
+    short[2][1] = 19
+    assert not bench.rank_report(short, 4, 20)["all_frames_done"]                         # a rank dropped a frame
+    dup = [list(r) for r in full]
+    dup[3][0] = 2
+    assert not bench.rank_report(dup, 4, 20)["all_frames_done"]                           # two records from one rank

@@ -28,6 +28,9 @@ def close_cs(a, b, rtol=2e-5):
 def _inputs(sd, cfg, case):
     if case == "c1":
         return make_synthetic_inputs(sd, n_points=1000, image_hw=(240, 320), n_plant=600, seed=1, config=cfg)
+    if case == "c1_hard":      # low-margin / outlier frame: confidences all over (0, 1), ~40 % of the reference's matches geometrically wrong
+        from onepose_st_amd.synthetic import HARD_PROFILE
+        return make_synthetic_inputs(sd, n_points=1000, image_hw=(240, 320), n_plant=600, seed=1, config=cfg, **HARD_PROFILE)
     i0 = make_synthetic_inputs(sd, n_points=333, image_hw=(96, 136), n_plant=120, seed=3, config=cfg, frame=0)
     i1 = make_synthetic_inputs(sd, n_points=333, image_hw=(96, 136), n_plant=120, seed=3, config=cfg, frame=1)
     both = {k: torch.cat([i0[k], i1[k]], 0) for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db", "feat_c", "feat_f")}
@@ -36,7 +39,7 @@ def _inputs(sd, cfg, case):
 
 
 @pytest.mark.parametrize("case,fname", [("c1", "c1_feature_boundary.npz"), ("b2", "b2_ragged_feature_boundary.npz"),
-                                        ("b2m", "b2_masked_scaled_feature_boundary.npz")])
+                                        ("b2m", "b2_masked_scaled_feature_boundary.npz"), ("c1_hard", "c1_hard_feature_boundary.npz")])
 def test_oracle_matches_reference_golden(sd, cfg, golden_dir, case, fname):
     g = np.load(os.path.join(golden_dir, fname))
     inp = _inputs(sd, cfg, case)
@@ -44,6 +47,11 @@ def test_oracle_matches_reference_golden(sd, cfg, golden_dir, case, fname):
         inp["query_image_mask"] = torch.from_numpy(g["query_image_mask"])
         inp["query_image_scale"] = torch.from_numpy(g["query_image_scale"])
         assert (~inp["query_image_mask"]).any() and len(g["i_ids"]) > 100
+    if case == "c1_hard":      # the fixture really is the low-margin case: row maxima around the threshold, a third of the matches wrong
+        rm, key = g["conf_rowmax"], lambda i, j: i.astype(np.int64) * 100000 + j
+        assert int(((rm > 0.05) & (rm < 0.3)).sum()) >= 50 and (g["mconf"] < 0.5).sum() >= 40
+        wrong = 1.0 - np.isin(key(g["i_ids"], g["j_ids"]), key(g["planted_i"], g["planted_j"])).mean()
+        assert 0.3 <= wrong <= 0.5, wrong
     # the seeded generator still produces the inputs the goldens were made from
     for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db", "feat_c", "feat_f"):
         np.testing.assert_allclose(cs(inp[k]), g["in_" + k], rtol=1e-12, atol=1e-9)
@@ -83,7 +91,7 @@ def test_oracle_matches_reference_golden(sd, cfg, golden_dir, case, fname):
     # the planted matches are recovered (sanity of the generator, not of the oracle)
     got = set(zip(out["i_ids"][out["b_ids"] == 0].tolist(), out["j_ids"][out["b_ids"] == 0].tolist()))
     planted = set(zip(g["planted_i"].tolist(), g["planted_j"].tolist()))
-    assert len(got & planted) >= 0.9 * len(got)
+    assert len(got & planted) >= (0.55 if case == "c1_hard" else 0.9) * len(got)          # (the hard case plants 35 % of its pairs wrong on purpose)
 
 
 def test_oracle_full_forward_empty_matches(sd, cfg, golden_dir):

@@ -74,6 +74,16 @@ def test_p3p_branch_gives_a_pose_from_four_or_five_matches(n):
     assert np.array_equal(pose3, np.eye(4)[:3]) and len(inl3) == 0
 
 
+@pytest.mark.parametrize("pycolmap_branch", [False, True])
+def test_outlier_heavy_frame_keeps_its_pose(pycolmap_branch):
+    """40 % outliers with the outliers FIRST in the list (the first hypotheses then have a handful of inliers): the adaptive branch used to
+    turn "billions of trials needed" into a negative int, stop at once and return no pose (found by the c1_hard fixture)."""
+    K, uv, X, R, t, n_out = _scene(300, 6, noise_px=0.8, outlier_frac=0.4)
+    pose, _, inl = ransac_PnP(K, uv, X, pnp_reprojection_error=7, use_pycolmap_ransac=pycolmap_branch)
+    assert len(inl) >= 0.95 * (300 - n_out) and (inl >= n_out).mean() > 0.97
+    assert _rot_err(pose[:, :3], R) < 0.3 and np.linalg.norm(pose[:, 3] - t) / np.linalg.norm(t) < 5e-3
+
+
 def test_pose_is_insensitive_at_matcher_noise_level():
     """1e-4 px perturbations of the 2D keypoints (the HIP path's deviation from the oracle) move the pose by < 1e-6 rel."""
     K, uv, X, R, t, _ = _scene(2800, 3, noise_px=0.7)
