@@ -32,6 +32,11 @@ int ophip_abi_version(void);
  * bench.py quotes committed counter values only when they were taken on the running build) */
 const char* ophip_build_stamp(void);
 const char* ophip_last_error(void);
+/* Tracing hook (the reference's profiler.record_function scopes, coarse_matching.py:122,167): on = 1 wraps every kernel
+ * launch and every stage of ophip_frame_enqueue in a roctx range (rocprofv3 --marker-trace); OPHIP_ROCTX=1 in the environment enables it
+ * without a call.  libroctx64 is loaded at run time; an error is returned when it is missing.  ophip_roctx_ranges(): ranges opened so far. */
+int ophip_roctx_enable(int on);
+long long ophip_roctx_ranges(void);
 /* host query: CU count, LDS bytes per block, gcn arch name of the current device */
 int ophip_device_info(int* cu_count, int* lds_per_block, char* arch, int arch_len);
 

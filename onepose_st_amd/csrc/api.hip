@@ -1,7 +1,10 @@
 // C-ABI plumbing: version, error reporting, device queries.  See include/onepose_hip.h.
 #include "tile.h"
 #include "onepose_hip.h"
+#include <atomic>
+#include <dlfcn.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -107,6 +110,47 @@ extern "C" int ophip_timing_read(int* launches, double* total_ms) {
 namespace { unsigned long long* g_stamps = nullptr; }
 extern "C" unsigned long long* ophip_stamp_buffer(void) { return g_stamps; }
 extern "C" int ophip_debug_stamps(void* device_buffer) { g_stamps = reinterpret_cast<unsigned long long*>(device_buffer); return 0; }
+
+// ---- tracing hook: roctx ranges (tile.h OPHIP_LAUNCH, frame.hip) ------------------------------------------------------------------------
+namespace {
+int (*g_roctx_push)(const char*) = nullptr;
+int (*g_roctx_pop)() = nullptr;
+int g_roctx_state = -1;              // -1: not decided (OPHIP_ROCTX is read at the first range), 0: off, 1: on
+std::atomic<long long> g_roctx_ranges{0};
+
+int roctx_load() {
+    if (g_roctx_push) return 0;
+    void* lib = nullptr;
+    for (const char* name : {"libroctx64.so.4", "libroctx64.so", "librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so"}) {
+        lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (lib) break;
+    }
+    if (!lib) return ophip_bad_arg("ophip_roctx_enable", "no roctx library found (libroctx64.so / librocprofiler-sdk-roctx.so)");
+    g_roctx_push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+    g_roctx_pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+    if (!g_roctx_push || !g_roctx_pop) { g_roctx_push = nullptr; return ophip_bad_arg("ophip_roctx_enable", "roctxRangePushA / roctxRangePop not found"); }
+    return 0;
+}
+}  // namespace
+
+extern "C" int ophip_roctx_enable(int on) {
+    if (on) { if (int rc = roctx_load()) { g_roctx_state = 0; return rc; } }
+    g_roctx_state = on ? 1 : 0;
+    return 0;
+}
+// ranges opened since the library was loaded (tests: the hook really fires on the default path)
+extern "C" long long ophip_roctx_ranges(void) { return g_roctx_ranges.load(); }
+
+void ophip_range_push(const char* name) {
+    if (g_roctx_state < 0) {
+        const char* e = getenv("OPHIP_ROCTX");
+        g_roctx_state = (e && e[0] && e[0] != '0' && roctx_load() == 0) ? 1 : 0;
+    }
+    if (g_roctx_state == 1) { g_roctx_push(name); g_roctx_ranges.fetch_add(1, std::memory_order_relaxed); }
+}
+void ophip_range_pop() {
+    if (g_roctx_state == 1) g_roctx_pop();
+}
 
 extern "C" int ophip_abi_version(void) { return OPHIP_ABI_VERSION; }
 

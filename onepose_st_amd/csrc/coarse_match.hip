@@ -343,7 +343,7 @@ constexpr size_t SIM_FRAG_LDS = SIM_FRAG_STAGE + 4 * 128 * sizeof(float) + 64;
 // MODE 0: the scaled S tile goes to the conf buffer and into the (max, sum exp) partials (the eager form: conf_kernel follows);
 // MODE 1: partials only, nothing stored (first pass of the lazy form: conf_matrix is not materialised);
 // MODE 2: second pass of the lazy form: the tile is recomputed, turned into confidences with the merged statistics -- the very
-//         expression of conf_kernel, so every value is bit-identical to the eager form's -- and only what select_kernel consumes
+//         expression of conf_kernel, so every value is bit-identical to the eager form's -- and only what the selection consumes
 //         leaves the chip: per (row, column tile) the best candidate above the threshold (value, lowest j, tie count) and the
 //         column maxima.  Reference callers read only the match lists (inference.py:179-180): 134 MB store + 269 MB pass saved.
 template <int NS, int MODE>
@@ -576,7 +576,7 @@ struct CombineArgs {
     unsigned* colmax_bits;        // [B][M], cleared here for the conf pass's atomicMax
     int N, M, ntr, ntc;
     float *rowlog, *collog;       // optional [B][N], [B][M]: logf(sum exp) for the lazy form's candidate pass (NULL: not written)
-    int* lazy_flag;               // optional: count[1], cleared here (select_kernel sets it on an exact row tie it cannot resolve without conf)
+    int* lazy_flag;               // optional: count[1], cleared here (select_decide sets it on an exact row tie it cannot resolve without conf)
 };
 
 // 8 lanes per row / column: lane q merges partials q, q+8, ... in order, then the 8 are merged by an xor
@@ -813,127 +813,113 @@ struct SelectArgs {
     int* count;
 };
 
-// SEL_IT workgroups compact the surviving rows in (b, i) order: every one of them decides all rows and scans all wave counts (the
-// same loads, from L2), but writes only the matches of its own 1024-row slice of each chunk -- the ~12 scattered stores per match
-// were 3/4 of the single-workgroup kernel (one CU's store issue rate).  A thread owns SEL_IT rows of a chunk of 1024 * SEL_IT rows:
-// all its row-best records are loaded first, then all its column maxima (independent gathers, one memory round trip each
-// instead of one per 1024 rows), then one scan over the SEL_IT x 16 wave counts places every match.
-constexpr int SEL_IT = 8;
-static_assert(SEL_IT * 16 == 128, "the wave-count scan of select_kernel assumes two waves of counts");
+// Selection in two small kernels (round 4; the single 8 x 1024-thread kernel of round 3 needed whole CUs, which beside the previous
+// frame's fine stage -- two 256-register waves on every SIMD -- it got only after 50-200 us):
+//   select_decide: one thread per 3D point (b, i): merges its row-best records, applies threshold, border and the mutual test (and the
+//                  exact-tie walk along the stored row, coarse_matching.py:166 "first true j"), writes j or -1 and a count per workgroup;
+//   select_place:  the same grid; a workgroup adds up the counts of the workgroups before it (<= a few hundred ints) and writes its own
+//                  matches at their final positions -- ascending (b, i), the order of torch.where in the reference (coarse_matching.py:170).
+// 256-thread workgroups, < 64 registers, 1 KiB of LDS: they fit wherever one wave slot per SIMD is free.
+constexpr int SEL_T = 256;
 
-__global__ __launch_bounds__(1024) void select_kernel(SelectArgs p) {
-    __shared__ int wcount[SEL_IT * 16];
-    __shared__ int wpref[SEL_IT * 16 + 1];
-    __shared__ int wtot[2];
-    __shared__ int base_s;
+__global__ __launch_bounds__(SEL_T) void select_decide_kernel(SelectArgs p, int* __restrict__ dec, int* __restrict__ wgcount) {
+    __shared__ int wsum[SEL_T / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) base_s = 0;
-    __syncthreads();
-    for (int b = 0; b < p.B; ++b) {
-        const float* conf = p.conf ? p.conf + (size_t)b * p.N * p.M : nullptr;
-        const float* cmx = p.colmax + (size_t)b * p.M;
-        const float* kpb = p.kpts + (size_t)b * p.kpts_bs;
-        for (int ib = 0; ib < p.N; ib += 1024 * SEL_IT) {
-            float v[SEL_IT], cm[SEL_IT], kx[SEL_IT], ky[SEL_IT], kz[SEL_IT];
-            int j[SEL_IT], c[SEL_IT];
-            bool ok[SEL_IT];
+    const long long g = (long long)blockIdx.x * SEL_T + tid;
+    const long long total = (long long)p.B * p.N;
+    int jsel = -1;
+    if (g < total) {
+        const int b = (int)(g / p.N), i = (int)(g % p.N);
+        float v = -1.f;
+        int j = 0x7fffffff, c = 0;
+        for (int sp0 = 0; sp0 < p.nspan; sp0 += 4) {          // four records in flight (the lazy form has one per column tile: 38 at c2)
+            float rv[4][3];
 #pragma unroll
-            for (int it = 0; it < SEL_IT; ++it) {
-                const int i = ib + it * 1024 + tid;
-                v[it] = -1.f; j[it] = 0x7fffffff; c[it] = 0;
-                if (i < p.N) {
-                    for (int sp = 0; sp < p.nspan; ++sp) {
-                        const float* q = p.rowbest + (((size_t)b * p.nspan + sp) * p.N + i) * 3;
-                        const float v2 = q[0];
-                        const int j2 = __float_as_int(q[1]), c2 = __float_as_int(q[2]);
-                        if (v2 > v[it]) { v[it] = v2; j[it] = j2; c[it] = c2; }
-                        else if (v2 == v[it]) { j[it] = min(j[it], j2); c[it] += c2; }
-                    }
-                }
+            for (int u = 0; u < 4; ++u) {
+                const int sp = min(sp0 + u, p.nspan - 1);
+                const float* q = p.rowbest + (((size_t)b * p.nspan + sp) * p.N + i) * 3;
+                rv[u][0] = q[0]; rv[u][1] = q[1]; rv[u][2] = q[2];
             }
 #pragma unroll
-            for (int it = 0; it < SEL_IT; ++it) {
-                const int i = ib + it * 1024 + tid;
-                const bool live = i < p.N && v[it] > p.thr;
-                cm[it] = live ? cmx[j[it]] : 0.f;
-                const bool mine = live && it == (int)blockIdx.x;
-                kx[it] = mine ? kpb[(size_t)i * 3] : 0.f;
-                ky[it] = mine ? kpb[(size_t)i * 3 + 1] : 0.f;
-                kz[it] = mine ? kpb[(size_t)i * 3 + 2] : 0.f;
+            for (int u = 0; u < 4; ++u) {
+                if (sp0 + u >= p.nspan) break;
+                const float v2 = rv[u][0];
+                const int j2 = __float_as_int(rv[u][1]), c2 = __float_as_int(rv[u][2]);
+                if (v2 > v) { v = v2; j = j2; c = c2; }
+                else if (v2 == v) { j = min(j, j2); c += c2; }
             }
-#pragma unroll
-            for (int it = 0; it < SEL_IT; ++it) {
-                const int i = ib + it * 1024 + tid;
-                const float vv = v[it];
-                auto inside = [&](int jj) {
-                    const int jy = jj / p.wc, jx = jj % p.wc;
-                    if (p.border_mode == 0) return (jy >= p.border) && (jx >= p.border);
-                    return jy >= p.border && jx >= p.border && jy < p.M / p.wc - p.border && jx < p.wc - p.border;
-                };
-                bool o = false;
-                bool i_ok = true;
-                if (p.border_mode == 1) {
-                    const int iy = i / p.wi, ix = i % p.wi;
-                    i_ok = iy >= p.border && ix >= p.border && iy < p.N / p.wi - p.border && ix < p.wi - p.border;
-                }
-                if (i < p.N && vv > p.thr && i_ok) {
-                    o = inside(j[it]) && vv == cm[it];
-                    if (!o && c[it] > 1) {
-                        // exact tie of the row maximum: the reference takes the first j whose mask is true
-                        if (p.conf) {
-                            const float* row = conf + (size_t)i * p.M;
-                            for (int jj = j[it] + 1; jj < p.M; ++jj)
-                                if (row[jj] == vv && inside(jj) && vv == cmx[jj]) { j[it] = jj; o = true; break; }
-                        } else {
-                            p.count[1] = 1;          // lazy form: the other tied columns were never stored -> the caller re-runs this frame eagerly
-                        }
-                    }
-                }
-                ok[it] = o;
-                const unsigned long long mask = __ballot(o);
-                if (lane == 0) wcount[it * 16 + wave] = __popcll(mask);
-            }
-            __syncthreads();
-            if (tid < SEL_IT * 16) {                 // exclusive scan of the 128 wave counts: two waves, shuffle scan + carry
-                const int own = wcount[tid];
-                int inc = own;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int up = __shfl_up(inc, o, 64);
-                    if (lane >= o) inc += up;
-                }
-                wpref[tid] = inc - own;                              // exclusive within the wave
-                if (lane == 63) wtot[wave] = inc;                    // the two waves' totals
-            }
-            __syncthreads();
-            if (tid >= 64 && tid < SEL_IT * 16) wpref[tid] += wtot[0];
-            if (tid == 0) wpref[SEL_IT * 16] = wtot[0] + wtot[1];
-            __syncthreads();
-            const int base = base_s;
-#pragma unroll
-            for (int it = 0; it < SEL_IT; ++it) {
-                const unsigned long long mask = __ballot(ok[it]);
-                if (ok[it] && it == (int)blockIdx.x) {
-                    const int i = ib + it * 1024 + tid;
-                    const int pos = base + wpref[it * 16 + wave] + __popcll(mask & ((1ull << lane) - 1ull));
-                    p.b_ids[pos] = b; p.i_ids[pos] = i; p.j_ids[pos] = j[it];
-                    p.mconf[pos] = v[it];
-                    p.mk3d[3 * pos] = kx[it]; p.mk3d[3 * pos + 1] = ky[it]; p.mk3d[3 * pos + 2] = kz[it];
-                    // scale_total = scale * query_image_scale[b][[1, 0]] (f32), then (x, y) * scale_total
-                    const float sx = p.qscale ? __fmul_rn(p.scale, p.qscale[2 * b + 1]) : p.scale;
-                    const float sy = p.qscale ? __fmul_rn(p.scale, p.qscale[2 * b]) : p.scale;
-                    p.mkq[2 * pos] = (float)(j[it] % p.wc) * sx;
-                    p.mkq[2 * pos + 1] = (float)(j[it] / p.wc) * sy;
-                    if (p.m_bids) p.m_bids[pos] = b;
-                    if (p.gt_mask) p.gt_mask[pos] = v[it] == 0.f ? 1 : 0;
-                }
-            }
-            __syncthreads();
-            if (tid == 0) base_s = base + wpref[SEL_IT * 16];
-            __syncthreads();
         }
+        auto inside = [&](int jj) {
+            const int jy = jj / p.wc, jx = jj % p.wc;
+            if (p.border_mode == 0) return (jy >= p.border) && (jx >= p.border);
+            return jy >= p.border && jx >= p.border && jy < p.M / p.wc - p.border && jx < p.wc - p.border;
+        };
+        bool i_ok = true;
+        if (p.border_mode == 1) {
+            const int iy = i / p.wi, ix = i % p.wi;
+            i_ok = iy >= p.border && ix >= p.border && iy < p.N / p.wi - p.border && ix < p.wi - p.border;
+        }
+        if (v > p.thr && i_ok) {
+            const float* cmx = p.colmax + (size_t)b * p.M;
+            bool o = inside(j) && v == cmx[j];
+            if (!o && c > 1) {
+                // exact tie of the row maximum: the reference takes the first j whose mask is true
+                if (p.conf) {
+                    const float* row = p.conf + ((size_t)b * p.N + i) * p.M;
+                    for (int jj = j + 1; jj < p.M; ++jj)
+                        if (row[jj] == v && inside(jj) && v == cmx[jj]) { j = jj; o = true; break; }
+                } else {
+                    p.count[1] = 1;          // lazy form: the other tied columns were never stored -> the caller re-runs this frame eagerly
+                }
+            }
+            if (o) jsel = j;
+        }
+        dec[g] = jsel;
     }
-    if (tid == 0 && blockIdx.x == 0) *p.count = base_s;          // (count[1], the lazy form's "needs the eager form" flag, is cleared by the caller's memset / stat pass)
+    const unsigned long long mask = __ballot(jsel >= 0);
+    if (lane == 0) wsum[wave] = __popcll(mask);
+    __syncthreads();
+    if (tid == 0) wgcount[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+__global__ __launch_bounds__(SEL_T) void select_place_kernel(SelectArgs p, const int* __restrict__ dec, const int* __restrict__ wgcount) {
+    __shared__ int red[SEL_T / 64];
+    __shared__ int wpre[SEL_T / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // matches of all workgroups before this one (integer sums: any order gives the same result)
+    int part = 0;
+    for (int w = tid; w < (int)blockIdx.x; w += SEL_T) part += wgcount[w];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if (lane == 0) red[wave] = part;
+    const long long g = (long long)blockIdx.x * SEL_T + tid;
+    const long long total = (long long)p.B * p.N;
+    const int j = g < total ? dec[g] : -1;
+    const unsigned long long mask = __ballot(j >= 0);
+    if (lane == 0) wpre[wave] = __popcll(mask);
+    __syncthreads();
+    const int base = (red[0] + red[1]) + (red[2] + red[3]);
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += wpre[w];
+    if (j >= 0) {
+        const int b = (int)(g / p.N), i = (int)(g % p.N);
+        const int pos = base + before + __popcll(mask & ((1ull << lane) - 1ull));
+        const float* q = p.rowbest + ((size_t)b * p.nspan * p.N + i) * 3;
+        float v = q[0];
+        for (int sp = 1; sp < p.nspan; ++sp) v = fmaxf(v, q[(size_t)sp * p.N * 3]);
+        const float* kpb = p.kpts + (size_t)b * p.kpts_bs + (size_t)i * 3;
+        p.b_ids[pos] = b; p.i_ids[pos] = i; p.j_ids[pos] = j;
+        p.mconf[pos] = v;
+        p.mk3d[3 * pos] = kpb[0]; p.mk3d[3 * pos + 1] = kpb[1]; p.mk3d[3 * pos + 2] = kpb[2];
+        // scale_total = scale * query_image_scale[b][[1, 0]] (f32), then (x, y) * scale_total
+        const float sx = p.qscale ? __fmul_rn(p.scale, p.qscale[2 * b + 1]) : p.scale;
+        const float sy = p.qscale ? __fmul_rn(p.scale, p.qscale[2 * b]) : p.scale;
+        p.mkq[2 * pos] = (float)(j % p.wc) * sx;
+        p.mkq[2 * pos + 1] = (float)(j / p.wc) * sy;
+        if (p.m_bids) p.m_bids[pos] = b;
+        if (p.gt_mask) p.gt_mask[pos] = v == 0.f ? 1 : 0;
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) *p.count = base + (wpre[0] + wpre[1]) + (wpre[2] + wpre[3]);
 }
 
 inline int conf_nspan(int M) { return (M + 1024 * CONF_U - 1) / (1024 * CONF_U); }
@@ -941,7 +927,7 @@ inline int conf_spanw(int M) { const int ns = conf_nspan(M); return (((M + ns - 
 
 // workspace map (floats), shared by the sizing helper, coarse_impl and the fragment-plane accessor
 struct CoarseWs {
-    size_t rowpart, colpart, rowstat, colstat, rowbest, colmax, rowlog, collog, planes, total;
+    size_t rowpart, colpart, rowstat, colstat, rowbest, colmax, rowlog, collog, seldec, selcnt, planes, total;
     int nspan_cap;                                   // row-best records per row: conf_kernel's spans or (lazy form) the column tiles
 };
 CoarseWs coarse_ws(int B, int N, int M) {
@@ -957,6 +943,8 @@ CoarseWs coarse_ws(int B, int N, int M) {
     w.colmax = f; f += (size_t)B * M;
     w.rowlog = f; f += (size_t)B * N;
     w.collog = f; f += (size_t)B * M;
+    w.seldec = f; f += (size_t)B * N;                                   // select_decide: chosen j (int) or -1 per 3D point
+    w.selcnt = f; f += ((size_t)B * N + SEL_T - 1) / SEL_T + 4;        // ... and the matches per workgroup
     w.planes = f; f += (size_t)B * (ntr + ntc) * TM * C + 64;      // fragment planes of both inputs (hi + lo bf16 = 4 bytes per element), rows padded to 128
     w.total = f + 64;
     return w;
@@ -1064,7 +1052,12 @@ int coarse_impl(int parts, int border_mode, int wi, double temp_eps,
     if (parts & 2) {
         SelectArgs se{conf, rowbest, colmax, keypoints3d, kpts_bstride, B, N, M, sel_nspan, wc, border_rm, border_mode, wi, thr, scale, qscale,
                       b_ids, i_ids, j_ids, mconf, mkpts3d, mkpts_c, m_bids, gt_mask, count};      // (conf == NULL: an exact row tie sets count[1])
-        OPHIP_LAUNCH("select", stream, select_kernel, dim3(SEL_IT), dim3(1024), 0, stream, se);
+        int* dec = reinterpret_cast<int*>(workspace + ws.seldec);
+        int* wgc = reinterpret_cast<int*>(workspace + ws.selcnt);
+        const int nwg = (int)(((long long)B * N + SEL_T - 1) / SEL_T);
+        OPHIP_LAUNCH("select", stream, select_decide_kernel, dim3(nwg), dim3(SEL_T), 0, stream, se, dec, wgc);
+        OPHIP_CHECK_LAUNCH();
+        OPHIP_LAUNCH("select_place", stream, select_place_kernel, dim3(nwg), dim3(SEL_T), 0, stream, se, dec, wgc);
         OPHIP_CHECK_LAUNCH();
     }
     return 0;

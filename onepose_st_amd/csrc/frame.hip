@@ -233,6 +233,13 @@ extern "C" int ophip_frame_enqueue_padded(const ophip_frame_desc* d, const ophip
 
     // ---- input kernels (a1-a3 + the fine map's transpose): on their own stream when the caller's tensors are complete ----------
     hipStream_t sin = s_prep ? s_prep : s_main;
+    OphipRange frame_range("ophip_frame_enqueue");
+    struct StageRange {                 // one open roctx range at a time, closed on every exit path
+        bool open = false;
+        void next(const char* name) { if (open) ophip_range_pop(); ophip_range_push(name); open = true; }
+        ~StageRange() { if (open) ophip_range_pop(); }
+    } stage;
+    stage.next("a1-a3 input kernels");
     float* x2d = F(L->x2d);
     FR_CHECK(ophip_pe_add_transpose(feat_c, d->pe, x2d, B, 256, M, sin));
     const float* ff = feat_f;
@@ -249,6 +256,7 @@ extern "C" int ophip_frame_enqueue_padded(const ophip_frame_desc* d, const ophip
             FR_CHECK(ophip_transpose_cl(desc_c, x3d, B, 256, N, sin));
         }
     }
+    stage.next("a4-a6 coarse encoder");
     // The first encoder layer's K / V half (kv_reduce + kv_sum: ~20 us of the frame at c2) reads this frame's input rows only.  It used to
     // be the first thing BEHIND the wait for the previous frame's fine stage, i.e. on the critical path of every frame; it now goes out
     // ahead of that wait: "prep" = behind the input kernels on their stream (beside whatever runs when they run), "main" = on the
@@ -289,6 +297,7 @@ extern "C" int ophip_frame_enqueue_padded(const ophip_frame_desc* d, const ophip
         float* t2 = x2; x2 = y2; y2 = t2;
     }
     // ---- a7 + a8: coarse matching; selection, fine stage and read-back on their side streams -----------------------------------
+    stage.next("a7-a11 coarse matching, fine stage, read-back");
     float* conf = d->lazy_conf ? nullptr : F(L->conf);
     float* cws = F(L->cws);
     int* count = reinterpret_cast<int*>(blob + L->result);

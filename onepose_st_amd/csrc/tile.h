@@ -173,9 +173,23 @@ int ophip_lds_attr(const void* fn, size_t bytes, const char* what);
 // hipEventRecord pair around the launch read 7 us more than the trace at c2 and cost the stream 2-3 us per pair).
 bool ophip_timed_events(const char* name, hipEvent_t* start, hipEvent_t* stop);
 
+// Tracing hook ("roctx ranges around each custom op"; the reference's counterpart is profiler.record_function,
+// coarse_matching.py:122,167): with ophip_roctx_enable(1) -- or OPHIP_ROCTX=1 in the environment -- every kernel launch and every stage of
+// ophip_frame_enqueue sits in a roctx range named like the launch (rocprofv3 --marker-trace shows them beside the kernel trace).  Off: one
+// predictable branch per launch.  libroctx64 is loaded with dlopen, so the library has no link-time dependency on the profiler.
+void ophip_range_push(const char* name);
+void ophip_range_pop();
+struct OphipRange {
+    explicit OphipRange(const char* name) { ophip_range_push(name); }
+    ~OphipRange() { ophip_range_pop(); }
+    OphipRange(const OphipRange&) = delete;
+    OphipRange& operator=(const OphipRange&) = delete;
+};
+
 // launch + optional event pair; NAME is the string ophip_timing_select() matches
 #define OPHIP_LAUNCH(NAME, STREAM, KERNEL, GRID, BLOCK, LDSBYTES, STREAM2, ...)                                  \
     do {                                                                                                         \
+        OphipRange range__(NAME);                                                                                \
         hipEvent_t s__ = nullptr, e__ = nullptr;                                                                 \
         if (ophip_timed_events(NAME, &s__, &e__))                                                                \
             hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, LDSBYTES, STREAM2, s__, e__, 0, __VA_ARGS__);             \

@@ -43,6 +43,8 @@ _SIGNATURES = {
     "ophip_abi_version": (c_i, []),
     "ophip_build_stamp": (ctypes.c_char_p, []),
     "ophip_last_error": (ctypes.c_char_p, []),
+    "ophip_roctx_enable": (c_i, [c_i]),
+    "ophip_roctx_ranges": (c_ll, []),
     "ophip_device_info": (c_i, [ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.c_char_p, c_i]),
     "ophip_timing_select": (c_i, [ctypes.c_char_p]),
     "ophip_timing_read": (c_i, [ctypes.POINTER(c_i), ctypes.POINTER(ctypes.c_double)]),

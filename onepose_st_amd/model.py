@@ -79,9 +79,10 @@ class _KeypointEncoderParams(nn.Module):
 
 
 class _NullProfiler:
-    @contextlib.contextmanager
+    _scope = contextlib.nullcontext()
+
     def record_function(self, name):
-        yield
+        return self._scope
 
 
 class OnePosePlus_model(nn.Module):
@@ -308,7 +309,7 @@ class OnePosePlus_model(nn.Module):
         # a lazy frame whose selection meets an exact row tie it cannot resolve without the stored row is run again with conf_matrix
         rerun = (lambda: self.enqueue_features(data, feat_c, feat_f, image_hw, want_fine_debug, host_copy, _pe_applied, False, True)) if lazy else None
         if (self.frame_call and self.precision == "bf16x3" and self.overlap_fine and not _pe_applied and not want_fine_debug
-                and not self.debug and isinstance(self.profiler, _NullProfiler) and bool(cfg["fine_matching"]["enable"])
+                and not self.debug and bool(cfg["fine_matching"]["enable"])
                 and (self.kpt_3d_pos_encoding is not None or B == 1 or desc_in_d.shape[0] == B)
                 and len(self.loftr_coarse.layer_names) <= 16):
             x3d_ext = None
@@ -617,10 +618,14 @@ class OnePosePlus_model(nn.Module):
         else:
             fs = (ff.stride(0), 1, ff.stride(2), ff.stride(3))
         try:
-            # the whole frame through ONE custom op (torch.ops.onepose_hip.frame_enqueue -> ophip_frame_enqueue)
-            slot = torch.ops.onepose_hip.frame_enqueue(plan_id, blob, fc, ff, list(fs), kpts_d, desc_in_d, desc_fine_d, x3d_ext, pin, nbytes,
-                                                       main.cuda_stream, sprep.cuda_stream if sprep is not None else 0,
-                                                       sfine.cuda_stream, scopy.cuda_stream, qmask, qscale)
+            # the whole frame through ONE custom op (torch.ops.onepose_hip.frame_enqueue -> ophip_frame_enqueue).  The reference's two
+            # profiler scopes (coarse_matching.py:122,167) enclose it -- get_coarse_match and its argmax are inside this call; a profiler no
+            # longer takes the model off the one-call path -- and the library adds a roctx range per stage and kernel (OPHIP_ROCTX=1).
+            with self.profiler.record_function("LoFTR/coarse-matching/get_coarse_match"), \
+                    self.profiler.record_function("LoFTR/coarse-matching/get_coarse_match/argmax-conf"):
+                slot = torch.ops.onepose_hip.frame_enqueue(plan_id, blob, fc, ff, list(fs), kpts_d, desc_in_d, desc_fine_d, x3d_ext, pin, nbytes,
+                                                           main.cuda_stream, sprep.cuda_stream if sprep is not None else 0,
+                                                           sfine.cuda_stream, scopy.cuda_stream, qmask, qscale)
         except Exception:
             # part of the frame may be queued on the side streams already: nothing may touch the block or the pinned buffer again
             # before those streams are idle

@@ -1204,3 +1204,46 @@ def test_c2_hard_full_size_against_oracle(model, sd, cfg, dev):
     v = conf[i, j]
     assert torch.equal(v, data["mconf"]) and bool((v > 0.1).all())
     assert torch.equal(v, conf.max(dim=1)[0][i]) and torch.equal(v, conf.max(dim=0)[0][j])          # mutual nearest, on the device's own matrix
+
+
+@pytest.mark.gpu
+def test_profiler_and_roctx_ranges_on_the_one_call_path(sd, cfg, dev):
+    """SURVEY section 5's hook on the DEFAULT path: a profiler object no longer takes the model off the one-call frame path, its
+    record_function sees the reference's two scope names (coarse_matching.py:122,167) once per frame, and with the roctx hook enabled
+    the library opens ranges around the frame's stages and kernels -- results bit-identical to the unprofiled frame."""
+    import contextlib
+    from onepose_st_amd import ops
+    from onepose_st_amd.model import OnePosePlus_model
+
+    class Recorder:
+        def __init__(self):
+            self.names = []
+
+        @contextlib.contextmanager
+        def record_function(self, name):
+            self.names.append(name)
+            yield
+
+    inp = make_synthetic_inputs(sd, n_points=300, image_hw=(64, 96), n_plant=90, seed=4, config=cfg)
+    plain = _run_features(_model(sd, cfg, dev, "bf16x3"), inp, dev)
+    rec = Recorder()
+    c2 = dict(cfg)
+    c2["hip_precision"] = "bf16x3"
+    m = OnePosePlus_model(c2, profiler=rec).eval()
+    m.load_state_dict(sd, strict=True)
+    m.to(dev)
+    lib = hip.load()
+    n_calls, n_ranges = ops.CALLS["frame_enqueue"], lib.ophip_roctx_ranges()
+    hip.call("ophip_roctx_enable", 1)
+    try:
+        got = _run_features(m, inp, dev)
+    finally:
+        hip.call("ophip_roctx_enable", 0)
+    assert ops.CALLS["frame_enqueue"] == n_calls + 1                      # still ONE op call for the frame
+    assert rec.names == ["LoFTR/coarse-matching/get_coarse_match", "LoFTR/coarse-matching/get_coarse_match/argmax-conf"]
+    assert lib.ophip_roctx_ranges() - n_ranges >= 20                      # frame + 3 stages + every kernel launch of the frame
+    for key in ("i_ids", "j_ids", "mconf", "mkpts_query_f", "expec_f"):
+        assert torch.equal(got[key], plain[key]), key
+    n_off = lib.ophip_roctx_ranges()
+    _run_features(m, inp, dev)
+    assert lib.ophip_roctx_ranges() == n_off                              # off again: no range is opened

@@ -10,7 +10,7 @@ import sys
 
 def short(name):
     for key, tag in (("fine_pair", "fine"), ("fine_refine", "fine"), ("sim_frag_kernel<3, 0>", "sim_frag"), ("sim_frag_kernelILi3ELi0", "sim_frag"),
-                     ("sim_frag", "sim_frag*"), ("conf_kernel", "conf"), ("select_kernel", "select"), ("stat_combine", "stat_combine"), ("kv_sum", "kv_sum"),
+                     ("sim_frag", "sim_frag*"), ("conf_kernel", "conf"), ("select_place", "select_place"), ("select_decide", "select"), ("select_kernel", "select"), ("stat_combine", "stat_combine"), ("kv_sum", "kv_sum"),
                      ("enc_x3w8_kernel<true", "kv_reduce"), ("enc_x3w8_kernelILb1", "kv_reduce"), ("enc_x3w8_kernel<false", "attn_apply"),
                      ("enc_x3w8_kernelILb0", "attn_apply"), ("pe_add", "pe_add"), ("transpose", "transpose"), ("kpt", "kpt")):
         if key in name:
