@@ -357,6 +357,7 @@ def main():
     n_inliers = int(poses[-1][1]) if poses else -1
 
     own_dt = [0.0]          # this rank's own seconds of the last timed region (before the max over ranks)
+    HOT_STEPS = int(os.environ.get("OPHIP_BENCH_HOT_STEPS", "8"))          # untimed matcher-only frames right before every timed region (see timed_region)
 
     def timed_region(active_pool):
         """W warm-up + exactly K timed steps with `active_pool` solving the poses (None: matcher only); returns seconds (max over ranks)"""
@@ -366,13 +367,23 @@ def main():
             step(i)
         drain()
         join_poses()
+        gc.collect()
+        gc.disable()                                     # no collector pause of the feeder thread inside the timed steps
+        # Joining the warm-up's poses and the collector pause leave the GPU idle for 1-50 ms; a chip that comes out of idle first boosts, then
+        # overshoots its power limit and runs ~10 % slow for 5-8 ms before it settles (kernel trace of a 20-step region: attn_apply 47 us
+        # in frames 0-2, 51-54 us in frames 3-10, 47 us from frame 11 on) -- a third of a 17 ms region.  A few more untimed frames without
+        # host PnP (nothing to join afterwards) bring it back to the state it holds in a running pipeline; then the barrier + synchronize the
+        # contract asks for, and the clock starts on a GPU that has been idle for microseconds.  (Counted in setup_steps_untimed.)
+        pool = None
+        for i in range(HOT_STEPS):
+            step(i)
+        drain()
+        pool = active_pool
         for st in streams:
             st.synchronize()
         sync_all()
         for k in host_t:
             host_t[k] = 0.0
-        gc.collect()
-        gc.disable()                                     # no collector pause of the feeder thread inside the timed steps
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(i)
@@ -533,7 +544,7 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "setup_steps_untimed": setup_steps + (1 if args.main_region_only else (5 if args.precision != "f32" else 4)) * args.warmup,      # settle blocks before the W warm-up steps + the warm-ups of the side regions
+        "setup_steps_untimed": setup_steps + (1 if args.main_region_only else (5 if args.precision != "f32" else 4)) * (args.warmup + HOT_STEPS),      # settle blocks before the W warm-up steps + the warm-ups (and hot steps) of the side regions
         "ms_per_step": dt / args.steps * 1e3,
         "value_matcher_only": (frames_total / dt_matcher) if dt_matcher else None,
         "lazy_conf_frames_rerun_eagerly": lazy_reruns,

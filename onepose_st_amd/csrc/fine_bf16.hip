@@ -17,6 +17,17 @@
 #include "tile_bf16.h"
 #include <stdlib.h>
 
+// OPHIP_FINE_INTERLEAVE=1 (experiment): no scheduling fence between a match's K|V projection and the other match's attention block, so
+// that the compiler may run the one's matrix instructions under the other's vector work
+#ifndef OPHIP_FINE_INTERLEAVE
+#define OPHIP_FINE_INTERLEAVE 0
+#endif
+#if OPHIP_FINE_INTERLEAVE
+#define OPHIP_FINE_SCHED_FENCE() do {} while (0)
+#else
+#define OPHIP_FINE_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 namespace {
 
 constexpr int CF = 128, WIN = 25, TOK3D = 25;
@@ -645,10 +656,10 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_pair_kern
             const int lk_ = opaque(lane);
             gemm_bf16_ring<2, 1, NS, false, KB, 2>(kv_, rkv, w_hi + OKV + (size_t)(2 * ft) * TS + lk_, w_lo + OKV + (size_t)(2 * ft) * TS + lk_, TS,
                                                    XH + 32 * tt * ROWB, XL + 32 * tt * ROWB, ROWB, 0, lane);
-            __builtin_amdgcn_sched_barrier(0);
+            OPHIP_FINE_SCHED_FENCE();
             f32x16 num = attend_match<NS>(q[0][tt], kv_[0][0], kv_[1][0], cross, scratch + 96 * ft, lane, ones, zeros);
             store_featrow_acc<NS>(num, YH, YL, ROWB, 32 * ft, 32 * tt, lane);
-            __builtin_amdgcn_sched_barrier(0);
+            OPHIP_FINE_SCHED_FENCE();
             if (tt == 0) rkv.fill(w_hi + OKV + (size_t)(2 * ft) * TS + lk_, w_lo + OKV + (size_t)(2 * ft) * TS + lk_, TS);      // the second match's K|V weights
         }
         WRing<1, 2, NS> rm;                      // merge weights travel under the barrier
@@ -804,7 +815,10 @@ int fine_bf16(const float* feat_f, long long fs_b, long long fs_c, long long fs_
     static const bool pair = [] { const char* e = getenv("OPHIP_FINE_PAIR"); return !(e && e[0] == '0'); }();
     if (pair) {
         const int gridp = (max_matches + 1) / 2;
-        const size_t ldsp = (size_t)64 * 1024 + 2048;
+        // (OPHIP_FINE_LDS_PAD: diagnostic -- extra dynamic LDS per workgroup, e.g. 40000 leaves room for ONE workgroup per CU: tools/stamps_fine.py
+        //  then shows the phases of a workgroup that has its SIMDs to itself)
+        static const size_t lds_pad = [] { const char* e = getenv("OPHIP_FINE_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
+        const size_t ldsp = (size_t)64 * 1024 + 2048 + lds_pad;
         if (nsplit == 3) {
             if (int rc = set_lds(fine_pair_kernel<3>, ldsp, "hipFuncSetAttribute(fine_pair)")) return rc;
             OPHIP_LAUNCH("fine_refine", stream, (fine_pair_kernel<3>), dim3(gridp), dim3(256), ldsp, stream, a);

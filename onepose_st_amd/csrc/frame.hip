@@ -104,16 +104,26 @@ int launch_fine_job(int dev, Slot& s, hipEvent_t after = nullptr) {
 }
 
 // OPHIP_FRAME_DEFER_FINE=0: the fine stage follows its own frame's selection at once (the round-2 order)
-// OPHIP_FRAME_KV_FIRST: where the first encoder layer's K / V half is issued (see ophip_frame_enqueue_padded): "prep" (1), "main" (2, default), "off" (0)
+// OPHIP_FRAME_KV_FIRST: where the first encoder layer's K / V half is issued (see ophip_frame_enqueue_padded): "prep" (1), "main" (2), "off" (0).
+// Default: "prep" when the kept-back fine stage runs on the compute stream (there the compute stream's next free point is BEHIND that fine
+// stage; the input stream runs beside it), "main" otherwise.
+bool fine_on_main_enabled();
 int kv_first_mode() {
     static const int mode = [] {
         const char* e = getenv("OPHIP_FRAME_KV_FIRST");
-        if (!e || !e[0]) return 2;
+        if (!e || !e[0]) return fine_on_main_enabled() ? 1 : 2;
         if (e[0] == 'p' || e[0] == '1') return 1;
         if (e[0] == 'm' || e[0] == '2') return 2;
         return 0;
     }();
     return mode;
+}
+
+// OPHIP_FRAME_FINE_ON_MAIN=1: the kept-back fine stage on the compute stream, conf / selection on the side stream (experiment, see
+// ophip_frame_enqueue_padded; default 0 = round 3's assignment, which measured 1-2 % faster again in round 4)
+bool fine_on_main_enabled() {
+    static const bool on = [] { const char* e = getenv("OPHIP_FRAME_FINE_ON_MAIN"); return e && e[0] == '1'; }();
+    return on;
 }
 
 bool defer_fine_enabled() {
@@ -324,16 +334,26 @@ extern "C" int ophip_frame_enqueue_padded(const ophip_frame_desc* d, const ophip
                                            b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count,
                                            nsplit_flags, d->lazy_conf ? 1 : 4, qmask, qscale, s_main));      // (lazy form: its candidate pass is a second matrix-bound tile pass)
         FR_HIP(hipEventRecord(slot->enc_done, s_main), "hipEventRecord(similarity)");
+        // Which of the two halves that follow the similarity tiles stays on the compute stream (OPHIP_FRAME_FINE_ON_MAIN, default 0):
+        //   0: this frame's HBM-bound half (statistics merge, conf, selection) does; the previous frame's fine stage runs on the side stream.
+        //   1: the fine stage does (the next encoder then follows it on the same hardware queue: ~2 us instead of the 10-17 us of a
+        //      cross-stream event) and the HBM-bound half goes to the side stream.  Measured in round 3 (equal) and again in round 4 with
+        //      the two-kernel selection: 1 362 against 1 391 frames/s, three interleaved 100-step runs each -- the side stream's kernels
+        //      start 10-17 us later behind THEIR cross-stream edge and the fine stage, first in its queue, takes the chip before them.
+        const bool fine_on_main = fine_on_main_enabled() && !d->lazy_conf;
+        const hipStream_t s_tail = fine_on_main ? s_fine : s_main;          // where this frame's merge / conf / selection run
+        if (fine_on_main) FR_HIP(hipStreamWaitEvent(s_tail, slot->enc_done, 0), "hipStreamWaitEvent(similarity)");
         FR_CHECK(ophip_coarse_match_masked(x3, x2, kpts, kpts_bs, B, N, M, d->wc, d->temperature, d->thr, d->border_rm, d->scale_c, conf, cws,
                                            b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count,
-                                           nsplit_flags, d->lazy_conf ? 2 : (8 | 2), qmask, qscale, s_main));
-        FR_HIP(hipEventRecord(slot->coarse_done, s_main), "hipEventRecord(coarse)");
-        // the kept-back fine stage of the previous frame: on the side stream, behind this frame's similarity tiles, beside the rest.
-        // Submitted AFTER this frame's confidence pass and selection, so that those are in their hardware queue first (HIP maps streams
-        // onto a few hardware queues; the read-back stream's wait for that fine stage may share one with another stream of the frame).
-        // (Frames alternating between the two streams -- t + 2 right behind fine(t) on one queue, one cross-stream edge per frame instead
-        // of two -- was built and measured: 1 429 against 1 470 frames/s; the read-back's packets then sit between fine(t) and encoder(t + 2).)
-        if (kept) FR_CHECK(launch_fine_job(dev, *kept, slot->enc_done));
+                                           nsplit_flags, d->lazy_conf ? 2 : (8 | 2), qmask, qscale, s_tail));
+        FR_HIP(hipEventRecord(slot->coarse_done, s_tail), "hipEventRecord(coarse)");
+        // the kept-back fine stage of the previous frame, behind this frame's similarity tiles and beside the rest.  Submitted AFTER this
+        // frame's confidence pass and selection, so that those are in their hardware queue first (HIP maps streams onto a few hardware
+        // queues; the read-back stream's wait for that fine stage may share one with another stream of the frame).
+        // (Frames alternating between the two streams -- t + 2 right behind fine(t) on one queue -- was built and measured in round 3:
+        //  1 429 against 1 470 frames/s; the read-back's packets then sat between fine(t) and encoder(t + 2).)
+        if (kept) FR_CHECK(launch_fine_job(dev, *kept, kept->job.s_fine == s_main ? nullptr : slot->enc_done));      // (on the compute stream: behind the tiles by stream order, and behind its own selection's event)
+        if (fine_on_main) s_fine = s_main;                                   // this frame's own fine stage (launched by its successor) runs on the compute stream
         FineJob& j = slot->job;
         j.s_main = s_main; j.s_fine = s_fine; j.s_copy = s_copy;
         j.ff = ff; j.fs_b = fs_b; j.fs_c = fs_c; j.fs_y = fs_y; j.fs_x = fs_x; j.hf = d->hf; j.wf = d->wf;
