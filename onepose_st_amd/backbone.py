@@ -1,8 +1,8 @@
-"""ResNet-FPN 8->2 image backbone (PyTorch-ROCm / MIOpen; *not* a hand-written kernel).
+"""ResNet-FPN 8->2 image backbone: the PARAMETER HOLDER under the reference's keys, and the PyTorch-ROCm (MIOpen) path of the
+exact-f32 debug mode.  The default (bf16-pipe) modes run the backbone on this repo's own HIP convolution kernels
+(``csrc/conv.hip`` through ``backbone_hip.py``, SURVEY section 8(f)-1 / DESIGN.md section 4b), which read the weights held here.
 
-SURVEY section 8(f)-1: the backbone runs inside ``forward`` before the north_star hot
-path and is kept on stock PyTorch-ROCm convolutions.  This module exists so that the
-drop-in class accepts the reference's full ``state_dict`` (``backbone.*`` keys, 107
+This module exists so that the drop-in class accepts the reference's full ``state_dict`` (``backbone.*`` keys, 107
 tensors) and the reference's ``query_image`` input.  Architecture and parameter names
 follow ``src/models/OnePosePlus/backbone/resnet.py:20-44,85-164`` (BasicBlock x2 per
 stage, dims 128/196/256, FPN with bilinear ``align_corners=True`` upsampling); the

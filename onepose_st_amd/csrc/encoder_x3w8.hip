@@ -1,6 +1,7 @@
-// Coarse LoFTR encoder layer, split-bf16, 48-token workgroups of EIGHT waves (two per SIMD).  Same mathematics, data layout,
-// K/V slab format and kv_sum as csrc/encoder_x3.hip (reference: loftr_module/transformer.py:65-94,146-159,
-// linear_attention.py:29-61); what changes is the split of a workgroup's work over waves:
+// Coarse LoFTR encoder layer, split-bf16, 48-token workgroups of EIGHT waves (two per SIMD).  Same mathematics as the exact-f32 layer
+// csrc/encoder.hip (reference: loftr_module/transformer.py:65-94,146-159, linear_attention.py:29-61); K / V partial slabs of
+// KV_PART_FLOATS floats per workgroup, summed in fixed order by kv_sum_w8_kernel below.  (Round 2's four-wave kernel, whose file this
+// one replaced in round 3, had the same data layout; what the eight-wave form changed is the split of a workgroup's work over waves:)
 //
 //   * wave fw = head fw owns 32 of the 256 output features (two 16-row feature tiles) of all three token tiles, so every weight
 //     fragment still enters the CU once -- but a SIMD now holds two waves, and while one of them is stuck issuing a 1 KiB buffer
