@@ -357,7 +357,7 @@ def main():
     n_inliers = int(poses[-1][1]) if poses else -1
 
     own_dt = [0.0]          # this rank's own seconds of the last timed region (before the max over ranks)
-    HOT_STEPS = int(os.environ.get("OPHIP_BENCH_HOT_STEPS", "8"))          # untimed matcher-only frames right before every timed region (see timed_region)
+    HOT_STEPS = int(os.environ.get("OPHIP_BENCH_HOT_STEPS", "32"))          # untimed matcher-only frames right before every timed region (see timed_region)
 
     def timed_region(active_pool):
         """W warm-up + exactly K timed steps with `active_pool` solving the poses (None: matcher only); returns seconds (max over ranks)"""
@@ -545,6 +545,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "setup_steps_untimed": setup_steps + (1 if args.main_region_only else (5 if args.precision != "f32" else 4)) * (args.warmup + HOT_STEPS),      # settle blocks before the W warm-up steps + the warm-ups (and hot steps) of the side regions
+        "hot_steps_untimed_before_each_timed_region": HOT_STEPS,      # matcher-only frames that bring the GPU out of its post-idle clock transient (see timed_region)
         "ms_per_step": dt / args.steps * 1e3,
         "value_matcher_only": (frames_total / dt_matcher) if dt_matcher else None,
         "lazy_conf_frames_rerun_eagerly": lazy_reruns,

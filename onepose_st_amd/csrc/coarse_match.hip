@@ -619,13 +619,20 @@ struct ConfArgs {
     unsigned* colmax_bits;   // [B][M] column maxima as float bits (conf >= 0, so unsigned order == float order)
     int N, M, nspan, spanw, nrb;
     float thr;               // match threshold (strict >): entries at or below it are never tracked
+    int rows;                // rows per workgroup (a multiple of 2 * CONF_RB, <= CONF_ROWS_MAX)
 };
 
 #ifndef OPHIP_CONF_ROWS
 #define OPHIP_CONF_ROWS 32
 #endif
-constexpr int CONF_ROWS = OPHIP_CONF_ROWS;      // rows per workgroup (measured at c2: 16 -> 106 us, 32 -> 90, 48 -> 114, 64 -> 132: fewer, less contended column atomics vs grid fill)
-constexpr int CONF_RB = 2;         // rows per pipeline stage (two stages in flight)
+constexpr int CONF_ROWS = OPHIP_CONF_ROWS;      // default rows per workgroup (measured ALONE at c2 with CONF_RB = 2: 16 -> 106 us, 32 -> 90, 48 -> 114, 64 -> 132: fewer, less contended column atomics vs grid fill)
+constexpr int CONF_ROWS_MAX = 512;              // OPHIP_CONF_ROWS_RT (run time): more rows per workgroup = fewer workgroups holding slots beside the fine stage.
+                                                // Round 4, c2, in the pipeline (frames/s, 100 steps, interleaved, two boxes): rows 32 / 48 / 64 / 80 / 96 at CONF_RB 2 and 4 all within
+                                                // the +-3 % run-to-run spread (1 428-1 472), 128 and 256 worse (the pass, 143 / 275 us alone, becomes the frame's longest kernel)
+#ifndef OPHIP_CONF_RB
+#define OPHIP_CONF_RB 2
+#endif
+constexpr int CONF_RB = OPHIP_CONF_RB;          // rows per pipeline stage (two stages in flight): what a workgroup keeps in flight is 2 * CONF_RB * CONF_U KiB per wave
 #ifndef OPHIP_CONF_U
 #define OPHIP_CONF_U 3
 #endif
@@ -637,13 +644,17 @@ constexpr int CONF_U = OPHIP_CONF_U;
 
 template <bool VEC, bool FAST>
 __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
-    __shared__ float red_v[4][CONF_ROWS];
-    __shared__ int red_j[4][CONF_ROWS];
-    __shared__ int red_c[4][CONF_ROWS];
+    // dynamic LDS, p.rows rows: [4][rows] best value | [4][rows] its column | [4][rows] tie count | [rows][2] row statistics
+    extern __shared__ __attribute__((aligned(16))) float conf_lds[];
+    const int ROWS = p.rows;
+    float* red_v = conf_lds;
+    int* red_j = reinterpret_cast<int*>(conf_lds + 4 * ROWS);
+    int* red_c = reinterpret_cast<int*>(conf_lds + 8 * ROWS);
+    float* rstat_s = conf_lds + 12 * ROWS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int span = blockIdx.x, rb = blockIdx.y, b = blockIdx.z;
     const int jb = span * p.spanw, je = min(p.M, jb + p.spanw);
-    const int i0 = rb * CONF_ROWS;
+    const int i0 = rb * ROWS;
     float* conf = p.conf + (size_t)b * p.N * p.M;
     const float* cst = p.colstat + (size_t)b * p.M * 2;
     const float* rst = p.rowstat + (size_t)b * p.N * 2;
@@ -652,13 +663,12 @@ __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
     // row pair).  Exact mode: (max, 1 / sum) of the true maxima.  bf16 modes: the merged partials' reference is a tile maximum,
     // possibly far above a row's own, so both its inverse sum and its exponent can leave f32's range when multiplied out; the
     // log form conf = exp((s - M_c - log E_c) + (s - M_r - log E_r)) has every term <= 0 and needs no division at all.
-    __shared__ float rstat_s[CONF_ROWS][2];
-    if (tid < CONF_ROWS) {
-        const int i = min(i0 + tid, p.N - 1);
-        rstat_s[tid][0] = rst[2 * i];
-        rstat_s[tid][1] = FAST ? logf(rst[2 * i + 1]) : 1.0f / rst[2 * i + 1];
+    for (int t = tid; t < ROWS; t += 256) {
+        const int i = min(i0 + t, p.N - 1);
+        rstat_s[2 * t] = rst[2 * i];
+        rstat_s[2 * t + 1] = FAST ? logf(rst[2 * i + 1]) : 1.0f / rst[2 * i + 1];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { red_v[w][tid] = -1.f; red_j[w][tid] = 0x7fffffff; red_c[w][tid] = 0; }
+        for (int w = 0; w < 4; ++w) { red_v[w * ROWS + t] = -1.f; red_j[w * ROWS + t] = 0x7fffffff; red_c[w * ROWS + t] = 0; }
     }
     float cm[CONF_U][4], cinv[CONF_U][4], cbest[CONF_U][4];
 #pragma unroll
@@ -670,7 +680,7 @@ __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
             cinv[u][e] = (j < je) ? (FAST ? logf(cst[2 * j + 1]) : 1.0f / cst[2 * j + 1]) : (FAST ? 0.f : 1.f);
             cbest[u][e] = 0.f;
         }
-    const int nrows = min(CONF_ROWS, p.N - i0);
+    const int nrows = min(ROWS, p.N - i0);
     // software pipeline over batches of CONF_RB rows: the loads of batch k + 1 are in flight while batch k is processed
     float s[2][CONF_RB][CONF_U][4];
     auto load_batch = [&](int r0, float (&dst)[CONF_RB][CONF_U][4]) {
@@ -704,7 +714,7 @@ __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
             const int rr = r0 + q;
             if (rr < nrows) {
                 const int i = i0 + rr;
-                const float rm = rstat_s[rr][0], rinv = rstat_s[rr][1];
+                const float rm = rstat_s[2 * rr], rinv = rstat_s[2 * rr + 1];
                 float* row = conf + (size_t)i * p.M;
                 bool hit = false;
 #pragma unroll
@@ -757,7 +767,7 @@ __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
                         cj = min(cj, __shfl_xor(cj, o, 64));
                         cc += __shfl_xor(cc, o, 64);
                     }
-                    if (lane == 0) { red_v[wave][rr] = wv; red_j[wave][rr] = cj; red_c[wave][rr] = cc; }
+                    if (lane == 0) { red_v[wave * ROWS + rr] = wv; red_j[wave * ROWS + rr] = cj; red_c[wave * ROWS + rr] = cc; }
                 }
             }
         }
@@ -771,16 +781,16 @@ __global__ __launch_bounds__(256) void conf_kernel(ConfArgs p) {
         if (r0 + CONF_RB < nrows) process_batch(r0 + CONF_RB, s[1]);
     }
     __syncthreads();
-    if (tid < nrows) {
-        float v = red_v[0][tid];
-        int j = red_j[0][tid], c = red_c[0][tid];
+    for (int t = tid; t < nrows; t += 256) {
+        float v = red_v[t];
+        int j = red_j[t], c = red_c[t];
 #pragma unroll
         for (int w = 1; w < 4; ++w) {
-            const float v2 = red_v[w][tid];
-            if (v2 > v) { v = v2; j = red_j[w][tid]; c = red_c[w][tid]; }
-            else if (v2 == v) { j = min(j, red_j[w][tid]); c += red_c[w][tid]; }
+            const float v2 = red_v[w * ROWS + t];
+            if (v2 > v) { v = v2; j = red_j[w * ROWS + t]; c = red_c[w * ROWS + t]; }
+            else if (v2 == v) { j = min(j, red_j[w * ROWS + t]); c += red_c[w * ROWS + t]; }
         }
-        float* o = p.rowbest + (((size_t)b * p.nspan + span) * p.N + i0 + tid) * 3;
+        float* o = p.rowbest + (((size_t)b * p.nspan + span) * p.N + i0 + t) * 3;
         o[0] = v; o[1] = __int_as_float(j); o[2] = __int_as_float(c);
     }
     // column maxima: max is order independent, so an integer atomicMax on the float bits is deterministic
@@ -984,7 +994,14 @@ int coarse_impl(int parts, int border_mode, int wi, double temp_eps,
     if (planes_ready && nsplit == 0) return ophip_bad_arg(__func__, "fragment planes are an input of the bf16 modes only");
     if (lazy && nsplit == 0) return ophip_bad_arg(__func__, "conf == NULL (lazy conf_matrix) needs a bf16 mode: the exact-f32 mode always materialises it");
     hipStream_t stream = (hipStream_t)stream_;
-    const int ntr = (N + TM - 1) / TM, ntc = (M + TN - 1) / TN, nrb = (N + CONF_ROWS - 1) / CONF_ROWS;
+    // rows per conf workgroup: OPHIP_CONF_ROWS_RT (a multiple of 2 * CONF_RB up to CONF_ROWS_MAX), default CONF_ROWS
+    static const int conf_rows = [] {
+        const char* e = getenv("OPHIP_CONF_ROWS_RT");
+        int r = e ? atoi(e) : CONF_ROWS;
+        r = r < 2 * CONF_RB ? 2 * CONF_RB : (r > CONF_ROWS_MAX ? CONF_ROWS_MAX : r);
+        return r / (2 * CONF_RB) * (2 * CONF_RB);
+    }();
+    const int ntr = (N + TM - 1) / TM, ntc = (M + TN - 1) / TN, nrb = (N + conf_rows - 1) / conf_rows;
     const int nspan = conf_nspan(M), spanw = conf_spanw(M);
     const CoarseWs ws = coarse_ws(B, N, M);
     float* rowpart = workspace + ws.rowpart;
@@ -1041,12 +1058,13 @@ int coarse_impl(int parts, int border_mode, int wi, double temp_eps,
     }
 #undef OPHIP_SIM_CASE
     if (do_conf && !lazy) {
-        ConfArgs fa{conf, rowstat, colstat, rowbest, reinterpret_cast<unsigned*>(colmax), N, M, nspan, spanw, nrb, thr};
+        ConfArgs fa{conf, rowstat, colstat, rowbest, reinterpret_cast<unsigned*>(colmax), N, M, nspan, spanw, nrb, thr, conf_rows};
+        const size_t clds = (size_t)14 * conf_rows * sizeof(float);
         const bool vec = M % 4 == 0, fast = nsplit != 0;
-        if (vec && fast) OPHIP_LAUNCH("conf", stream, (conf_kernel<true, true>), dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
-        else if (vec) OPHIP_LAUNCH("conf", stream, (conf_kernel<true, false>), dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
-        else if (fast) OPHIP_LAUNCH("conf", stream, (conf_kernel<false, true>), dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
-        else OPHIP_LAUNCH("conf", stream, (conf_kernel<false, false>), dim3(nspan, nrb, B), dim3(256), 0, stream, fa);
+        if (vec && fast) OPHIP_LAUNCH("conf", stream, (conf_kernel<true, true>), dim3(nspan, nrb, B), dim3(256), clds, stream, fa);
+        else if (vec) OPHIP_LAUNCH("conf", stream, (conf_kernel<true, false>), dim3(nspan, nrb, B), dim3(256), clds, stream, fa);
+        else if (fast) OPHIP_LAUNCH("conf", stream, (conf_kernel<false, true>), dim3(nspan, nrb, B), dim3(256), clds, stream, fa);
+        else OPHIP_LAUNCH("conf", stream, (conf_kernel<false, false>), dim3(nspan, nrb, B), dim3(256), clds, stream, fa);
         OPHIP_CHECK_LAUNCH();
     }
     if (parts & 2) {
