@@ -121,7 +121,8 @@ std::atomic<long long> g_roctx_ranges{0};
 int roctx_load() {
     if (g_roctx_push) return 0;
     void* lib = nullptr;
-    for (const char* name : {"libroctx64.so.4", "libroctx64.so", "librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so"}) {
+    // rocprofv3 (--marker-trace) intercepts the rocprofiler-sdk library's ranges; libroctx64 is the older roctracer one
+    for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
         lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (lib) break;
     }
