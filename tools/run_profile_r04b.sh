@@ -19,3 +19,8 @@ for f in $O/marker/*/*marker*.csv; do head -60 $f > $O/marker_sample.csv; wc -l 
 python3 bench.py --steps 20 --warmup 5 > $O/bench20_final.json 2> $O/bench20_final.err
 tail -c 600 $O/bench20_final.json
 find $O -name "*.csv" -size +3M -delete
+# where a 20-step region's time goes on the host side (per-step enqueue / wait / finish / submit and the tail after the last frame)
+for i in 1 2 3; do OPHIP_BENCH_TRACE=1 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --main-region-only --no-side-legs > $O/trace20_$i.json 2> $O/trace20_$i.err; tail -2 $O/trace20_$i.err; python3 -c "
+import json,sys
+d=json.loads(open('$O/trace20_$i.json').read().strip().splitlines()[-1]); print('value', round(d['value'],1), 'ceiling', round(d['host']['pnp_ceiling_fps']))"; done
+for i in 1 2; do OPHIP_BENCH_TRACE=1 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --main-region-only --no-side-legs --no-pnp > $O/trace20np_$i.json 2> $O/trace20np_$i.err; tail -1 $O/trace20np_$i.err; done
