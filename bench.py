@@ -597,7 +597,7 @@ def main():
             "library_build_stamp": hip.build_stamp(),
             # SQ_VALU_MFMA_BUSY_CYCLES of the committed counter pass over (1024 SIMDs x this run's launch time x the 2.4 GHz the
             # 2.5 PFLOP/s peak is quoted at): the matrix pipe's busy share at PEAK clock.  The clock the chip really holds in this
-            # kernel is the in-kernel s_memtime / s_memrealtime ratio in profiles/r03_stamps_enc_x3w8.txt
+            # kernel is the in-kernel s_memtime / s_memrealtime ratio in profiles/r04_stamps_enc_x3w8.txt
             "mfma_busy_frac_at_peak_clock": (mfma_busy / (1024.0 * avg_ms * 1e-3 * 2.4e9)) if (mfma_busy and launches) else None,
             "launches": launches,
             "launches_sampled_every": time_every,
