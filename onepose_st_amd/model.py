@@ -314,13 +314,27 @@ class OnePosePlus_model(nn.Module):
                 and len(self.loftr_coarse.layer_names) <= 16):
             x3d_ext = None
             if self.cache_object:
+                # the reference keeps the object block resident across frames (OnePosePlus_inference_dataset.py:157-169): its keypoint encoding
+                # (rows a2 + a3) is computed once per (object tensors, weights) and handed to the frame call as an external input.  A MISS
+                # computes it here, with the same two kernels the frame call would run, and then takes the one-call path like a hit
+                # (until round 4 a miss fell back to the stage-by-stage host path).
                 ckey = (str(dev), B, N, kpts_d.data_ptr(), kpts_d._version, desc_in_d.data_ptr(), desc_in_d._version, id(W))
-                if self._obj_cache is not None and self._obj_cache[0] == ckey:
-                    x3d_ext = self._obj_cache[1]
-                    main.wait_event(self._obj_cache[2])
-            if not self.cache_object or x3d_ext is not None:          # a cache miss takes the stage-by-stage path below, which fills the cache
-                return self._enqueue_frame_call(data, feat_c, feat_f, kpts_d, desc_in_d, desc_fine_d, x3d_ext, W, dev, main, fkey,
-                                                B, N, M, hc, wc, hf, wf, host_copy, inputs_ready, lazy, rerun, qmask, qscale)
+                if self._obj_cache is None or self._obj_cache[0] != ckey:
+                    x3d_new = torch.empty(B, N, C, **f32)
+                    if self.kpt_3d_pos_encoding is not None:
+                        stats = torch.empty(4 * B + 4, **f32)
+                        lib_call("ophip_kpt_encode", P(kpts_d), bstride(kpts_d), P(desc_in_d), bstride(desc_in_d), P(W["kpt"]),
+                                 P(stats), P(x3d_new), B, N, hip.stream_handle())
+                    else:
+                        src = desc_in_d if desc_in_d.shape[0] == B else desc_in_d.expand(B, -1, -1).contiguous()
+                        lib_call("ophip_transpose_cl", P(src), P(x3d_new), B, C, N, hip.stream_handle())
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    self._obj_cache = (ckey, x3d_new, ev, kpts_d, desc_in_d)          # the key's tensors stay alive with the entry
+                x3d_ext = self._obj_cache[1]
+                main.wait_event(self._obj_cache[2])
+            return self._enqueue_frame_call(data, feat_c, feat_f, kpts_d, desc_in_d, desc_fine_d, x3d_ext, W, dev, main, fkey,
+                                            B, N, M, hc, wc, hf, wf, host_copy, inputs_ready, lazy, rerun, qmask, qscale)
         if fkey in self._frame_call_pending:                          # order this frame's encoder behind the C path's last fine stage
             self._frame_call_pending.discard(fkey)
             lib_call("ophip_frame_order_after_fine", ctypes.c_void_p(main.cuda_stream))

@@ -940,6 +940,8 @@ def test_object_cache_is_bit_identical(sd, cfg, dev):
     cached = OnePosePlus_model(ccfg).eval()
     cached.load_state_dict(sd, strict=True)
     cached.to(dev)
+    from onepose_st_amd import ops
+    n_calls = ops.CALLS["frame_enqueue"]
     for f in frames:
         a, b = dict(obj), dict(obj)
         plain.forward_features(a, f["feat_c"].to(dev), f["feat_f"].to(dev), f["image_hw"])
@@ -947,6 +949,7 @@ def test_object_cache_is_bit_identical(sd, cfg, dev):
         assert len(a["i_ids"]) > 200
         for k in keys:
             assert torch.equal(a[k], b[k]), k
+    assert ops.CALLS["frame_enqueue"] == n_calls + 6            # the cache MISS (first frame) takes the one-call frame path like the hits
     entry = cached._obj_cache
     assert entry is not None
     d = dict(obj)
