@@ -267,20 +267,18 @@ def main():
         pend.wait()
         host_t["wait"] += time.perf_counter() - t
         t = time.perf_counter()
-        data = pend.finish()
-        host_t["finish"] += time.perf_counter() - t
-        t = time.perf_counter()
-        if pend.host is not None:
-            last_host[0] = pend.host
-        if pool is not None:
-            hst = pend.host
-            if B == 1:
-                pending.append(pool.submit(hst["mkpts_2d"], hst["mkpts_3d_db"]))
-            else:
-                for bb in range(B):
-                    sel = hst["b_ids"] == bb
-                    pending.append(pool.submit(hst["mkpts_2d"][sel], hst["mkpts_3d_db"][sel]))
-        host_t["submit"] += time.perf_counter() - t
+
+        def submit(hst):          # called by finish() as soon as the host-side matches exist: the pose solve starts before the data dict is filled
+            last_host[0] = hst
+            if pool is not None:
+                if B == 1:
+                    pending.append(pool.submit(hst["mkpts_2d"], hst["mkpts_3d_db"]))
+                else:
+                    for bb in range(B):
+                        sel = hst["b_ids"] == bb
+                        pending.append(pool.submit(hst["mkpts_2d"][sel], hst["mkpts_3d_db"][sel]))
+        data = pend.finish(on_host=submit)
+        host_t["finish"] += time.perf_counter() - t          # (includes the submit since round 4)
         return data
 
     # frames alternate over `--streams` HIP streams: consecutive frames are independent, so the single-workgroup
