@@ -500,7 +500,7 @@ def main():
     # HBM bytes and matrix-pipe busy cycles per launch of the roofline kernel: from the committed counter passes (separate
     # rocprofv3 --pmc runs, tools/run_profile_r03.sh), not live -- and quoted ONLY when those passes ran on the build that is
     # running now (the pmc file records ophip_build_stamp): a kernel change without a re-profile prints null, never a stale number
-    traffic, mfma_busy, pmc_note = None, None, None
+    traffic, mfma_busy, pmc_note, coarse_stage = None, None, None, None
     stem = {"bf16x3": "enc_x3w8_kernel<false,", "bf16": "attn_apply_bf16_kernel<1", "f32": "attn_apply_kernel"}[args.precision]
     try:
         pmc_path = sorted(p for p in os.listdir(os.path.join(REPO, "profiles")) if p.endswith("_pmc.json"))[-1]
@@ -513,6 +513,19 @@ def main():
                 traffic = hits[0]["hbm_bytes_per_launch"]
                 mfma_busy = hits[0].get("SQ_VALU_MFMA_BUSY_CYCLES_median")
                 pmc_note = f"profiles/{pmc_path} (build {hip.build_stamp()})"
+                # the HBM-bound stage of the path (dual softmax + mutual-NN): counter bytes per frame of its kernels against the
+                # algorithmic figure (inputs once + ONE f32 write of conf_matrix), and the similarity tile kernel's matrix-pipe share
+                kern = pmc_all["kernels"]
+                pick = lambda part: [v for k, v in kern.items() if part in k]
+                parts_ = {n: pick(n) for n in ("sim_frag_kernel<3, 0>", "conf_kernel", "stat_combine_kernel", "select_decide_kernel", "select_place_kernel")}
+                if all(parts_.values()):
+                    coarse_stage = {
+                        "hbm_bytes_per_frame": sum(v[0]["hbm_bytes_per_launch"] for v in parts_.values()),
+                        "algorithmic_bytes_per_frame": float((n_points + M) * 256 * 2 + 4 * n_points * M),
+                        "per_kernel_bytes": {n.split("<")[0]: v[0]["hbm_bytes_per_launch"] for n, v in parts_.items()},
+                        "sim_frag_mfma_busy_frac_at_peak_clock": parts_["sim_frag_kernel<3, 0>"][0].get("mfma_busy_frac"),
+                        "counters_from": pmc_note,
+                    }
     except (OSError, KeyError, ValueError, IndexError):
         pass
 
@@ -603,6 +616,8 @@ def main():
             "flops_per_launch": flops,
         },
     }
+    if coarse_stage is not None:
+        result["coarse_stage"] = coarse_stage
     if args.roofline_kernel == "conf":
         # the HBM-bound kernel of the path (dual softmax + mutual-NN): conf_kernel reads the stored similarity once and writes
         # conf_matrix once -- 2 x 4 B per (i, j) pair.  The STAGE's algorithmic traffic (inputs once + ONE f32 write of the matrix) is
