@@ -72,8 +72,7 @@ struct FineBArgs {
 // (an fp16 overflow guard, linear_attention.py:52,59) cancels in f32 and is not applied.
 //   3D set: ONE source token, so KV = phi(k3)^T v3 has rank one and the message is v3 * a / (a + eps) with a[token][head] = phi(q) . phi(k3).
 template <int NS>
-__device__ __forceinline__ f32x16 attend_match(f32x16& qt, const f32x16& kt, const f32x16& vt, bool cross, float* strip, int lane,
-                                               const bf16x8&, const bf16x8&) {
+__device__ __forceinline__ f32x16 attend_match(f32x16& qt, const f32x16& kt, const f32x16& vt, bool cross, float* strip, int lane) {
 #pragma clang fp contract(off)                    // every fused multiply-add below is written out: the one-match and the pair kernel stay bit-identical
     const int r = lane & 31, h = lane >> 5;
     const bool is3d = r == TOK3D;                 // on the token (lane) axis of D[feature][token] tiles
@@ -325,10 +324,6 @@ __global__ __launch_bounds__(NM * 256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_refi
     store_featrow_acc<NS>(xres, XH, XL, ROWB, 32 * ft, 32 * tt, lane);
     __syncthreads();
 
-    const bf16x8 zeros = zero_bf8();
-    bf16x8 ones;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
     // this wave's token rows inside the planes
     const char* xh = XH + 32 * tt * ROWB; const char* xl = XL + 32 * tt * ROWB;
     const char* yh = YH + 32 * tt * ROWB; const char* yl = YL + 32 * tt * ROWB;
@@ -352,7 +347,7 @@ __global__ __launch_bounds__(NM * 256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_refi
         rm.fill(w_hi + OM + (size_t)ft * TS + lane, w_lo + OM + (size_t)ft * TS + lane, TS);
         // ---- KV / Ksum of the window set, the 3D token's rank-one message, phi(Q) KV: all in registers (attend_match) ------
         {
-            f32x16 num = attend_match<NS>(q[0][0], kv_[0][0], kv_[1][0], cross, scratch + 96 * (4 * tt + ft), lane, ones, zeros);
+            f32x16 num = attend_match<NS>(q[0][0], kv_[0][0], kv_[1][0], cross, scratch + 96 * (4 * tt + ft), lane);
             store_featrow_acc<NS>(num, YH, YL, ROWB, 32 * ft, 32 * tt, lane);
         }
         __syncthreads();
@@ -625,10 +620,6 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_pair_kern
     for (int tt = 0; tt < 2; ++tt) store_featrow_acc<NS>(xres[tt], XH, XL, ROWB, 32 * ft, 32 * tt, lane);      // X region: disjoint from the staging image
     __syncthreads();
 
-    const bf16x8 zeros = zero_bf8();
-    bf16x8 ones;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 
     for (int l = 0; l < nl; ++l) {
         const char* wl = p.wpack + (size_t)l * LAYER_BYTES;
@@ -657,7 +648,7 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_pair_kern
             gemm_bf16_ring<2, 1, NS, false, KB, 2>(kv_, rkv, w_hi + OKV + (size_t)(2 * ft) * TS + lk_, w_lo + OKV + (size_t)(2 * ft) * TS + lk_, TS,
                                                    XH + 32 * tt * ROWB, XL + 32 * tt * ROWB, ROWB, 0, lane);
             OPHIP_FINE_SCHED_FENCE();
-            f32x16 num = attend_match<NS>(q[0][tt], kv_[0][0], kv_[1][0], cross, scratch + 96 * ft, lane, ones, zeros);
+            f32x16 num = attend_match<NS>(q[0][tt], kv_[0][0], kv_[1][0], cross, scratch + 96 * ft, lane);
             store_featrow_acc<NS>(num, YH, YL, ROWB, 32 * ft, 32 * tt, lane);
             OPHIP_FINE_SCHED_FENCE();
             if (tt == 0) rkv.fill(w_hi + OKV + (size_t)(2 * ft) * TS + lk_, w_lo + OKV + (size_t)(2 * ft) * TS + lk_, TS);      // the second match's K|V weights
