@@ -14,8 +14,9 @@
 //                reduces it to the smallest eigenvector of a 4x4 Schur complement (inverse iteration), projected to SO(3) by
 //                Newton polar iteration, four samples at a time, one per lane of a 4 x double vector; a sample whose DLT is
 //                singular (coplanar 3D points) is solved by P3P on its first three points, the root picked by the other three
-//   scoring    : reprojection error < threshold (pixels) on a float structure-of-arrays copy (AVX2 / AVX-512 clones of
-//                one loop, hypotheses that cannot win any more dropped block by block); a candidate best is re-scored in
+//   scoring    : reprojection error < threshold (pixels) on a float structure-of-arrays copy (AVX2 + FMA intrinsics in the
+//                build pnp.py prefers, clones of one plain loop otherwise; hypotheses that cannot win any more dropped block by
+//                block, the first block as long as the misses a hypothesis may afford); a candidate best is re-scored in
 //                double, which decides; at least min_iters trials (the
 //                reference's pycolmap call runs >= 10 000), then adaptive stopping at the requested confidence
 //   refinement : Levenberg-Marquardt on the inliers (6 dof, analytic Jacobian), inlier set re-evaluated once
@@ -35,6 +36,9 @@
 #include <unistd.h>
 #endif
 #include <vector>
+#if defined(__AVX2__) && defined(__FMA__)
+#include <immintrin.h>
+#endif
 
 namespace {
 
@@ -193,9 +197,90 @@ struct FastPoints {
 };
 
 // inliers and truncated cost of pose (premultiplied by K: 3 x 4 row-major floats) -- the vectorised hot loop of the RANSAC.
-// Scored in blocks of 256 points; after each block the hypothesis is dropped as soon as it can no longer beat the best one
-// (count first, then cost: with `rest` points to go it needs cnt + rest >= best_cnt, and on a possible tie a cost below
-// best_cost, while the cost only grows).  The decision is exactly the one a full pass would take; returns false when dropped.
+// Scored in blocks; after each block the hypothesis is dropped as soon as it can no longer beat the best one (count first, then
+// cost: with `rest` points to go it needs cnt + rest >= best_cnt, and on a possible tie a cost below best_cost, while the cost
+// only grows).  The decision is exactly the one a full pass would take; returns false when dropped.
+//
+// Block schedule (round 4, from cycle counts: 2/3 of a reference-policy frame's host time was this function): neither test can fire
+// before the hypothesis has MISSED n - best_cnt points, so the first block is exactly that long (at least 16 points): on a clean
+// frame (best_cnt = n) a wrong P3P root -- half of all hypotheses -- dies after two vectors instead of a 256-point block, and on a
+// frame with 40 % outliers the first thousand points are one loop without the per-block reductions; 256-point blocks after that.
+inline int first_block(int n, int best_cnt) {
+    int fb = n - best_cnt;
+    fb = fb < 16 ? 16 : fb;
+    return (fb + 7) & ~7;
+}
+
+inline bool keep_scoring(int cnt, float cost, int rest, int best_cnt, float best_cost) {
+    const int reach = cnt + rest;                        // the count if every remaining point were an inlier
+    if (reach < best_cnt || (reach == best_cnt && !(cost < best_cost))) return false;
+    if (cnt <= best_cnt && reach <= best_cnt && !(cost < best_cost)) return false;
+    return true;
+}
+
+#if defined(__AVX2__) && defined(__FMA__)
+// The -mavx2 -mfma build (what pnp.py loads on a CPU that has both): eight points per step, 21 vector instructions (the compiler's
+// version of the loop below spent 26 plus a dozen broadcasts per block): three-FMA rows, one division, masks summed as integers.
+bool score_fast(const FastPoints& F, const float* kp, float thr2, int best_cnt, float best_cost, int* cnt_out, float* cost_out) {
+    const int n = F.n;
+    const float *X = F.x.data(), *Y = F.y.data(), *Z = F.z.data(), *U = F.u.data(), *V = F.v.data();
+    const __m256 k0 = _mm256_set1_ps(kp[0]), k1 = _mm256_set1_ps(kp[1]), k2 = _mm256_set1_ps(kp[2]), k3 = _mm256_set1_ps(kp[3]);
+    const __m256 k4 = _mm256_set1_ps(kp[4]), k5 = _mm256_set1_ps(kp[5]), k6 = _mm256_set1_ps(kp[6]), k7 = _mm256_set1_ps(kp[7]);
+    const __m256 k8 = _mm256_set1_ps(kp[8]), k9 = _mm256_set1_ps(kp[9]), k10 = _mm256_set1_ps(kp[10]), k11 = _mm256_set1_ps(kp[11]);
+    const __m256 vthr = _mm256_set1_ps(thr2), veps = _mm256_set1_ps(1e-12f), one = _mm256_set1_ps(1.0f);
+    int cnt = 0;
+    float cost = 0.f;
+    int i1 = 0;
+    for (int i0 = 0; i0 < n; i0 = i1) {
+        const int len = i0 == 0 ? first_block(n, best_cnt) : 256;
+        i1 = i0 + len < n ? i0 + len : n;
+        __m256i vc = _mm256_setzero_si256();
+        __m256 vs = _mm256_setzero_ps();
+        auto step = [&](int i, __m256i live) {                       // live: all ones, or the lanes of a last partial vector
+            const __m256 x = _mm256_maskload_ps(X + i, live), y = _mm256_maskload_ps(Y + i, live), z = _mm256_maskload_ps(Z + i, live);
+            const __m256 a = _mm256_fmadd_ps(k0, x, _mm256_fmadd_ps(k1, y, _mm256_fmadd_ps(k2, z, k3)));
+            const __m256 b = _mm256_fmadd_ps(k4, x, _mm256_fmadd_ps(k5, y, _mm256_fmadd_ps(k6, z, k7)));
+            const __m256 c = _mm256_fmadd_ps(k8, x, _mm256_fmadd_ps(k9, y, _mm256_fmadd_ps(k10, z, k11)));
+            const __m256 ic = _mm256_div_ps(one, c);
+            const __m256 du = _mm256_fmsub_ps(a, ic, _mm256_maskload_ps(U + i, live)), dv = _mm256_fmsub_ps(b, ic, _mm256_maskload_ps(V + i, live));
+            const __m256 e2 = _mm256_fmadd_ps(du, du, _mm256_mul_ps(dv, dv));
+            const __m256 in = _mm256_and_ps(_mm256_cmp_ps(c, veps, _CMP_GT_OQ), _mm256_cmp_ps(e2, vthr, _CMP_LT_OQ));
+            vc = _mm256_sub_epi32(vc, _mm256_and_si256(_mm256_castps_si256(in), live));
+            vs = _mm256_add_ps(vs, _mm256_and_ps(_mm256_blendv_ps(vthr, e2, in), _mm256_castsi256_ps(live)));
+        };
+        int i = i0;
+        for (; i + 8 <= i1; i += 8) {
+            const __m256 x = _mm256_loadu_ps(X + i), y = _mm256_loadu_ps(Y + i), z = _mm256_loadu_ps(Z + i);
+            const __m256 a = _mm256_fmadd_ps(k0, x, _mm256_fmadd_ps(k1, y, _mm256_fmadd_ps(k2, z, k3)));
+            const __m256 b = _mm256_fmadd_ps(k4, x, _mm256_fmadd_ps(k5, y, _mm256_fmadd_ps(k6, z, k7)));
+            const __m256 c = _mm256_fmadd_ps(k8, x, _mm256_fmadd_ps(k9, y, _mm256_fmadd_ps(k10, z, k11)));
+            const __m256 ic = _mm256_div_ps(one, c);
+            const __m256 du = _mm256_fmsub_ps(a, ic, _mm256_loadu_ps(U + i)), dv = _mm256_fmsub_ps(b, ic, _mm256_loadu_ps(V + i));
+            const __m256 e2 = _mm256_fmadd_ps(du, du, _mm256_mul_ps(dv, dv));
+            const __m256 in = _mm256_and_ps(_mm256_cmp_ps(c, veps, _CMP_GT_OQ), _mm256_cmp_ps(e2, vthr, _CMP_LT_OQ));
+            vc = _mm256_sub_epi32(vc, _mm256_castps_si256(in));
+            vs = _mm256_add_ps(vs, _mm256_blendv_ps(vthr, e2, in));
+        }
+        if (i < i1) {                                                 // only the last block of the list can end inside a vector
+            alignas(32) int lanes[8];
+            for (int l = 0; l < 8; ++l) lanes[l] = i + l < i1 ? -1 : 0;
+            step(i, _mm256_load_si256(reinterpret_cast<const __m256i*>(lanes)));
+        }
+        __m128i c4 = _mm_add_epi32(_mm256_castsi256_si128(vc), _mm256_extracti128_si256(vc, 1));
+        c4 = _mm_add_epi32(c4, _mm_shuffle_epi32(c4, 0x4E));
+        c4 = _mm_add_epi32(c4, _mm_shuffle_epi32(c4, 0xB1));
+        __m128 s4 = _mm_add_ps(_mm256_castps256_ps128(vs), _mm256_extractf128_ps(vs, 1));
+        s4 = _mm_add_ps(s4, _mm_movehl_ps(s4, s4));
+        s4 = _mm_add_ss(s4, _mm_shuffle_ps(s4, s4, 1));
+        cnt += _mm_cvtsi128_si32(c4);
+        cost += _mm_cvtss_f32(s4);
+        if (!keep_scoring(cnt, cost, n - i1, best_cnt, best_cost)) return false;
+    }
+    *cnt_out = cnt;
+    *cost_out = cost;
+    return true;
+}
+#else
 #if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
 __attribute__((target_clones("avx512f", "avx2", "default")))
 #endif
@@ -203,9 +288,10 @@ bool score_fast(const FastPoints& F, const float* kp, float thr2, int best_cnt, 
     int cnt = 0;
     float cost = 0.f;
     const float *X = F.x.data(), *Y = F.y.data(), *Z = F.z.data(), *U = F.u.data(), *V = F.v.data();
-    constexpr int BLK = 256;          // (64 / 64 / 128 / 256-point first blocks were tried in round 4: -6 % on clean frames, +13 % on frames with 40 % outliers, both inside this host's timing noise)
-    for (int i0 = 0; i0 < F.n; i0 += BLK) {
-        const int i1 = i0 + BLK < F.n ? i0 + BLK : F.n;
+    int i1 = 0;
+    for (int i0 = 0; i0 < F.n; i0 = i1) {
+        const int len = i0 == 0 ? first_block(F.n, best_cnt) : 256;
+        i1 = i0 + len < F.n ? i0 + len : F.n;
         int c_b = 0;
         float s_b = 0.f;
 #pragma omp simd reduction(+ : c_b, s_b)
@@ -222,14 +308,13 @@ bool score_fast(const FastPoints& F, const float* kp, float thr2, int best_cnt, 
         }
         cnt += c_b;
         cost += s_b;
-        const int reach = cnt + (F.n - i1);              // the count if every remaining point were an inlier
-        if (reach < best_cnt || (reach == best_cnt && !(cost < best_cost))) return false;
-        if (cnt <= best_cnt && reach <= best_cnt && !(cost < best_cost)) return false;
+        if (!keep_scoring(cnt, cost, F.n - i1, best_cnt, best_cost)) return false;
     }
     *cnt_out = cnt;
     *cost_out = cost;
     return true;
 }
+#endif
 
 struct Problem {
     int n;
@@ -277,9 +362,13 @@ inline vd vsplat(double x) { return vd{x, x, x, x}; }
 inline vd vsel(vl m, vd a, vd b) { return (vd)(((vl)a & m) | ((vl)b & ~m)); }
 inline vd vabs(vd x) { return vsel(x < vsplat(0.0), -x, x); }
 inline vd vsqrt(vd x) {
+#if defined(__AVX2__) && defined(__FMA__)
+    return (vd)_mm256_sqrt_pd((__m256d)x);
+#else
     vd r;
     for (int i = 0; i < 4; ++i) r[i] = std::sqrt(x[i]);
     return r;
+#endif
 }
 inline vd vdet3(const vd* m) {
     return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
@@ -517,16 +606,19 @@ int quartic_real_roots(const double* c, double* roots) {
         if (d1 > -tol) { d1 = std::sqrt(d1 > 0.0 ? d1 : 0.0); y[n++] = 0.5 * (-s + d1); y[n++] = 0.5 * (-s - d1); }
         if (d2 > -tol) { d2 = std::sqrt(d2 > 0.0 ? d2 : 0.0); y[n++] = 0.5 * (s + d2); y[n++] = 0.5 * (s - d2); }
     }
-    for (int i = 0; i < n; ++i) {
-        double x = y[i] - 0.25 * a;
-        for (int it = 0; it < 3; ++it) {
-            const double f = (((c[4] * x + c[3]) * x + c[2]) * x + c[1]) * x + c[0];
-            const double df = ((4.0 * c[4] * x + 3.0 * c[3]) * x + 2.0 * c[2]) * x + c[1];
-            if (std::fabs(df) < 1e-300) break;
-            x -= f / df;
-        }
-        roots[i] = x;
+    // Newton polish on the original polynomial, the (up to four) roots as the lanes of one vector: three steps are three dependent
+    // divisions instead of twelve.  A lane whose derivative vanishes stops moving (the scalar loop's `break`).
+    vd x = vsplat(0.0);
+    for (int i = 0; i < n; ++i) x[i] = y[i] - 0.25 * a;
+    const vd c4 = vsplat(c[4]), c3 = vsplat(c[3]), c2 = vsplat(c[2]), c1 = vsplat(c[1]), c0 = vsplat(c[0]);
+    vl live = vsplat(1.0) > vsplat(0.0);
+    for (int it = 0; it < 3; ++it) {
+        const vd f = (((c4 * x + c3) * x + c2) * x + c1) * x + c0;
+        const vd df = ((vsplat(4.0) * c4 * x + vsplat(3.0) * c3) * x + vsplat(2.0) * c2) * x + c1;
+        live &= vabs(df) >= vsplat(1e-300);
+        x -= vsel(live, f / vsel(live, df, vsplat(1.0)), vsplat(0.0));
     }
+    for (int i = 0; i < n; ++i) roots[i] = x[i];
     return n;
 }
 
@@ -571,33 +663,55 @@ int p3p_poses(const double (*ray)[2], const double (*X)[3], double (*poses)[12])
         for (int j = 0; j < 2; ++j) c[i + j] -= 2.0 * cg * N[i] * D[j];
     double vs[4];
     const int nr = quartic_real_roots(c, vs);
+    if (nr == 0) return 0;
+    // every root through the same straight-line arithmetic, one root per lane (a sample has two real roots as a rule, four at most):
+    // depths -> camera-frame triangle -> its orthonormal frame -> R = E_C E_P^T, t = C_0 - R X_0.  Rejections become a lane mask.
+    const vd one = vsplat(1.0), zero = vsplat(0.0);
+    vd v = one;
+    vl ok = zero > one;                                                  // all lanes off
+    for (int ri = 0; ri < nr; ++ri) {
+        v[ri] = vs[ri];
+        bool good = vs[ri] > 0.0 && std::isfinite(vs[ri]);
+        for (int rj = 0; rj < ri; ++rj) good = good && !(std::fabs(vs[rj] - vs[ri]) < 1e-9 * (1.0 + std::fabs(vs[ri])));      // a double root counted once
+        if (good) ok[ri] = -1;
+    }
+    const vd den = vsplat(D[0]) + vsplat(D[1]) * v;
+    ok &= vabs(den) >= vsplat(1e-12);
+    const vd u = (vsplat(N[0]) + (vsplat(N[1]) + vsplat(N[2]) * v) * v) / vsel(ok, den, one);
+    ok &= u > zero;
+    const vd q = one + u * u - vsplat(2.0 * cg) * u;
+    ok &= q > vsplat(1e-300);
+    const vd s1 = vsqrt(vsplat(c2) / vsel(ok, q, one));
+    const vd sd[3] = {s1, u * s1, v * s1};
+    vd Cc[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int d = 0; d < 3; ++d) Cc[i][d] = sd[i] * vsplat(f[i][d]);
+    // triangle_frame on the lanes
+    vd e1[3] = {Cc[1][0] - Cc[0][0], Cc[1][1] - Cc[0][1], Cc[1][2] - Cc[0][2]}, w[3] = {Cc[2][0] - Cc[0][0], Cc[2][1] - Cc[0][1], Cc[2][2] - Cc[0][2]};
+    const vd n1 = vsqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+    ok &= n1 > vsplat(1e-300);
+    const vd in1 = one / vsel(ok, n1, one);
+    for (vd& t : e1) t *= in1;
+    vd e3[3] = {e1[1] * w[2] - e1[2] * w[1], e1[2] * w[0] - e1[0] * w[2], e1[0] * w[1] - e1[1] * w[0]};
+    const vd n3 = vsqrt(e3[0] * e3[0] + e3[1] * e3[1] + e3[2] * e3[2]);
+    const vd nw = vsqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    ok &= (n3 > vsplat(1e-9) * nw) & (nw > zero);
+    const vd in3 = one / vsel(ok, n3, one);
+    for (vd& t : e3) t *= in3;
+    const vd e2[3] = {e3[1] * e1[2] - e3[2] * e1[1], e3[2] * e1[0] - e3[0] * e1[2], e3[0] * e1[1] - e3[1] * e1[0]};
+    vd ps[12];
+    vd fin_sum = zero;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) ps[i * 4 + j] = e1[i] * vsplat(EP[j * 3]) + e2[i] * vsplat(EP[j * 3 + 1]) + e3[i] * vsplat(EP[j * 3 + 2]);
+        ps[i * 4 + 3] = Cc[0][i] - (ps[i * 4] * vsplat(X[0][0]) + ps[i * 4 + 1] * vsplat(X[0][1]) + ps[i * 4 + 2] * vsplat(X[0][2]));
+        for (int j = 0; j < 4; ++j) fin_sum += vabs(ps[i * 4 + j]);
+    }
+    ok &= fin_sum < vsplat(1e300);                                       // every entry finite (a NaN or an infinity fails the comparison)
     int n = 0;
     for (int ri = 0; ri < nr; ++ri) {
-        const double v = vs[ri];
-        if (!(v > 0.0) || !std::isfinite(v)) continue;
-        bool dup = false;
-        for (int rj = 0; rj < ri; ++rj) dup |= std::fabs(vs[rj] - v) < 1e-9 * (1.0 + std::fabs(v));      // a double root counted once
-        if (dup) continue;
-        const double den = D[0] + D[1] * v;
-        if (std::fabs(den) < 1e-12) continue;
-        const double u = (N[0] + (N[1] + N[2] * v) * v) / den;
-        if (!(u > 0.0)) continue;
-        const double q = 1.0 + u * u - 2.0 * u * cg;
-        if (!(q > 1e-300)) continue;
-        const double s1 = std::sqrt(c2 / q), sd[3] = {s1, u * s1, v * s1};
-        double Cc[3][3];
-        for (int i = 0; i < 3; ++i)
-            for (int d = 0; d < 3; ++d) Cc[i][d] = sd[i] * f[i][d];
-        double EC[9];
-        if (!triangle_frame(Cc[0], Cc[1], Cc[2], EC)) continue;
-        double* ps = poses[n];
-        for (int i = 0; i < 3; ++i) {
-            for (int j = 0; j < 3; ++j) ps[i * 4 + j] = EC[i * 3] * EP[j * 3] + EC[i * 3 + 1] * EP[j * 3 + 1] + EC[i * 3 + 2] * EP[j * 3 + 2];
-            ps[i * 4 + 3] = Cc[0][i] - (ps[i * 4] * X[0][0] + ps[i * 4 + 1] * X[0][1] + ps[i * 4 + 2] * X[0][2]);
-        }
-        bool fin = true;
-        for (int e = 0; e < 12; ++e) fin = fin && std::isfinite(ps[e]);
-        if (fin) ++n;
+        if (!ok[ri]) continue;
+        for (int e = 0; e < 12; ++e) poses[n][e] = ps[e][ri];
+        ++n;
     }
     return n;
 }
