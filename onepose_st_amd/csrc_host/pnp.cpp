@@ -23,6 +23,7 @@
 //   randomness : xorshift64* seeded by the caller -> bit-reproducible
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <condition_variable>
 #include <deque>
@@ -208,7 +209,7 @@ struct FastPoints {
 inline int first_block(int n, int best_cnt) {
     int fb = n - best_cnt;
     fb = fb < 16 ? 16 : fb;
-    return (fb + 7) & ~7;
+    return (fb + 15) & ~15;
 }
 
 inline bool keep_scoring(int cnt, float cost, int rest, int best_cnt, float best_cost) {
@@ -219,9 +220,56 @@ inline bool keep_scoring(int cnt, float cost, int rest, int best_cnt, float best
 }
 
 #if defined(__AVX2__) && defined(__FMA__)
+// Sixteen points per step on a CPU with AVX-512 (chosen once at load time, OPPNP_NO_AVX512=1 keeps the 256-bit loop): the same
+// arithmetic as the loop below, inlier masks in mask registers (counted with a popcount), the last partial vector by a lane mask.
+__attribute__((target("avx512f,avx512vl,fma")))
+bool score_fast_512(const FastPoints& F, const float* kp, float thr2, int best_cnt, float best_cost, int* cnt_out, float* cost_out) {
+    const int n = F.n;
+    const float *X = F.x.data(), *Y = F.y.data(), *Z = F.z.data(), *U = F.u.data(), *V = F.v.data();
+    const __m512 k0 = _mm512_set1_ps(kp[0]), k1 = _mm512_set1_ps(kp[1]), k2 = _mm512_set1_ps(kp[2]), k3 = _mm512_set1_ps(kp[3]);
+    const __m512 k4 = _mm512_set1_ps(kp[4]), k5 = _mm512_set1_ps(kp[5]), k6 = _mm512_set1_ps(kp[6]), k7 = _mm512_set1_ps(kp[7]);
+    const __m512 k8 = _mm512_set1_ps(kp[8]), k9 = _mm512_set1_ps(kp[9]), k10 = _mm512_set1_ps(kp[10]), k11 = _mm512_set1_ps(kp[11]);
+    const __m512 vthr = _mm512_set1_ps(thr2), veps = _mm512_set1_ps(1e-12f), one = _mm512_set1_ps(1.0f);
+    int cnt = 0;
+    float cost = 0.f;
+    int i1 = 0;
+    for (int i0 = 0; i0 < n; i0 = i1) {
+        const int len = i0 == 0 ? first_block(n, best_cnt) : 256;
+        i1 = i0 + len < n ? i0 + len : n;
+        __m512 vs = _mm512_setzero_ps();
+        int c_b = 0;
+        for (int i = i0; i < i1; i += 16) {
+            const __mmask16 live = i + 16 <= i1 ? (__mmask16)0xFFFF : (__mmask16)((1u << (i1 - i)) - 1u);
+            const __m512 x = _mm512_maskz_loadu_ps(live, X + i), y = _mm512_maskz_loadu_ps(live, Y + i), z = _mm512_maskz_loadu_ps(live, Z + i);
+            const __m512 a = _mm512_fmadd_ps(k0, x, _mm512_fmadd_ps(k1, y, _mm512_fmadd_ps(k2, z, k3)));
+            const __m512 b = _mm512_fmadd_ps(k4, x, _mm512_fmadd_ps(k5, y, _mm512_fmadd_ps(k6, z, k7)));
+            const __m512 c = _mm512_fmadd_ps(k8, x, _mm512_fmadd_ps(k9, y, _mm512_fmadd_ps(k10, z, k11)));
+            const __m512 ic = _mm512_div_ps(one, c);
+            const __m512 du = _mm512_fmsub_ps(a, ic, _mm512_maskz_loadu_ps(live, U + i)), dv = _mm512_fmsub_ps(b, ic, _mm512_maskz_loadu_ps(live, V + i));
+            const __m512 e2 = _mm512_fmadd_ps(du, du, _mm512_mul_ps(dv, dv));
+            const __mmask16 in = _mm512_mask_cmp_ps_mask(_mm512_mask_cmp_ps_mask(live, c, veps, _CMP_GT_OQ), e2, vthr, _CMP_LT_OQ);
+            c_b += __builtin_popcount((unsigned)in);
+            vs = _mm512_mask_add_ps(vs, live, vs, _mm512_mask_blend_ps(in, vthr, e2));
+        }
+        cnt += c_b;
+        cost += _mm512_reduce_add_ps(vs);
+        if (!keep_scoring(cnt, cost, n - i1, best_cnt, best_cost)) return false;
+    }
+    *cnt_out = cnt;
+    *cost_out = cost;
+    return true;
+}
+
+inline bool env_on(const char* name) {
+    const char* v = getenv(name);
+    return v && *v && !(v[0] == '0' && !v[1]);
+}
+const bool g_use_512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") && !env_on("OPPNP_NO_AVX512");
+
 // The -mavx2 -mfma build (what pnp.py loads on a CPU that has both): eight points per step, 21 vector instructions (the compiler's
 // version of the loop below spent 26 plus a dozen broadcasts per block): three-FMA rows, one division, masks summed as integers.
 bool score_fast(const FastPoints& F, const float* kp, float thr2, int best_cnt, float best_cost, int* cnt_out, float* cost_out) {
+    if (g_use_512) return score_fast_512(F, kp, thr2, best_cnt, best_cost, cnt_out, cost_out);
     const int n = F.n;
     const float *X = F.x.data(), *Y = F.y.data(), *Z = F.z.data(), *U = F.u.data(), *V = F.v.data();
     const __m256 k0 = _mm256_set1_ps(kp[0]), k1 = _mm256_set1_ps(kp[1]), k2 = _mm256_set1_ps(kp[2]), k3 = _mm256_set1_ps(kp[3]);

@@ -208,3 +208,31 @@ def test_reference_policy_cost_is_reported():
     ms6 = 1e3 * (time.perf_counter() - t0)
     print(f"10 000 trials at 3 000 correspondences, single thread: P3P {ms:.1f} ms, 6-point DLT {ms6:.1f} ms")
     assert _rot_err(pose[:, :3], R) < 0.05 and len(inl) > 2700 and ms < 2000
+
+
+def test_scorer_widths_pick_the_same_pose():
+    """The screening pass exists twice in the AVX2 build (256-bit, and 512-bit on a CPU with AVX-512; OPPNP_NO_AVX512=1 keeps the first):
+    the two sum a hypothesis' float cost in different orders, the double re-score decides either way -- same inlier set, same pose to
+    rounding, on a clean, a noisy and an outlier-heavy frame and on both trial policies.  (On a CPU without AVX-512 both runs take the
+    256-bit loop and the test is trivially true.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = ("import json, numpy as np, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from test_pnp_host import _scene; from onepose_st_amd.pnp import ransac_PnP\n"
+            "out = []\n"
+            "for n, seed, noise, of in ((2800, 3, 0.2, 0.0), (1500, 5, 0.5, 0.4), (300, 7, 1.0, 0.1), (37, 9, 0.3, 0.2)):\n"
+            "    K, uv, X, R, t, _ = _scene(n, seed, noise_px=noise, outlier_frac=of)\n"
+            "    for branch in (True, False):\n"
+            "        pose, _, inl = ransac_PnP(K, uv, X, pnp_reprojection_error=7, use_pycolmap_ransac=branch, min_iters=2000 if branch else None)\n"
+            "        out.append([pose.tolist(), inl.tolist()])\n"
+            "print(json.dumps(out))\n") % (os.path.dirname(os.path.abspath(__file__)), os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    res = []
+    for no512 in ("0", "1"):
+        env = dict(os.environ, OPPNP_NO_AVX512=no512)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True)
+        res.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    for (pa, ia), (pb, ib) in zip(*res):
+        assert ia == ib
+        assert np.allclose(np.array(pa), np.array(pb), rtol=0, atol=1e-9)
