@@ -26,6 +26,9 @@ int oppnp_ransac(const double* K, const float* pts2d, const float* pts3d, int n,
 /* The P3P minimal solver alone: rays3x2 = three normalised image points (x, y) = K^-1 (u, v, 1), X3x3 = their world points;
  * poses4x12 receives up to four [R | t] (row-major); returns their number. */
 int oppnp_p3p(const double* rays3x2, const double* X3x3, double* poses4x12);
+/* The same solver on four samples at once (what the RANSAC loop of `solver` 1 calls; ABI 3): rays4x3x2 / X4x3x3 = four samples as above,
+ * poses4x4x12 receives up to four poses per sample, nsol4 their numbers.  Same roots, same order, same poses as oppnp_p3p to rounding. */
+void oppnp_p3p4(const double* rays4x3x2, const double* X4x3x3, double* poses4x4x12, int* nsol4);
 
 /* Asynchronous pool: library-owned host threads solve poses while the caller keeps feeding the GPU (the per-frame path
  * has no Python in it).  submit copies its inputs and returns a ticket 0, 1, 2, ...; wait_all blocks until every

@@ -764,6 +764,184 @@ int p3p_poses(const double (*ray)[2], const double (*X)[3], double (*poses)[12])
     return n;
 }
 
+// ---- P3P on four samples at once ---------------------------------------------------------------------------------------------
+// The solver above is one long dependency chain (bearings -> quartic -> resolvent cubic -> roots -> polish -> depths -> two square
+// roots and two divisions per triangle frame -> pose): ~900 cycles of latency that a RANSAC trial cannot hide.  Four samples, one per
+// lane of a 4 x double vector, go through the same chain together.  Per lane the arithmetic is the scalar solver's, statement by
+// statement (same thresholds, same root order: the -s pair before the +s pair); the two places where samples take different paths are
+// handled without leaving the lanes: the resolvent cubic's closed form (cbrt or cos / acos by the sign of its discriminant) is
+// evaluated per lane and polished on the lanes, and a biquadratic quartic (q = 0: a symmetric configuration) sends its lane through
+// the scalar solver.  nsol[l] poses of sample l in poses[l][0 .. nsol[l]).
+inline vl vfinite(vd x) { return (x - x) == vsplat(0.0); }
+
+struct VFrame { vd e[9]; vl ok; };                                       // E[i * 3 + k]: component i of axis k, like triangle_frame
+
+inline VFrame triangle_frame4(const vd* Q0, const vd* Q1, const vd* Q2) {
+    const vd one = vsplat(1.0), zero = vsplat(0.0);
+    VFrame F;
+    vd e1[3] = {Q1[0] - Q0[0], Q1[1] - Q0[1], Q1[2] - Q0[2]}, w[3] = {Q2[0] - Q0[0], Q2[1] - Q0[1], Q2[2] - Q0[2]};
+    const vd n1 = vsqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+    F.ok = n1 > vsplat(1e-300);
+    const vd in1 = one / vsel(F.ok, n1, one);
+    for (vd& t : e1) t *= in1;
+    vd e3[3] = {e1[1] * w[2] - e1[2] * w[1], e1[2] * w[0] - e1[0] * w[2], e1[0] * w[1] - e1[1] * w[0]};
+    const vd n3 = vsqrt(e3[0] * e3[0] + e3[1] * e3[1] + e3[2] * e3[2]);
+    const vd nw = vsqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    F.ok &= (n3 > vsplat(1e-9) * nw) & (nw > zero);
+    const vd in3 = one / vsel(F.ok, n3, one);
+    for (vd& t : e3) t *= in3;
+    const vd e2[3] = {e3[1] * e1[2] - e3[2] * e1[1], e3[2] * e1[0] - e3[0] * e1[2], e3[0] * e1[1] - e3[1] * e1[0]};
+    for (int i = 0; i < 3; ++i) { F.e[i * 3] = e1[i]; F.e[i * 3 + 1] = e2[i]; F.e[i * 3 + 2] = e3[i]; }
+    return F;
+}
+
+void p3p_poses4(const double (*ray)[3][2], const double (*X)[3][3], double (*poses)[4][12], int* nsol) {
+    const vd one = vsplat(1.0), zero = vsplat(0.0);
+    vd f[3][3], Xw[3][3];
+    for (int i = 0; i < 3; ++i) {
+        vd rx, ry;
+        for (int l = 0; l < 4; ++l) {
+            rx[l] = ray[l][i][0]; ry[l] = ray[l][i][1];
+            for (int d = 0; d < 3; ++d) Xw[i][d][l] = X[l][i][d];
+        }
+        const vd inv = one / vsqrt(rx * rx + ry * ry + one);
+        f[i][0] = rx * inv; f[i][1] = ry * inv; f[i][2] = inv;
+    }
+    auto dot = [](const vd* a, const vd* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+    auto d2 = [](const vd* a, const vd* b) { return (a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]); };
+    const vd ca = dot(f[1], f[2]), cb = dot(f[0], f[2]), cg = dot(f[0], f[1]);
+    const vd a2 = d2(Xw[1], Xw[2]), b2 = d2(Xw[0], Xw[2]), c2 = d2(Xw[0], Xw[1]);
+    vl ok = (a2 > zero) & (b2 > zero) & (c2 > zero);
+    const VFrame EP = triangle_frame4(Xw[0], Xw[1], Xw[2]);
+    ok &= EP.ok;
+    const vd b2s = vsel(ok, b2, one);
+    const vd p = (a2 - c2) / b2s, k = c2 / b2s;
+    const vd two = vsplat(2.0);
+    const vd N[3] = {p + one, -two * p * cb, p - one}, D[2] = {two * cg, -two * ca}, E[3] = {one, -two * cb, one};
+    const vd D2[3] = {D[0] * D[0], two * D[0] * D[1], D[1] * D[1]};
+    vd c[5] = {D2[0], D2[1], D2[2], zero, zero};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c[i + j] += N[i] * N[j] - k * E[i] * D2[j];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 2; ++j) c[i + j] -= two * cg * N[i] * D[j];
+    // ---- the quartic's real roots: four slots per lane (valid[k]), polished on the original polynomial ---------------------------
+    vd y[4] = {zero, zero, zero, zero};
+    vl valid[4] = {zero > one, zero > one, zero > one, zero > one};
+    {
+        vl lead = vabs(c[4]) > vsplat(1e-14) * (vabs(c[3]) + vabs(c[2]) + vabs(c[1]) + vabs(c[0]) + vsplat(1e-300));
+        lead &= ok;
+        const vd c4s = vsel(lead, c[4], one);
+        const vd a = c[3] / c4s, b = c[2] / c4s, cc = c[1] / c4s, d = c[0] / c4s;
+        const vd aa = a * a;
+        const vd pp = b - vsplat(0.375) * aa, q = cc - vsplat(0.5) * a * b + vsplat(0.125) * aa * a;
+        const vd r = d - vsplat(0.25) * a * cc + vsplat(0.0625) * aa * b - vsplat(3.0 / 256.0) * aa * aa;
+        const vd scale = vabs(pp) + vsqrt(vabs(r)) + vsplat(1e-300);
+        const vl biq = vabs(q) < vsplat(1e-12) * scale * vsqrt(scale);
+        const vl gen = lead & ~biq;
+        // resolvent cubic z^3 + 2 p z^2 + (p^2 - 4 r) z - q^2: closed form per lane, Newton polish on the lanes
+        const vd A = two * pp, B = pp * pp - vsplat(4.0) * r, C = -q * q;
+        vd z = one;
+        {
+            const vd a3 = A / vsplat(3.0);
+            const vd P = B - A * a3, Q = two * a3 * a3 * a3 - a3 * B + C;
+            const vd disc = vsplat(0.25) * Q * Q + P * P * P / vsplat(27.0);
+            for (int l = 0; l < 4; ++l) {
+                if (!gen[l]) continue;
+                double w;
+                if (disc[l] > 0.0) {
+                    const double sq = std::sqrt(disc[l]);
+                    w = cbrt_s(-0.5 * Q[l] + sq) + cbrt_s(-0.5 * Q[l] - sq);
+                } else {
+                    const double m = 2.0 * std::sqrt(-P[l] / 3.0);
+                    double arg = m > 0.0 ? 3.0 * Q[l] / (P[l] * m) : 0.0;
+                    arg = arg < -1.0 ? -1.0 : (arg > 1.0 ? 1.0 : arg);
+                    w = m * std::cos(std::acos(arg) / 3.0);
+                }
+                z[l] = w - a3[l];
+            }
+            vl live = gen;
+            for (int it = 0; it < 3; ++it) {
+                const vd fz = ((z + A) * z + B) * z + C, dfz = (vsplat(3.0) * z + two * A) * z + B;
+                live &= vabs(dfz) >= vsplat(1e-300);
+                z -= vsel(live, fz / vsel(live, dfz, one), zero);
+            }
+        }
+        const vl zpos = gen & (z > zero);
+        const vd zs = vsel(zpos, z, one);
+        const vd s = vsqrt(zs), qs = q / s;
+        const vd t1 = vsplat(0.5) * (pp + zs - qs), t2 = vsplat(0.5) * (pp + zs + qs);
+        const vd tol = vsplat(1e-10) * (zs + vabs(t1) + vabs(t2));
+        const vd d1 = zs - vsplat(4.0) * t1, dd2 = zs - vsplat(4.0) * t2;
+        const vl m1 = zpos & (d1 > -tol), m2 = zpos & (dd2 > -tol);
+        const vd r1 = vsqrt(vsel(d1 > zero, d1, zero)), r2 = vsqrt(vsel(dd2 > zero, dd2, zero));
+        // a sample has two real roots as a rule -- one of the two pairs -- and which one differs from lane to lane: a lane's FIRST existing
+        // pair goes to slots 0, 1 and its second, if it has four real roots, to slots 2, 3 (the scalar solver's order within a lane), so
+        // that the passes over slots 2 and 3 below are skipped for most groups of four
+        const vd y0 = vsplat(0.5) * (-s + r1), y1 = vsplat(0.5) * (-s - r1), y2 = vsplat(0.5) * (s + r2), y3 = vsplat(0.5) * (s - r2);
+        y[0] = vsel(m1, y0, y2); y[1] = vsel(m1, y1, y3); valid[0] = valid[1] = m1 | m2;
+        y[2] = y2; y[3] = y3; valid[2] = valid[3] = m1 & m2;
+        const vd shift = vsplat(0.25) * a;
+        for (int kk = 0; kk < 4; ++kk) {
+            if (!(valid[kk][0] | valid[kk][1] | valid[kk][2] | valid[kk][3])) continue;
+            vd x = y[kk] - shift;
+            vl live = valid[kk];
+            for (int it = 0; it < 3; ++it) {
+                const vd fx = (((c[4] * x + c[3]) * x + c[2]) * x + c[1]) * x + c[0];
+                const vd dfx = ((vsplat(4.0) * c[4] * x + vsplat(3.0) * c[3]) * x + two * c[2]) * x + c[1];
+                live &= vabs(dfx) >= vsplat(1e-300);
+                x -= vsel(live, fx / vsel(live, dfx, one), zero);
+            }
+            y[kk] = x;
+        }
+        // a biquadratic lane: the scalar root finder (roots in its order, into the slots from 0)
+        for (int l = 0; l < 4; ++l) {
+            if (!(lead[l] && biq[l])) continue;
+            const double cl[5] = {c[0][l], c[1][l], c[2][l], c[3][l], c[4][l]};
+            double rts[4];
+            const int nr = quartic_real_roots(cl, rts);
+            for (int kk = 0; kk < 4; ++kk) {
+                valid[kk][l] = kk < nr ? -1 : 0;
+                if (kk < nr) y[kk][l] = rts[kk];
+            }
+        }
+    }
+    // ---- every root slot: depths -> camera-frame triangle -> its frame -> R = E_C E_P^T, t = C_0 - R X_0 ---------------------------
+    for (int l = 0; l < 4; ++l) nsol[l] = 0;
+    for (int kk = 0; kk < 4; ++kk) {
+        const vd v = vsel(valid[kk], y[kk], one);
+        vl good = valid[kk] & (y[kk] > zero) & vfinite(y[kk]);
+        if (!(good[0] | good[1] | good[2] | good[3])) continue;
+        for (int kj = 0; kj < kk; ++kj)                                  // a double root counted once
+            good &= ~(valid[kj] & (vabs(y[kj] - v) < vsplat(1e-9) * (one + vabs(v))));
+        const vd den = D[0] + D[1] * v;
+        good &= vabs(den) >= vsplat(1e-12);
+        const vd u = (N[0] + (N[1] + N[2] * v) * v) / vsel(good, den, one);
+        good &= u > zero;
+        const vd qq = one + u * u - two * u * cg;
+        good &= qq > vsplat(1e-300);
+        const vd s1 = vsqrt(c2 / vsel(good, qq, one));
+        const vd sd[3] = {s1, u * s1, v * s1};
+        vd Cc[3][3];
+        for (int i = 0; i < 3; ++i)
+            for (int d = 0; d < 3; ++d) Cc[i][d] = sd[i] * f[i][d];
+        const VFrame EC = triangle_frame4(Cc[0], Cc[1], Cc[2]);
+        good &= EC.ok;
+        vd ps[12];
+        vd mag = zero;
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) ps[i * 4 + j] = EC.e[i * 3] * EP.e[j * 3] + EC.e[i * 3 + 1] * EP.e[j * 3 + 1] + EC.e[i * 3 + 2] * EP.e[j * 3 + 2];
+            ps[i * 4 + 3] = Cc[0][i] - (ps[i * 4] * Xw[0][0] + ps[i * 4 + 1] * Xw[0][1] + ps[i * 4 + 2] * Xw[0][2]);
+            for (int j = 0; j < 4; ++j) mag += vabs(ps[i * 4 + j]);
+        }
+        good &= mag < vsplat(1e300);                                      // every entry finite
+        for (int l = 0; l < 4; ++l) {
+            if (!good[l]) continue;
+            double* o = poses[l][nsol[l]++];
+            for (int e = 0; e < 12; ++e) o[e] = ps[e][l];
+        }
+    }
+}
+
 void rodrigues(const double* w, double* R) {
     const double th = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
     const double a = th < 1e-12 ? 1.0 - th * th / 6.0 : std::sin(th) / th;
@@ -1058,13 +1236,28 @@ struct Ransac {
         if (solver == 1) {
             // P3P: a trial = one sample of three; every real root of its quartic is a hypothesis scored on all points (COLMAP's P3P
             // estimator does the same), wrong roots die in the scorer's first block
+            // four samples per solver call (drawn in trial order from this chunk's generator), their hypotheses then looked at trial by
+            // trial exactly as a one-at-a-time loop would: a trial the stopping rule no longer wants is neither counted nor looked at
             while (wanted(it)) {
-                int idx[3];
-                draw(idx, 3);
-                ++it;
-                double poses[4][12];
-                const int nsol = p3p_of(idx, poses);
-                for (int k = 0; k < nsol; ++k) consider(poses[k]);
+                const int g = limit - it < 4 ? limit - it : 4;
+                double ray4[4][3][2], X4[4][3][3];
+                for (int l = 0; l < 4; ++l) {
+                    int idx[3];
+                    if (l < g) draw(idx, 3);
+                    for (int k = 0; k < 3; ++k) {
+                        if (l >= g) { std::memcpy(ray4[l][k], ray4[0][k], sizeof(ray4[0][k])); std::memcpy(X4[l][k], X4[0][k], sizeof(X4[0][k])); continue; }
+                        ray4[l][k][0] = P.ray[2 * idx[k]]; ray4[l][k][1] = P.ray[2 * idx[k] + 1];
+                        for (int d = 0; d < 3; ++d) X4[l][k][d] = P.X[3 * idx[k] + d];
+                    }
+                }
+                double poses4[4][4][12];
+                int nsol4[4];
+                p3p_poses4(ray4, X4, poses4, nsol4);
+                for (int l = 0; l < g; ++l) {
+                    if (!wanted(it)) return it;
+                    ++it;
+                    for (int k = 0; k < nsol4[l]; ++k) consider(poses4[l][k]);
+                }
             }
             return it;
         }
@@ -1159,7 +1352,7 @@ const double kIdentPose[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
 
 }  // namespace
 
-extern "C" int oppnp_abi_version(void) { return 2; }
+extern "C" int oppnp_abi_version(void) { return 3; }          // 3: + oppnp_p3p4
 
 // Fewest correspondences that give a pose: the 6-point DLT needs its sample; P3P + RANSAC (the pycolmap branch, metric_utils.py:155-165)
 // needs the three of a sample and ONE more point to pick the root, so frames with 4 or 5 matches still get a pose there.
@@ -1170,6 +1363,11 @@ extern "C" int oppnp_p3p(const double* rays3x2, const double* X3x3, double* pose
     if (!rays3x2 || !X3x3 || !poses4x12) return -1;
     return p3p_poses(reinterpret_cast<const double(*)[2]>(rays3x2), reinterpret_cast<const double(*)[3]>(X3x3),
                      reinterpret_cast<double(*)[12]>(poses4x12));
+}
+
+extern "C" void oppnp_p3p4(const double* rays4x3x2, const double* X4x3x3, double* poses4x4x12, int* nsol4) {
+    p3p_poses4(reinterpret_cast<const double (*)[3][2]>(rays4x3x2), reinterpret_cast<const double (*)[3][3]>(X4x3x3),
+               reinterpret_cast<double (*)[4][12]>(poses4x4x12), nsol4);
 }
 
 extern "C" int oppnp_ransac(const double* K, const float* pts2d, const float* pts3d, int n, double reproj_err_px, double confidence,

@@ -50,7 +50,9 @@ def load():
         lib.oppnp_estimate_affine2d.restype = ctypes.c_int
         lib.oppnp_estimate_affine2d.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double,
                                                 ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
-        if lib.oppnp_abi_version() != 2:
+        lib.oppnp_p3p4.restype = None
+        lib.oppnp_p3p4.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        if lib.oppnp_abi_version() != 3:
             raise RuntimeError("libonepose_pnp.so ABI version mismatch")
         _lib = lib
     return _lib
@@ -82,6 +84,17 @@ def p3p(rays, X):
     out = np.zeros((4, 12), dtype=np.float64)
     n = lib.oppnp_p3p(r.ctypes.data, x.ctypes.data, out.ctypes.data)
     return [out[i].reshape(3, 4).copy() for i in range(max(n, 0))]
+
+
+def p3p4(rays, X):
+    """Four samples through the four-lane solver the RANSAC loop uses: ``rays [4, 3, 2]``, ``X [4, 3, 3]`` -> four lists of ``[3, 4]`` poses."""
+    lib = load()
+    r = np.ascontiguousarray(rays, dtype=np.float64).reshape(4, 3, 2)
+    x = np.ascontiguousarray(X, dtype=np.float64).reshape(4, 3, 3)
+    out = np.zeros((4, 4, 12), dtype=np.float64)
+    ns = np.zeros(4, dtype=np.int32)
+    lib.oppnp_p3p4(r.ctypes.data, x.ctypes.data, out.ctypes.data, ns.ctypes.data)
+    return [[out[l, i].reshape(3, 4).copy() for i in range(int(ns[l]))] for l in range(4)]
 
 
 def trial_policy(use_pycolmap_ransac: bool, min_iters=None, max_iters=None) -> tuple:

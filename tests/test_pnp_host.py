@@ -236,3 +236,38 @@ def test_scorer_widths_pick_the_same_pose():
     for (pa, ia), (pb, ib) in zip(*res):
         assert ia == ib
         assert np.allclose(np.array(pa), np.array(pb), rtol=0, atol=1e-9)
+
+
+def test_four_lane_p3p_equals_the_one_sample_solver():
+    """oppnp_p3p4 (what the RANSAC loop of the pycolmap branch calls) against oppnp_p3p, sample by sample: same number of poses, same order,
+    entries equal to rounding -- on exact data, noisy data (the roots a RANSAC sees), symmetric (biquadratic) and degenerate samples
+    mixed into one group of four."""
+    from onepose_st_amd.pnp import p3p, p3p4
+    rng = np.random.default_rng(5)
+    n_pose = 0
+    diffs = []
+    for group in range(400):
+        rays, Xs = np.zeros((4, 3, 2)), np.zeros((4, 3, 3))
+        for l in range(4):
+            R, t = _pose(rng)
+            X = (rng.random((3, 3)) - 0.5) * 0.2
+            kind = (group + l) % 7
+            if kind == 5:                                     # isosceles triangle seen head-on: the quartic's odd coefficients vanish
+                X = np.array([[-0.05, 0.0, 0.0], [0.05, 0.0, 0.0], [0.0, 0.08, 0.0]])
+                R, t = np.eye(3), np.array([0.0, 0.0, 0.5])
+            if kind == 6 and group % 3 == 0:
+                X[2] = 2 * X[1] - X[0]                        # collinear: no pose
+            pc = X @ R.T + t
+            rays[l] = pc[:, :2] / pc[:, 2:] + (1e-3 * rng.normal(size=(3, 2)) if kind in (1, 3) else 0.0)
+            Xs[l] = X
+        four = p3p4(rays, Xs)
+        for l in range(4):
+            one = p3p(rays[l], Xs[l])
+            assert len(one) == len(four[l]), (group, l, len(one), len(four[l]))
+            for pa, pb in zip(one, four[l]):
+                diffs.append(float(np.abs(pa - pb).max()))
+                n_pose += 1
+    diffs = np.sort(np.array(diffs))
+    print(f"{n_pose} poses: median |diff| {np.median(diffs):.1e}, 95 % below {diffs[int(0.95 * n_pose)]:.1e}, 99 % below {diffs[int(0.99 * n_pose)]:.1e}, max {diffs[-1]:.1e}")
+    # (a root next to a double root of the quartic is only as sharp as the square root of the rounding, in either solver)
+    assert n_pose > 2000 and np.median(diffs) < 1e-14 and diffs[int(0.95 * n_pose)] < 1e-9 and diffs[-1] < 1e-4
