@@ -78,6 +78,25 @@ class _KeypointEncoderParams(nn.Module):
         nn.init.constant_(self.encoder[-1].bias, 0.0)
 
 
+_stream_objs = {}
+
+
+def _current_stream(dev):
+    """``torch.cuda.current_stream(dev)`` without its ~8 us of Python (lazy-init and device-index helpers) on the per-frame path: the raw
+    handle of the current stream is one C call, the Stream object that wraps it is looked up by (device, handle)."""
+    idx = dev.index
+    if idx is None:
+        return torch.cuda.current_stream(dev)
+    raw = torch._C._cuda_getCurrentRawStream(idx)
+    st = _stream_objs.get((idx, raw))
+    if st is None:
+        st = torch.cuda.current_stream(dev)
+        if len(_stream_objs) >= 64:
+            _stream_objs.clear()
+        _stream_objs[(idx, raw)] = st
+    return st
+
+
 class _NullProfiler:
     _scope = contextlib.nullcontext()
 
@@ -162,11 +181,37 @@ class OnePosePlus_model(nn.Module):
     # ------------------------------------------------------------------------------------------
     # device-side weight blocks (re-packed when parameters change or move)
     # ------------------------------------------------------------------------------------------
+    _PARAM_REWALK = 64          # frames between two full walks of the module tree in _weights()
+
+    def _matcher_params(self):
+        """The parameters whose packed copies the kernels read, as a list that is NOT rebuilt on every frame: walking the module tree
+        (``named_parameters``: 145 tensors below ~40 modules) cost ~100 us of a 690 us frame period -- a third of the host time of an
+        enqueue -- for a question whose answer changes when a user edits the model.  The list is rebuilt every ``_PARAM_REWALK`` frames and
+        whenever ``_apply`` (``.to`` / ``.cuda`` / ``.float``) or ``load_state_dict`` ran; a parameter that is written in place, moved or
+        re-assigned inside an existing tensor is caught on the very next frame by the (data_ptr, _version) key below; only module surgery
+        (replacing a sub-module or a Parameter object) between two frames can go unseen, for at most ``_PARAM_REWALK`` frames."""
+        c = self.__dict__.get("_param_cache")
+        if c is None or c[1] <= 0:
+            c = self.__dict__["_param_cache"] = [[p for n, p in self.named_parameters() if not n.startswith("backbone.")], self._PARAM_REWALK]
+        c[1] -= 1
+        return c[0]
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__["_param_cache"] = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.__dict__["_param_cache"] = None
+        return super().load_state_dict(*args, **kwargs)
+
     def _weights(self, device):
-        params = [p for n, p in self.named_parameters() if not n.startswith("backbone.")]
-        key = (str(device), self.precision) + tuple((p.data_ptr(), p._version) for p in params)
+        params = self._matcher_params()
+        key = (str(device), self.precision, tuple([p.data_ptr() for p in params]), tuple([p._version for p in params]))
         if self._packed is not None and self._packed[0] == key:
             return self._packed[1]
+        self.__dict__["_param_cache"] = None              # a change: the next frame walks the tree again
+        params = self._matcher_params()
+        key = (str(device), self.precision, tuple([p.data_ptr() for p in params]), tuple([p._version for p in params]))
         sd = {k: v for k, v in self.state_dict().items() if not k.startswith("backbone.")}
         blocks = {
             "coarse": [packing.pack_coarse_layer(sd, f"loftr_coarse.layers.{i}.").to(device)
@@ -257,7 +302,7 @@ class OnePosePlus_model(nn.Module):
             raise hip.HipLibraryError("OnePosePlus_model runs on the HIP device only (no CPU fallback): move the "
                                       "model and its inputs to 'cuda'")
         hip.load()
-        lib_call, P, S = hip.call, hip.ptr, hip.stream_handle()
+        lib_call, P = hip.call, hip.ptr
         cfg = self.config
         dev = feat_c.device
         if image_hw is not None:
@@ -303,7 +348,8 @@ class OnePosePlus_model(nn.Module):
             qscale = qs.to(device=dev, dtype=torch.float32).contiguous()
         PM = lambda: P(qmask, torch.uint8)
 
-        main = torch.cuda.current_stream(dev)
+        main = _current_stream(dev)
+        S = ctypes.c_void_p(main.cuda_stream)          # (the stage-by-stage path below launches on it)
         fkey = (str(dev), main.cuda_stream)
         lazy = self.conf_matrix_mode == "lazy" and not _force_eager
         # a lazy frame whose selection meets an exact row tie it cannot resolve without the stored row is run again with conf_matrix

@@ -163,3 +163,37 @@ def test_frame_layout_is_aligned_and_disjoint():
     d.M = 1201                                                      # hc * wc != M
     with pytest.raises(ValueError):
         hip.call("ophip_frame_layout", ctypes.byref(d), 0, 0, ctypes.byref(hip.FrameLayout()))
+
+
+def test_packed_weights_follow_the_parameters_without_walking_the_module_tree_every_frame(sd, cfg):
+    """model._weights: the device-side weight blocks are re-packed when a parameter changes; the per-frame check reads (data_ptr, _version) of
+    a cached parameter list (the module-tree walk cost a third of an enqueue's host time), rebuilt after ``load_state_dict`` / ``_apply`` and
+    every ``_PARAM_REWALK`` frames."""
+    m = OnePosePlus_model(cfg).eval()
+    m.load_state_dict(sd)
+    cpu = torch.device("cpu")
+    w0 = m._weights(cpu)
+    walks = []
+    real = m.named_parameters
+    m.named_parameters = lambda *a, **k: (walks.append(1), real(*a, **k))[1]
+    for _ in range(10):
+        assert m._weights(cpu) is w0                                   # unchanged model: the cached blocks ...
+    assert len(walks) == 0                                             # ... and no walk of the module tree
+    p = m.loftr_coarse.layers[0].q_proj.weight
+    with torch.no_grad():
+        p.mul_(2.0)                                                    # in place: seen on the next frame through the cached list
+    w1 = m._weights(cpu)
+    assert w1 is not w0 and not torch.equal(w1["coarse_x3"][0], w0["coarse_x3"][0])
+    assert m._weights(cpu) is w1
+    m.load_state_dict(sd)                                              # copies in place AND drops the cached list
+    w2 = m._weights(cpu)
+    assert w2 is not w1 and torch.equal(w2["coarse_x3"][0], w0["coarse_x3"][0])
+    m.loftr_coarse.layers[0].q_proj.weight = torch.nn.Parameter(p.detach() * 3.0)       # module surgery: seen after at most _PARAM_REWALK frames
+    seen = None
+    for i in range(m._PARAM_REWALK + 1):
+        if m._weights(cpu) is not w2:
+            seen = i
+            break
+    assert seen is not None and seen <= m._PARAM_REWALK
+    m.double()                                                         # _apply drops the list as well
+    assert m.__dict__["_param_cache"] is None
