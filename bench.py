@@ -245,12 +245,22 @@ def main():
     # threads must be free to leave CPUs a neighbour takes -- pinned to fixed CPUs, 3 of 10 runs lost 30-60 % -- and it keeps below the
     # quota by running fewer pool threads instead, hostsize.pnp_threads(under_quota=True).)
     pin_workers = pinned
-    with (hostsize.worker_cpus(my_cpus) if pin_workers else contextlib.nullcontext()):
+    # experiment (OPHIP_SPLIT_FEEDER=n): a confined one-rank job keeps its n idlest CPUs for the thread that enqueues frames; the RANSAC
+    # workers roam over the others
+    split_n = int(os.environ.get("OPHIP_SPLIT_FEEDER", "0"))
+    split = confined and split_n > 0 and len(hostsize.confined_order) >= 4 * split_n
+    worker_ctx = hostsize.worker_cpus(my_cpus) if pin_workers else (hostsize.worker_cpus(hostsize.confined_order, split_n) if split else contextlib.nullcontext())
+    with worker_ctx:
         pools = {} if args.no_pnp else {pol: PnPPool(first["K"].numpy(), threads=pnp_threads, pnp_reprojection_error=7, policy=pol)
                                         for pol in ("reference", "adaptive")}
     if pinned and pools and len(my_cpus) >= 2 * hostsize.FEEDER_CORES:
         try:
             os.sched_setaffinity(0, my_cpus[:hostsize.FEEDER_CORES])          # this thread (it enqueues the frames) stays on the feeder cores
+        except OSError:
+            pass
+    if split and pools:
+        try:
+            os.sched_setaffinity(0, hostsize.confined_order[:split_n])
         except OSError:
             pass
     pool = pools.get(args.pnp_policy)

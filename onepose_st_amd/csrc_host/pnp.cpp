@@ -32,6 +32,7 @@
 #include <thread>
 #include <unordered_map>
 #if defined(__linux__)
+#include <sched.h>
 #include <sys/resource.h>
 #include <sys/syscall.h>
 #include <unistd.h>
@@ -42,6 +43,11 @@
 #endif
 
 namespace {
+
+inline bool env_on(const char* name) {
+    const char* v = getenv(name);
+    return v && *v && !(v[0] == '0' && !v[1]);
+}
 
 struct Rng {
     uint64_t s;
@@ -260,10 +266,6 @@ bool score_fast_512(const FastPoints& F, const float* kp, float thr2, int best_c
     return true;
 }
 
-inline bool env_on(const char* name) {
-    const char* v = getenv(name);
-    return v && *v && !(v[0] == '0' && !v[1]);
-}
 const bool g_use_512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") && !env_on("OPPNP_NO_AVX512");
 
 // The -mavx2 -mfma build (what pnp.py loads on a CPU that has both): eight points per step, 21 vector instructions (the compiler's
@@ -1447,7 +1449,14 @@ struct Pool {
     void run() {
 #if defined(__linux__)
         // background priority: the thread that feeds the GPU must never wait for a core behind a RANSAC chunk
-        (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), 10);
+        // (OPPNP_WORKER_NICE=n: another nice value; OPPNP_WORKER_IDLE=1: SCHED_IDLE -- a worker then runs only on a CPU nothing else wants)
+        const char* nv = getenv("OPPNP_WORKER_NICE");
+        (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), nv && *nv ? atoi(nv) : 10);
+        if (env_on("OPPNP_WORKER_IDLE")) {
+            struct sched_param sp;
+            std::memset(&sp, 0, sizeof(sp));
+            (void)sched_setscheduler(0, SCHED_IDLE, &sp);
+        }
 #endif
         for (;;) {
             std::pair<std::shared_ptr<Job>, int> task;

@@ -156,6 +156,7 @@ def pnp_threads(n_cores: int, under_quota: bool = False, world: int = 1) -> int:
     return max(1, n_cores - 1)
 
 
+confined_order = []       # pin_rank(): the CPUs a one-rank job under a quota was confined to, idlest physical cores first (empty: not confined)
 QUOTA_ROOM = 3            # a one-rank job under a CPU quota keeps its threads on QUOTA_ROOM x quota CPUs of its mask
 
 
@@ -181,6 +182,7 @@ def pin_rank(rank: int, world: int, affinity=None, quota=None):
             wide = job_cpus(None, QUOTA_ROOM * int(q), prefer_idle=True)
             if len(wide) < len(_affinity()):
                 os.sched_setaffinity(0, wide)
+                confined_order[:] = wide
     except OSError:
         pass                                # a restricted container: sizing still holds, pinning is best effort
     return mine
@@ -198,15 +200,16 @@ class worker_cpus:
     RANSAC workers would otherwise sit on every CPU the feeder can wake up on, and it waits for a worker's time slice (milliseconds) now and
     then.  No-op when the share is too small to split or the platform has no ``sched_setaffinity``."""
 
-    def __init__(self, cpus):
+    def __init__(self, cpus, feeder_cores=FEEDER_CORES):
         self.cpus = list(cpus)
         self.saved = None
+        self.feeder_cores = int(feeder_cores)
 
     def __enter__(self):
-        if len(self.cpus) >= 2 * FEEDER_CORES and hasattr(os, "sched_setaffinity"):
+        if len(self.cpus) >= 2 * self.feeder_cores and hasattr(os, "sched_setaffinity"):
             try:
                 self.saved = os.sched_getaffinity(0)
-                os.sched_setaffinity(0, self.cpus[FEEDER_CORES:])
+                os.sched_setaffinity(0, self.cpus[self.feeder_cores:])
             except OSError:
                 self.saved = None
         return self
