@@ -21,6 +21,7 @@
 //                reference's pycolmap call runs >= 10 000), then adaptive stopping at the requested confidence
 //   refinement : Levenberg-Marquardt on the inliers (6 dof, analytic Jacobian), inlier set re-evaluated once
 //   randomness : xorshift64* seeded by the caller -> bit-reproducible
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -33,6 +34,7 @@
 #include <unordered_map>
 #if defined(__linux__)
 #include <sched.h>
+#include <semaphore.h>
 #include <sys/resource.h>
 #include <sys/syscall.h>
 #include <unistd.h>
@@ -1413,22 +1415,67 @@ struct Job {
     int remaining = 0;                       // unconditional chunks not finished yet (guarded by Pool::mu)
 };
 
+// The submitting thread is the one that feeds the GPU; the workers run at background priority.  A mutex shared by the two inverts that
+// priority: a worker that is descheduled while it holds the lock (a loaded host: other tenants on its CPU) stops the feeder for
+// milliseconds -- seen as `finish` at 260-320 us per frame instead of 100 in one 20-step region out of ten, 20 % of the frame rate.  So
+// submit takes NO lock the workers take: the job goes onto a lock-free inbox (an atomic singly linked list) and a semaphore counts the
+// tasks that exist (inbox entries + queue entries); a worker that has taken a count moves the inbox into the queue under `mu` -- which only
+// workers and the joining calls (wait_all, result) hold -- and pops one task.
+struct Inbox {
+    std::shared_ptr<Job> job;            // null: `ident` (a frame with too few correspondences: identity pose, recorded by a worker)
+    int chunk = 0;
+    long long ticket = 0;
+    Inbox* next = nullptr;
+};
+
 struct Pool {
     std::vector<std::thread> workers;
-    std::deque<std::pair<std::shared_ptr<Job>, int>> queue;      // (job, chunk); chunk -1: the whole tail (no full chunks)
+    std::deque<std::pair<std::shared_ptr<Job>, int>> queue;      // (job, chunk); chunk -1: the whole tail (no full chunks); guarded by mu
     std::unordered_map<long long, Result> results;     // by ticket; erased when read
     std::mutex mu;
-    std::condition_variable cv_work, cv_done;
-    long long submitted = 0, finished = 0;
-    bool stop = false;
+    std::condition_variable cv_done;
+    std::atomic<Inbox*> inbox{nullptr};
+    sem_t tasks;                                       // inbox entries + queue entries not yet taken by a worker
+    std::atomic<long long> submitted{0};
+    long long finished = 0;
+    std::atomic<bool> stop{false};
 
     explicit Pool(int n) {
+        sem_init(&tasks, 0, 0);
         for (int i = 0; i < n; ++i) workers.emplace_back([this] { run(); });
     }
     ~Pool() {
-        { std::lock_guard<std::mutex> lk(mu); stop = true; }
-        cv_work.notify_all();
+        stop.store(true);
+        for (size_t i = 0; i < workers.size(); ++i) sem_post(&tasks);
         for (auto& t : workers) t.join();
+        for (Inbox* e = inbox.exchange(nullptr); e;) { Inbox* nx = e->next; delete e; e = nx; }
+        sem_destroy(&tasks);
+    }
+    void post(Inbox* e) {                    // any thread, no lock
+        Inbox* head = inbox.load(std::memory_order_relaxed);
+        do { e->next = head; } while (!inbox.compare_exchange_weak(head, e, std::memory_order_release, std::memory_order_relaxed));
+        sem_post(&tasks);
+    }
+    void drain_inbox_locked() {              // mu held: inbox entries, oldest first, to the back of the queue
+        Inbox* e = inbox.exchange(nullptr, std::memory_order_acquire);
+        Inbox* rev = nullptr;
+        while (e) { Inbox* nx = e->next; e->next = rev; rev = e; e = nx; }
+        while (rev) {
+            Inbox* nx = rev->next;
+            if (rev->job) {
+                queue.emplace_back(std::move(rev->job), rev->chunk);
+            } else {                         // no pose: identity, recorded at once; the count taken for it is given back as a no-op task
+                Result r;
+                std::memcpy(r.pose, kIdentPose, sizeof(kIdentPose));
+                r.n_inliers = 0; r.rc = 1;
+                results[rev->ticket] = r;
+                ++finished;
+                queue.emplace_back(std::shared_ptr<Job>(), -2);
+                cv_done.notify_all();
+            }
+            delete rev;
+            rev = nx;
+        }
     }
     void finish_job(Job& job) {              // merge in chunk order, sequential tail, refinement
         Candidate best;
@@ -1460,13 +1507,18 @@ struct Pool {
 #endif
         for (;;) {
             std::pair<std::shared_ptr<Job>, int> task;
+            while (sem_wait(&tasks) != 0) {}                 // (EINTR)
             {
-                std::unique_lock<std::mutex> lk(mu);
-                cv_work.wait(lk, [this] { return stop || !queue.empty(); });
-                if (stop && queue.empty()) return;
+                std::lock_guard<std::mutex> lk(mu);
+                drain_inbox_locked();
+                if (queue.empty()) {                          // only the destructor posts without a task
+                    if (stop.load()) return;
+                    continue;
+                }
                 task = std::move(queue.front());
                 queue.pop_front();
             }
+            if (task.second == -2) continue;                  // the place-holder of an identity result
             Job& job = *task.first;
             if (task.second < 0) { finish_job(job); continue; }
             if (task.second == 0) {                  // chunk 0 first, alone: its float best then bounds the others, which start now
@@ -1479,7 +1531,7 @@ struct Pool {
                         --job.remaining;
                         for (int c = 1; c < nfull; ++c) queue.emplace_back(task.first, c);
                     }
-                    cv_work.notify_all();
+                    for (int c = 1; c < nfull; ++c) sem_post(&tasks);
                     continue;
                 }
             } else {
@@ -1507,15 +1559,11 @@ extern "C" long long oppnp_pool_submit(void* pool_, const double* K, const float
                                        double confidence, int min_iters, int max_iters, unsigned long long seed, int solver) {
     Pool* pool = reinterpret_cast<Pool*>(pool_);
     if (!pool || !K || n < 0 || (n > 0 && (!pts2d || !pts3d)) || max_iters < 1 || min_iters < 0 || (solver != 0 && solver != 1)) return -1;
-    long long ticket;
-    if (n < min_points(solver)) {                         // no pose: identity, recorded at once
-        Result r;
-        std::memcpy(r.pose, kIdentPose, sizeof(kIdentPose));
-        r.n_inliers = 0; r.rc = 1;
-        std::lock_guard<std::mutex> lk(pool->mu);
-        ticket = pool->submitted++;
-        pool->results[ticket] = r;
-        ++pool->finished;
+    Inbox* e = new Inbox();
+    if (n < min_points(solver)) {                         // no pose: identity, recorded by the worker that takes the entry
+        e->ticket = pool->submitted.fetch_add(1);
+        const long long ticket = e->ticket;
+        pool->post(e);
         return ticket;
     }
     auto job = std::make_shared<Job>();
@@ -1523,13 +1571,10 @@ extern "C" long long oppnp_pool_submit(void* pool_, const double* K, const float
     const int nfull = job->R.full_chunks();
     job->chunk_best.resize((size_t)nfull);
     job->remaining = nfull;
-    {
-        std::lock_guard<std::mutex> lk(pool->mu);
-        ticket = job->ticket = pool->submitted++;
-        if (nfull == 0) pool->queue.emplace_back(job, -1);
-        else pool->queue.emplace_back(job, 0);            // the other chunks follow chunk 0
-    }
-    pool->cv_work.notify_all();
+    const long long ticket = job->ticket = e->ticket = pool->submitted.fetch_add(1);
+    e->chunk = nfull == 0 ? -1 : 0;                       // the other chunks follow chunk 0
+    e->job = std::move(job);
+    pool->post(e);                                        // no lock shared with the workers: see Pool
     return ticket;
 }
 
@@ -1537,7 +1582,7 @@ extern "C" long long oppnp_pool_submit(void* pool_, const double* K, const float
 extern "C" long long oppnp_pool_wait_all(void* pool_) {
     Pool* pool = reinterpret_cast<Pool*>(pool_);
     std::unique_lock<std::mutex> lk(pool->mu);
-    pool->cv_done.wait(lk, [pool] { return pool->finished == pool->submitted; });
+    pool->cv_done.wait(lk, [pool] { return pool->finished == pool->submitted.load(); });
     return pool->finished;
 }
 

@@ -271,3 +271,45 @@ def test_four_lane_p3p_equals_the_one_sample_solver():
     print(f"{n_pose} poses: median |diff| {np.median(diffs):.1e}, 95 % below {diffs[int(0.95 * n_pose)]:.1e}, 99 % below {diffs[int(0.99 * n_pose)]:.1e}, max {diffs[-1]:.1e}")
     # (a root next to a double root of the quartic is only as sharp as the square root of the rounding, in either solver)
     assert n_pose > 2000 and np.median(diffs) < 1e-14 and diffs[int(0.95 * n_pose)] < 1e-9 and diffs[-1] < 1e-4
+
+
+def test_pool_submit_from_several_threads_with_empty_frames_and_early_close():
+    """The pool's submit path takes no lock its workers take (a lock-free inbox + a counting semaphore: a descheduled background worker must
+    never stop the thread that feeds the GPU).  Three threads submit 600 small frames between them, every seventh with too few matches
+    (identity pose, rc 1, recorded by a worker); every ticket is unique, every job finishes, results equal the sequential call; a pool
+    closed with work still queued shuts down cleanly."""
+    import threading
+    scenes = [_scene(60 + 5 * i, 50 + i, noise_px=0.3, outlier_frac=0.1) for i in range(5)]
+    K = scenes[0][0]
+    ref = [ransac_PnP(K, s[1], s[2], pnp_reprojection_error=7, use_pycolmap_ransac=True, min_iters=300) for s in scenes]
+    pool = PnPPool(K, threads=4, pnp_reprojection_error=7, policy="reference", min_iters=300)
+    got = {}
+    lock = threading.Lock()
+
+    def feed(tid):
+        for i in range(200):
+            which = (i + tid) % 7
+            if which >= 5:
+                tk = pool.submit(np.zeros((2, 2), np.float32), np.zeros((2, 3), np.float32))
+            else:
+                tk = pool.submit(scenes[which][1], scenes[which][2])
+            with lock:
+                assert tk not in got
+                got[tk] = which
+    ths = [threading.Thread(target=feed, args=(t,)) for t in range(3)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert pool.wait_all() == 600 and sorted(got) == list(range(600))
+    for tk, which in got.items():
+        pose, n_in, rc = pool.result(tk)
+        if which >= 5:
+            assert rc == 1 and n_in == 0 and np.array_equal(pose, np.eye(4)[:3])
+        else:
+            assert rc == 0 and np.array_equal(pose, ref[which][0]) and n_in == len(ref[which][2])
+    pool.close()
+    pool = PnPPool(K, threads=2, pnp_reprojection_error=7, policy="reference", min_iters=20000)
+    for s in scenes * 4:
+        pool.submit(s[1], s[2])
+    pool.close()                                          # 20 frames of 20 000 trials queued: the workers finish what is queued, then exit
