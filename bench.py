@@ -250,6 +250,12 @@ def main():
     split_n = int(os.environ.get("OPHIP_SPLIT_FEEDER", "0"))
     split = confined and split_n > 0 and len(hostsize.confined_order) >= 4 * split_n
     worker_ctx = hostsize.worker_cpus(my_cpus) if pin_workers else (hostsize.worker_cpus(hostsize.confined_order, split_n) if split else contextlib.nullcontext())
+    # experiment (OPHIP_PIN_WORKERS=k): each RANSAC worker of a confined one-rank job on its own k CPUs of the confined set (idlest first, after
+    # the first two, which stay free for the feeder)
+    pin_k = int(os.environ.get("OPHIP_PIN_WORKERS", "0"))
+    if confined and pin_k > 0 and len(hostsize.confined_order) >= 2 + pin_k * pnp_threads:
+        os.environ["OPPNP_WORKER_CPUS"] = ",".join(str(c) for c in hostsize.confined_order[2:2 + pin_k * pnp_threads])
+        os.environ["OPPNP_WORKER_CPUS_PER"] = str(pin_k)
     with worker_ctx:
         pools = {} if args.no_pnp else {pol: PnPPool(first["K"].numpy(), threads=pnp_threads, pnp_reprojection_error=7, policy=pol)
                                         for pol in ("reference", "adaptive")}

@@ -1442,7 +1442,7 @@ struct Pool {
 
     explicit Pool(int n) {
         sem_init(&tasks, 0, 0);
-        for (int i = 0; i < n; ++i) workers.emplace_back([this] { run(); });
+        for (int i = 0; i < n; ++i) workers.emplace_back([this, i] { run(i); });
     }
     ~Pool() {
         stop.store(true);
@@ -1493,7 +1493,37 @@ struct Pool {
         }
         cv_done.notify_all();
     }
-    void run() {
+    // OPPNP_WORKER_CPUS="c0,c1,c2,..." (+ OPPNP_WORKER_CPUS_PER=k, default 1): worker i may run on CPUs [i k, (i + 1) k) of the list (taken
+    // modulo its length) instead of everywhere the process may -- background threads that all wake on the same few CPUs are spread by the
+    // scheduler's load balancer only slowly (their weight is a tenth of a normal thread's), and a frame's pose then waits for one CPU
+    static void pin_worker(int index) {
+#if defined(__linux__)
+        const char* lst = getenv("OPPNP_WORKER_CPUS");
+        if (!lst || !*lst) return;
+        std::vector<int> cpus;
+        for (const char* p = lst; *p;) {
+            char* end = nullptr;
+            const long v = strtol(p, &end, 10);
+            if (end == p) break;
+            cpus.push_back((int)v);
+            p = *end ? end + 1 : end;
+        }
+        if (cpus.empty()) return;
+        const char* per = getenv("OPPNP_WORKER_CPUS_PER");
+        const int k = per && atoi(per) > 0 ? atoi(per) : 1;
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        for (int j = 0; j < k; ++j) {
+            const int c = cpus[((size_t)index * k + j) % cpus.size()];
+            if (c >= 0 && c < CPU_SETSIZE) CPU_SET(c, &set);
+        }
+        (void)sched_setaffinity(0, sizeof(set), &set);
+#else
+        (void)index;
+#endif
+    }
+    void run(int index) {
+        pin_worker(index);
 #if defined(__linux__)
         // background priority: the thread that feeds the GPU must never wait for a core behind a RANSAC chunk
         // (OPPNP_WORKER_NICE=n: another nice value; OPPNP_WORKER_IDLE=1: SCHED_IDLE -- a worker then runs only on a CPU nothing else wants)
