@@ -30,9 +30,10 @@ int oppnp_p3p(const double* rays3x2, const double* X3x3, double* poses4x12);
  * poses4x4x12 receives up to four poses per sample, nsol4 their numbers.  Same roots, same order, same poses as oppnp_p3p to rounding. */
 void oppnp_p3p4(const double* rays4x3x2, const double* X4x3x3, double* poses4x4x12, int* nsol4);
 
-/* Asynchronous pool: library-owned host threads solve poses while the caller keeps feeding the GPU (the per-frame path
- * has no Python in it).  submit copies its inputs and returns a ticket 0, 1, 2, ...; wait_all blocks until every
- * submitted pose is solved; result reads one (return value as oppnp_ransac). */
+/* Asynchronous pool: library-owned host threads (background priority) solve poses while the caller keeps feeding the GPU (the
+ * per-frame path has no Python in it).  submit copies its inputs and returns a ticket 0, 1, 2, ... without taking any lock the
+ * workers take (it may be called from several threads); wait_all blocks until every submitted pose is solved; result reads one
+ * (return value as oppnp_ransac; -1 for a ticket that is unknown, unfinished or already read). */
 void* oppnp_pool_create(int threads);
 void oppnp_pool_destroy(void* pool);
 long long oppnp_pool_submit(void* pool, const double* K, const float* pts2d, const float* pts3d, int n, double reproj_err_px,
