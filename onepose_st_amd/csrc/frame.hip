@@ -111,7 +111,7 @@ bool fine_on_main_enabled();
 int kv_first_mode() {
     static const int mode = [] {
         const char* e = getenv("OPHIP_FRAME_KV_FIRST");
-        if (!e || !e[0]) return fine_on_main_enabled() ? 1 : 2;
+        if (!e || !e[0]) return 1;          // (round 4's default was "main" while the encoder still waited for the previous fine stage)
         if (e[0] == 'p' || e[0] == '1') return 1;
         if (e[0] == 'm' || e[0] == '2') return 2;
         return 0;
@@ -126,6 +126,15 @@ bool fine_on_main_enabled() {
     return on;
 }
 
+// OPHIP_FRAME_FINE_WAIT=1: the encoder waits for the previous frame's fine stage (rounds 2-4: "attn_apply never shares the chip").  Default
+// since the end of round 4: no wait.  The fine stage's 1 400 workgroups are 2.7 rounds on 512 slots, so the last quarter of its time runs on a
+// thinning set of CUs; the encoder's first layer now fills them instead of starting when the last workgroup has ended (interleaved A/B on
+// one box, c2: 1 344 -> 1 366 frames/s at 20 steps, 1 429 -> 1 458 at 100; with the first layer's K / V half on the input stream, below,
+// 1 391 and 1 496).
+bool fine_wait_enabled() {
+    static const bool on = [] { const char* e = getenv("OPHIP_FRAME_FINE_WAIT"); return e && e[0] == '1'; }();
+    return on;
+}
 bool defer_fine_enabled() {
     static const bool on = [] { const char* e = getenv("OPHIP_FRAME_DEFER_FINE"); return !(e && e[0] == '0'); }();
     return on;
@@ -187,8 +196,10 @@ extern "C" int ophip_frame_enqueue_padded(const ophip_frame_desc* d, const ophip
     //     s_fine:                                 | fine stage(t)  ------------------------------------>|
     // Frame t's fine stage is kept back until frame t + 1's encoder and similarity tiles are queued and runs BESIDE the HBM-bound half
     // of frame t + 1's coarse matching (conf_kernel streams 269 MB, with non-temporal accesses so that it does not evict the fine
-    // stage's weights from L2, and needs no matrix pipe; the fine stage is matrix-bound and moves little).  The encoder's 150 KB workgroups leave no LDS for a second kernel on a CU (it never shares the chip with a fine stage, as
-    // before).  A frame with no successor is completed by ophip_frame_wait() (or ophip_frame_order_after_fine()).
+    // stage's weights from L2, and needs no matrix pipe; the fine stage is matrix-bound and moves little).  The encoder's 150 KB workgroups
+    // leave no LDS for a second kernel on a CU; since the end of round 4 frame t + 2's encoder no longer waits for frame t's fine stage to
+    // END (fine_wait_enabled()): its first layer takes the CUs that stage's last, thinning round of workgroups frees one by one.
+    // A frame with no successor is completed by ophip_frame_wait() (or ophip_frame_order_after_fine()).
     const bool defer = defer_fine_enabled() && s_fine != s_main;
     std::lock_guard<std::mutex> launch_lock(g_launch_mu);
     Slot* slot;
@@ -273,16 +284,18 @@ extern "C" int ophip_frame_enqueue_padded(const ophip_frame_desc* d, const ophip
     // compute stream in front of the wait (in the tail of the previous fine stage), "off" = inside the layer call as before.
     const int kv_first = kv_first_mode();
     const bool kv_hoisted = kv_first != 0 && d->n_coarse > 0;
-    if (kv_hoisted && kv_first == 1 && s_prep)
+    // (a padded frame's cell mask is made by the caller on the compute stream just before this call: its K / V half stays on that stream)
+    const bool kv_on_prep = kv_first == 1 && s_prep && !qmask;
+    if (kv_hoisted && kv_on_prep)
         FR_CHECK(ophip_encoder_kv_first_x3w8(x3d, x2d, B, N, M, d->w_coarse[0], 0, blob + L->enc_ws, qmask, s_prep));
     if (s_prep) {
         FR_HIP(hipEventRecord(slot->prep_done, s_prep), "hipEventRecord(prep)");
         FR_HIP(hipStreamWaitEvent(s_main, slot->prep_done, 0), "hipStreamWaitEvent(prep)");
     }
-    if (kv_hoisted && !(kv_first == 1 && s_prep))
+    if (kv_hoisted && !kv_on_prep)
         FR_CHECK(ophip_encoder_kv_first_x3w8(x3d, x2d, B, N, M, d->w_coarse[0], 0, blob + L->enc_ws, qmask, s_main));
-    // ---- a4-a6: coarse encoder; attn_apply never shares the chip with the previous frame's fine stage -------------------------
-    if (prev_fine) FR_HIP(hipStreamWaitEvent(s_main, prev_fine, 0), "hipStreamWaitEvent(previous fine)");      // (a no-op when it ran on s_main)
+    // ---- a4-a6: coarse encoder (OPHIP_FRAME_FINE_WAIT=1: behind the previous frame's fine stage) ----------------------------------
+    if (prev_fine && fine_wait_enabled()) FR_HIP(hipStreamWaitEvent(s_main, prev_fine, 0), "hipStreamWaitEvent(previous fine)");      // (a no-op when it ran on s_main)
     float *y3d = F(L->y3d), *y2d = F(L->y2d), *y2 = y2d, *x2 = x2d;
     float* z3d = x3d_external ? F(L->z3d) : x3d;          // a cached encoding is read-only: ping-pong between y and z
     float *x3 = x3d, *y3 = y3d;

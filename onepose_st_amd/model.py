@@ -379,6 +379,8 @@ class OnePosePlus_model(nn.Module):
                     self._obj_cache = (ckey, x3d_new, ev, kpts_d, desc_in_d)          # the key's tensors stay alive with the entry
                 x3d_ext = self._obj_cache[1]
                 main.wait_event(self._obj_cache[2])
+                if inputs_ready:                                      # the first layer's K / V half reads the cached encoding on the input stream
+                    self._side_stream(self._prep_streams, fkey, dev).wait_event(self._obj_cache[2])
             return self._enqueue_frame_call(data, feat_c, feat_f, kpts_d, desc_in_d, desc_fine_d, x3d_ext, W, dev, main, fkey,
                                             B, N, M, hc, wc, hf, wf, host_copy, inputs_ready, lazy, rerun, qmask, qscale)
         if fkey in self._frame_call_pending:                          # order this frame's encoder behind the C path's last fine stage
