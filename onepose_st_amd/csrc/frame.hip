@@ -261,6 +261,10 @@ extern "C" int ophip_frame_enqueue_padded(const ophip_frame_desc* d, const ophip
         ~StageRange() { if (open) ophip_range_pop(); }
     } stage;
     stage.next("a1-a3 input kernels");
+    // OPHIP_FRAME_PREP_AFTER_SIM=1 (experiment): this frame's input kernels start when the previous frame's similarity tiles have ended
+    // (beside its confidence pass and the fine stage) instead of whenever the host queued them (beside its last encoder layers)
+    static const bool prep_after_sim = [] { const char* e = getenv("OPHIP_FRAME_PREP_AFTER_SIM"); return e && e[0] == '1'; }();
+    if (prep_after_sim && s_prep && kept) FR_HIP(hipStreamWaitEvent(s_prep, kept->enc_done, 0), "hipStreamWaitEvent(previous similarity)");
     float* x2d = F(L->x2d);
     FR_CHECK(ophip_pe_add_transpose(feat_c, d->pe, x2d, B, 256, M, sin));
     const float* ff = feat_f;
