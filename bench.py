@@ -489,6 +489,25 @@ def main():
     launches, kern_ms = hip.timing_read()
     hip.timing_select("")
 
+    # The same kernel with the chip to itself: eight frames one at a time (enqueue, flush the kept-back fine stage, finish, synchronize), every
+    # launch bracketed.  Since the end of round 4 the pipeline lets the encoder's first layer start beside the previous frame's last fine
+    # workgroups and the next frame's input kernels run beside the last layers (both raise frames/s and lengthen the launches they
+    # touch): `roofline.achieved` stays what the contract asks for -- the launch time inside the timed region -- and `roofline.alone` says
+    # what the kernel does when nothing shares the chip.
+    alone_launches, alone_ms = 0, 0.0
+    if args.roofline_kernel == "attn_apply":
+        torch.cuda.synchronize()
+        hip.timing_select(args.roofline_kernel, every=1)
+        for i in range(8):
+            fc_a, ff_a = batches[i % len(batches)]
+            with torch.cuda.stream(streams[0]):
+                pa = model.enqueue_features(dict(obj_b), fc_a, ff_a, image_hw, host_copy=False, inputs_ready=image is None and not args.inputs_behind)
+                model.flush()
+            pa.finish()
+            torch.cuda.synchronize()
+        alone_launches, alone_ms = hip.timing_read()
+        hip.timing_select("")
+
     # what the host side can sustain by itself: this rank's pool alone on recorded matches, every rank at once (they share the host);
     # when that ceiling is below the matcher's rate, `value` is a host number and the line says so ("host_bound")
     pnp_ceiling = None
@@ -630,6 +649,14 @@ def main():
             "launches_sampled_every": time_every,
             "avg_launch_ms": avg_ms,
             "flops_per_launch": flops,
+            # nothing else on the chip (frames one at a time, every launch timed): the kernel's own number; the fields above are its launches
+            # inside the timed region, where the first layer shares the chip with the previous frame's last fine workgroups and the last
+            # layers with the next frame's input kernels
+            "alone": ({"avg_launch_ms": alone_ms / alone_launches, "launches": alone_launches,
+                       "achieved": flops / (alone_ms / alone_launches * 1e-3) / 1e12,
+                       "frac": flops / (alone_ms / alone_launches * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[args.precision],
+                       "mfma_issue_frac": flops / (alone_ms / alone_launches * 1e-3) / 1e12 * (3.0 if args.precision == "bf16x3" else 1.0) / MFMA_PEAK_TFLOPS[args.precision]}
+                      if alone_launches else None),
         },
     }
     if coarse_stage is not None:

@@ -16,7 +16,7 @@ python3 tools/l2_summary.py $O/pmc_l2 > $O/l2_summary.txt 2>&1 || true
 OPHIP_ROCTX=1 rocprofv3 --marker-trace --kernel-trace --output-format csv -d $O/marker -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-pnp --main-region-only --no-side-legs > /dev/null 2> $O/marker.err || echo "marker trace failed"
 ls $O/marker/*/
 for f in $O/marker/*/*marker*.csv; do head -60 $f > $O/marker_sample.csv; wc -l $f; done
-python3 bench.py --steps 20 --warmup 5 > $O/bench20_final.json 2> $O/bench20_final.err
+python3 bench.py --steps 20 --warmup 5 > $O/bench20_final.json 2> $O/bench20_final.err || true
 tail -c 600 $O/bench20_final.json
 find $O -name "*.csv" -size +3M -delete
 # where a 20-step region's time goes on the host side (per-step enqueue / wait / finish / submit and the tail after the last frame)
