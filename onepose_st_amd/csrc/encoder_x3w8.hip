@@ -144,28 +144,6 @@ __device__ unsigned g_kv_sync_timeouts = 0;        // workgroups whose wait for 
 // the host checks as far as it can; what it cannot see -- a second process on the device running the same kind of launch, each holding
 // half the chip and waiting for the other half -- ends in the wait's bound, after which a workgroup sums the whole block it needs itself
 // (same code, same bits, written to the same place): slow, never wrong, never stuck.
-// The summed block crosses workgroups on different XCDs, whose L2s are not coherent with each other.  A device-scope fence would do it --
-// and costs a write-back of the writer's whole L2 and an invalidate of the reader's (measured: the launch 49 -> 116 us, its weight stream
-// refetched from memory) -- so the few kilobytes that cross are moved with device-scope relaxed atomics instead (write-through stores, loads
-// that miss a stale line by construction), ordered against the counter by workgroup-scope fences, which are waits and nothing else.
-template <int N>
-__device__ __forceinline__ void st_agent(void* dst, const void* src) {
-    unsigned w[N];
-    __builtin_memcpy(w, src, 4 * N);
-#pragma unroll
-    for (int i = 0; i < N; ++i) __hip_atomic_store(reinterpret_cast<unsigned*>(dst) + i, w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <typename T>
-__device__ __forceinline__ T ld_agent(const void* src) {
-    constexpr int N = sizeof(T) / 4;
-    unsigned w[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) w[i] = __hip_atomic_load(reinterpret_cast<const unsigned*>(src) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    T v;
-    __builtin_memcpy(&v, w, sizeof(T));
-    return v;
-}
-
 __device__ __forceinline__ void fused_kv_sum(const EncW8Args& a, int q_begin, int q_end, int fw, int lane) {
     constexpr int QUADS = KV_PART_FLOATS / 4;                       // per (batch, stream)
     const int ttot = a.tiles[0] + a.tiles[1];
@@ -207,10 +185,10 @@ __device__ __forceinline__ void fused_kv_sum(const EncW8Args& a, int q_begin, in
                     vh[r] = hh; vl[r] = ll;
                 }
                 const size_t fr = (size_t)(head * 2 + vt) * 2;
-                st_agent<2>(blk + ((fr + 0) * 64 + ln) * 16 + 8 * dt, &vh);
-                st_agent<2>(blk + ((fr + 1) * 64 + ln) * 16 + 8 * dt, &vl);
+                *reinterpret_cast<bf16x4*>(blk + ((fr + 0) * 64 + ln) * 16 + 8 * dt) = vh;
+                *reinterpret_cast<bf16x4*>(blk + ((fr + 1) * 64 + ln) * 16 + 8 * dt) = vl;
             } else {
-                st_agent<4>(blk + KV_FRAG_BYTES + (size_t)(e - NH * 1024) * 4, &tot);
+                *reinterpret_cast<f32x4*>(blk + KV_FRAG_BYTES + (size_t)(e - NH * 1024) * 4) = tot;
             }
         }
     }
@@ -225,7 +203,7 @@ __device__ __forceinline__ void wait_kv_shares(const EncW8Args& a, int nwg, int 
     if (tid == 0) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         int ok = 1;
-        while (__hip_atomic_load(a.red_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nwg) {
+        while (__hip_atomic_load(a.red_count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nwg) {
             __builtin_amdgcn_s_sleep(4);
             if (__builtin_amdgcn_s_memrealtime() - t0 > KV_WAIT_TICKS) { ok = 0; atomicAdd(&g_kv_sync_timeouts, 1u); break; }
         }
@@ -238,10 +216,10 @@ __device__ __forceinline__ void wait_kv_shares(const EncW8Args& a, int nwg, int 
         const int src = (int)((a.kv[s] - a.red_kv) / KV_BLOCK_BYTES) & 1;
         const int q0 = (b * 2 + src) * QUADS;
         fused_kv_sum(a, q0, q0 + QUADS, fw, lane);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __threadfence();
         __syncthreads();
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 template <bool ONLY_KV, bool MASKED = false>
@@ -302,22 +280,12 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
     f32x4 ksm[2], g1[2], b1[2], g2[2], b2[2];
     auto load_kv = [&] {
         const char* kvb = a.kv[s] + (size_t)b * a.kvbs;
-        const float* kp = reinterpret_cast<const float*>(kvb + KV_FRAG_BYTES) + fw * 32 + 4 * q;
-        if (fused_sum) {                               // written by other workgroups of THIS launch: device-scope loads (see st_agent)
-#pragma unroll
-            for (int vt = 0; vt < 2; ++vt) {
-                kvh[vt] = ld_agent<bf16x8>(kvb + ((size_t)((fw * 2 + vt) * 2 + 0) * 64 + lane) * 16);
-                kvl[vt] = ld_agent<bf16x8>(kvb + ((size_t)((fw * 2 + vt) * 2 + 1) * 64 + lane) * 16);
-            }
-            ksm[0] = ld_agent<f32x4>(kp);
-            ksm[1] = ld_agent<f32x4>(kp + 16);
-            return;
-        }
 #pragma unroll
         for (int vt = 0; vt < 2; ++vt) {
             kvh[vt] = *reinterpret_cast<const bf16x8*>(kvb + ((size_t)((fw * 2 + vt) * 2 + 0) * 64 + lane) * 16);
             kvl[vt] = *reinterpret_cast<const bf16x8*>(kvb + ((size_t)((fw * 2 + vt) * 2 + 1) * 64 + lane) * 16);
         }
+        const float* kp = reinterpret_cast<const float*>(kvb + KV_FRAG_BYTES) + fw * 32 + 4 * q;
         ksm[0] = *reinterpret_cast<const f32x4*>(kp);
         ksm[1] = *reinterpret_cast<const f32x4*>(kp + 16);
     };
@@ -340,9 +308,9 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
             const int total = 2 * (int)gridDim.y * (KV_PART_FLOATS / 4), per = (total + nwg - 1) / nwg;
             fused_kv_sum(a, min(total, wg * per), min(total, (wg + 1) * per), fw, lane);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // every wave's write-through stores have completed ...
+        __threadfence();
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(a.red_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... before the count moves
+        if (tid == 0) __hip_atomic_fetch_add(a.red_count, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
