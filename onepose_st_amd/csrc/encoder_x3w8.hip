@@ -616,11 +616,7 @@ int layer_x3w8(const float* x3d, const float* x2d, float* y3d, float* y2d, int B
         if (int rc = ophip_lds_attr(reinterpret_cast<const void*>(enc_x3w8_kernel<true, true>), LDS_BYTES, "hipFuncSetAttribute(enc_x3w8 kv masked)")) return rc;
     }
 
-    unsigned* sync = reinterpret_cast<unsigned*>(kv + (size_t)B * 2 * KV_BLOCK_BYTES);          // two launch counters behind the K^T V blocks
-    sync = reinterpret_cast<unsigned*>((reinterpret_cast<uintptr_t>(sync) + 63) & ~(uintptr_t)63);
     EncW8Args aa;
-    aa.red_partial = nullptr; aa.red_kv = nullptr; aa.red_count = nullptr;
-    aa.zero_count = sync + (slot ^ 1);                    // the next launch of the chain counts on the other slot's word: every launch clears it
     aa.x[0] = x3d; aa.x[1] = x2d; aa.y[0] = y3d; aa.y[1] = y2d;
     aa.xbs[0] = aa.ybs[0] = (long long)L3d * C; aa.xbs[1] = aa.ybs[1] = (long long)L2d * C;
     aa.L[0] = L3d; aa.L[1] = L2d; aa.tiles[0] = t3; aa.tiles[1] = t2;
@@ -646,6 +642,10 @@ int layer_x3w8(const float* x3d, const float* x2d, float* y3d, float* y2d, int B
     // The slab sum inside the consuming launch (fused_kv_sum) when every workgroup of that launch is resident at once -- one workgroup
     // per CU, so B x tiles <= CUs: c1 and c2 at B = 1, not c4 or a batch of 32 -- and the slabs come from the previous layer's fused tail
     // (kv_mode 1: layers 1 .. n - 1 of a chain; the first layer's sum runs off the critical path anyway).  OPHIP_ENC_FUSED_KVSUM=0: never.
+    unsigned* sync = reinterpret_cast<unsigned*>(kv + (size_t)B * 2 * KV_BLOCK_BYTES);
+    sync = reinterpret_cast<unsigned*>((reinterpret_cast<uintptr_t>(sync) + 63) & ~(uintptr_t)63);
+    aa.red_partial = nullptr; aa.red_kv = nullptr; aa.red_count = nullptr;
+    aa.zero_count = sync + (slot ^ 1);                    // the next launch of the chain counts on the other slot's word
     const bool fuse_sum = fused_kvsum_enabled() && kv_mode == 1 && !only_kv && (long long)B * (t3 + t2) <= cu_count_cached();
     if (kv_mode != 2 && !fuse_sum) {
         KvSumArgs sa;
