@@ -25,10 +25,8 @@ extern "C" {
  * compares the two before its first call.  History: 1 = rounds 1-2; 2 = round 3 (lazy_conf inside ophip_frame_desc, the extended
  * ophip_frame_layout_t, ophip_frame_wait takes the TICKET ophip_frame_enqueue returned (generation * 16 + slot, never below 16),
  * ophip_encoder_layer_x3 / ophip_fine_refine_x3 removed); 3 = round 4 (ophip_encoder_kv_first_x3w8 added, kv_from_prev = 2 accepted by the
- * x3w8 layer entry points: additive, but a binding that names the new symbol needs a library that has it); 4 = end of round 4
- * (ophip_encoder_sync_timeouts added; ophip_encoder_x3w8_workspace_bytes grew by 128 bytes -- a workspace sized by an older library is
- * too small for this one). */
-#define OPHIP_ABI_VERSION 4
+ * x3w8 layer entry points: additive, but a binding that names the new symbol needs a library that has it). */
+#define OPHIP_ABI_VERSION 3
 int ophip_abi_version(void);
 /* host string: 16 hex digits of the sha256 over the sources this library was built from (the profiles/ pmc summaries record it;
  * bench.py quotes committed counter values only when they were taken on the running build) */
@@ -116,11 +114,6 @@ int ophip_encoder_layer_x3w8(const float* x3d, const float* x2d, float* y3d, flo
  * slot, workspace).  mask2d: NULL, or the layer's query mask.  Bit-identical to the one-call layer (same kernels in the same order). */
 int ophip_encoder_kv_first_x3w8(const float* x3d, const float* x2d, int B, int L3d, int L2d, const void* wpack, int slot,
                                 void* workspace, const unsigned char* mask2d, void* stream);
-/* Layers 1 .. n - 1 of a chain whose B x ceil(L / 48) workgroups fit the chip at once (one per CU) sum the previous layer's K^T V slabs
- * INSIDE the consuming launch (each workgroup a share, a counter, a bounded wait before the attention phase: no kv_sum launch, bit-identical
- * sums; OPHIP_ENC_FUSED_KVSUM=0 switches it off).  The wait is bounded at about a second; this returns how many launches ran into the bound
- * since the library was loaded (0 in a healthy process; -1: the query failed).  Synchronises the device. */
-int ophip_encoder_sync_timeouts(void);
 
 /* a7 + a8 -- CoarseMatching.forward + get_coarse_match, inference branch
  * (utils/coarse_matching.py:76-123, :125-242, mask_border :10-20).

@@ -45,11 +45,6 @@ struct EncW8Args {
     char* frag[2];             // optional: the output rows also as the similarity kernel's operand fragments (csrc/coarse_match.hip:
     int frag_rows[2];          // frag_planes layout, rows padded to frag_rows = a multiple of 128); NULL: not written
     const unsigned char* mask2d;   // MASKED kernels: [B][L[1]] 1 = real cell, 0 = padding of the 2D stream (linear_attention.py:49-53)
-    // the slab sum inside this launch (fused_kv_sum below) instead of a kv_sum launch in front of it; red_count NULL: not used
-    const float* red_partial;      // the slabs this layer's K^T V is the sum of (what kv_sum_w8_kernel would read)
-    char* red_kv;                  // where it goes (what kv_sum_w8_kernel would write: the block kv[] points into)
-    unsigned* red_count;           // workgroups that have published their share; the launch waits for all of them before it reads kv[]
-    unsigned* zero_count;          // the counter of the NEXT launch of this chain, cleared by this one (NULL: none)
 };
 
 __device__ __forceinline__ int stash_off(int row, int chunk) { return row * (C * 4) + ((chunk ^ (row & 15)) << 4); }
@@ -131,97 +126,6 @@ __device__ __forceinline__ void kv_tail(Ring& ring, const WStream& wsk, const ch
     }
 }
 
-constexpr int KVS_G = 64;          // tile groups per workgroup: a thread sums tiles g, g + 64, g + 128, ... (<= 3 at c2: all its loads in flight at once)
-constexpr int KVS_L = 16;          // lanes per group: one workgroup reduces 64 consecutive floats (16 x f32x4) of the 8448 of a slab
-
-__device__ unsigned g_kv_sync_timeouts = 0;        // workgroups whose wait for the other workgroups' shares ran out (ophip_encoder_sync_timeouts)
-
-// kv_sum_w8_kernel's sum, distributed over the workgroups of the launch that consumes it: workgroup w of W takes quads [w per, (w + 1) per) of
-// the 2 B x 2112 output quads, one quad per wave and step; lane g plays thread group g of kv_sum_w8_kernel (tiles g, g + 64, g + 128 in that
-// kernel's association), the 64 -> 8 -> 1 merge runs over the lanes in its order: bit-identical outputs, no launch, no launch boundary.
-// The launch then needs every workgroup's share before its attention phase: a counter and a BOUNDED wait (wait_kv_shares).  All W
-// workgroups are resident at once when W <= number of CUs (a workgroup takes a whole CU's LDS) and nothing else holds CUs for good, which
-// the host checks as far as it can; what it cannot see -- a second process on the device running the same kind of launch, each holding
-// half the chip and waiting for the other half -- ends in the wait's bound, after which a workgroup sums the whole block it needs itself
-// (same code, same bits, written to the same place): slow, never wrong, never stuck.
-__device__ __forceinline__ void fused_kv_sum(const EncW8Args& a, int q_begin, int q_end, int fw, int lane) {
-    constexpr int QUADS = KV_PART_FLOATS / 4;                       // per (batch, stream)
-    const int ttot = a.tiles[0] + a.tiles[1];
-    for (int qq = q_begin + fw; qq < q_end; qq += NW) {
-        const int bs = qq / QUADS, e = (qq - bs * QUADS) * 4;
-        const int s = bs & 1, b = bs >> 1;
-        const int t0 = s ? a.tiles[0] : 0, nt = a.tiles[s];
-        const float* p = a.red_partial + ((size_t)b * ttot + t0) * KV_PART_FLOATS + e;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        int t = lane;
-        for (; t + 2 * KVS_G < nt; t += 3 * KVS_G) {
-            const f32x4 u0 = *reinterpret_cast<const f32x4*>(p + (size_t)t * KV_PART_FLOATS);
-            const f32x4 u1 = *reinterpret_cast<const f32x4*>(p + (size_t)(t + KVS_G) * KV_PART_FLOATS);
-            const f32x4 u2 = *reinterpret_cast<const f32x4*>(p + (size_t)(t + 2 * KVS_G) * KV_PART_FLOATS);
-            acc = ((acc + u0) + u1) + u2;
-        }
-        for (; t < nt; t += KVS_G) acc += *reinterpret_cast<const f32x4*>(p + (size_t)t * KV_PART_FLOATS);
-        // 64 -> 8: lane g < 8 adds groups g, g + 8, ..., g + 56 in that order (every lane computes the chain of lane & 7); 8 -> 1: 0, 1, ..., 7
-        f32x4 tot;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = __shfl(acc[r], lane & 7, 64);
-#pragma unroll
-            for (int k = 1; k < KVS_G / 8; ++k) v += __shfl(acc[r], (lane & 7) + 8 * k, 64);
-            float f = __shfl(v, 0, 64);
-#pragma unroll
-            for (int k = 1; k < 8; ++k) f += __shfl(v, k, 64);
-            tot[r] = f;
-        }
-        if (lane == 0) {
-            char* blk = a.red_kv + ((size_t)b * 2 + s) * KV_BLOCK_BYTES;
-            if (e < NH * 1024) {
-                const int ln = (e >> 2) & 63, vt = (e >> 8) & 1, dt = (e >> 9) & 1, head = e >> 10;
-                bf16x4 vh, vl;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    __bf16 hh, ll;
-                    split_bf16(tot[r], hh, ll);
-                    vh[r] = hh; vl[r] = ll;
-                }
-                const size_t fr = (size_t)(head * 2 + vt) * 2;
-                *reinterpret_cast<bf16x4*>(blk + ((fr + 0) * 64 + ln) * 16 + 8 * dt) = vh;
-                *reinterpret_cast<bf16x4*>(blk + ((fr + 1) * 64 + ln) * 16 + 8 * dt) = vl;
-            } else {
-                *reinterpret_cast<f32x4*>(blk + KV_FRAG_BYTES + (size_t)(e - NH * 1024) * 4) = tot;
-            }
-        }
-    }
-}
-
-constexpr unsigned long long KV_WAIT_TICKS = 20000;            // bound of the wait below: 200 us of the 100 MHz s_memrealtime clock
-
-// Every workgroup of the launch has published its share (release: fence + counter) -> this workgroup may read kv[] (acquire).  One thread
-// polls, for at most KV_WAIT_TICKS; when the bound is reached the workgroup sums the block it reads -- (batch b, source stream of its own
-// stream) -- itself.  `flag`: one LDS word.
-__device__ __forceinline__ void wait_kv_shares(const EncW8Args& a, int nwg, int tid, int fw, int lane, int b, int s, volatile int* flag) {
-    if (tid == 0) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        int ok = 1;
-        while (__hip_atomic_load(a.red_count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nwg) {
-            __builtin_amdgcn_s_sleep(4);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > KV_WAIT_TICKS) { ok = 0; atomicAdd(&g_kv_sync_timeouts, 1u); break; }
-        }
-        *flag = ok;
-    }
-    __syncthreads();
-    const int ok = *flag;
-    if (!ok) {
-        constexpr int QUADS = KV_PART_FLOATS / 4;
-        const int src = (int)((a.kv[s] - a.red_kv) / KV_BLOCK_BYTES) & 1;
-        const int q0 = (b * 2 + src) * QUADS;
-        fused_kv_sum(a, q0, q0 + QUADS, fw, lane);
-        __threadfence();
-        __syncthreads();
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-
 template <bool ONLY_KV, bool MASKED = false>
 __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kernel(EncW8Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -249,9 +153,6 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
     Ring ring;
     OPHIP_STAMP(a.stamps, wg, 0);
     OPHIP_STAMP_REAL(a.stamps, wg, 30);
-    if (a.zero_count && wg == 0 && tid == 0) *a.zero_count = 0u;
-    const int nwg = gridDim.x * gridDim.y;
-    const bool fused_sum = !ONLY_KV && a.red_count != nullptr;
 
     // activation rows: 48 x 256 f32, (row, 8-feature chunk) items over 512 threads
     constexpr int ITEMS = TOK * (C / 8) / 512;       // 3
@@ -278,7 +179,7 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
     // attention state of head fw and the LayerNorm parameters of this lane's features
     bf16x8 kvh[2], kvl[2];
     f32x4 ksm[2], g1[2], b1[2], g2[2], b2[2];
-    auto load_kv = [&] {
+    if (!ONLY_KV) {
         const char* kvb = a.kv[s] + (size_t)b * a.kvbs;
 #pragma unroll
         for (int vt = 0; vt < 2; ++vt) {
@@ -288,9 +189,6 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
         const float* kp = reinterpret_cast<const float*>(kvb + KV_FRAG_BYTES) + fw * 32 + 4 * q;
         ksm[0] = *reinterpret_cast<const f32x4*>(kp);
         ksm[1] = *reinterpret_cast<const f32x4*>(kp + 16);
-    };
-    if (!ONLY_KV) {
-        if (!fused_sum) load_kv();
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft) {
             const int f0 = 32 * fw + 16 * ft + 4 * q;
@@ -301,17 +199,6 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (fused_sum) {
-        // this workgroup's share of the slab sum, while its activation rows and first weight fragments are on their way; published with a
-        // release (fence, then the counter) after every wave's stores
-        {
-            const int total = 2 * (int)gridDim.y * (KV_PART_FLOATS / 4), per = (total + nwg - 1) / nwg;
-            fused_kv_sum(a, min(total, wg * per), min(total, (wg + 1) * per), fw, lane);
-        }
-        __threadfence();
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(a.red_count, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const int it = tid + 512 * i, row = it >> 5, ch = it & 31;
@@ -346,11 +233,6 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
             for (int tt = 0; tt < NTT; ++tt) qa[ft][tt] = zero4();
         gemm_stage<NTT, 2, 8, true>(qa, ring, wsm, 0 + R, XH, XL, ROWB, 0, c16, q);
         OPHIP_STAMP(a.stamps, wg, 2);
-        if (fused_sum) {                             // the summed K^T V / Ksum block is complete when every workgroup has published its share
-            wait_kv_shares(a, nwg, tid, fw, lane, b, s, reinterpret_cast<volatile int*>(scratch));
-            __syncthreads();                         // (the flag word lives in the LayerNorm scratch: read by every wave before anything reuses it)
-            load_kv();
-        }
         const float S = a.srclen[s];
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) {
@@ -505,6 +387,9 @@ struct KvSumArgs {
     int tiles[2];
 };
 
+constexpr int KVS_G = 64;          // tile groups per workgroup: a thread sums tiles g, g + 64, g + 128, ... (<= 3 at c2: all its loads in flight at once)
+constexpr int KVS_L = 16;          // lanes per group: one workgroup reduces 64 consecutive floats (16 x f32x4) of the 8448 of a slab
+
 // Sum of a stream's K|V partial slabs in a FIXED order (no float atomics: bit-reproducible) -> KV as (hi, lo) bf16 A-operand
 // fragments + Ksum f32.  Latency-bound: 264 workgroups (every CU busy) whose threads each issue all their loads at once, instead of
 // 66 workgroups looping over the tiles (5.4 -> ~2 us per launch at c2).
@@ -561,31 +446,12 @@ __global__ __launch_bounds__(1024) void kv_sum_w8_kernel(KvSumArgs a) {
 
 extern "C" size_t ophip_encoder_x3w8_workspace_bytes(int B, int L3d, int L2d) {
     const size_t tiles = (size_t)((L3d + TOK - 1) / TOK + (L2d + TOK - 1) / TOK);
-    return 2 * (size_t)B * tiles * KV_PART_FLOATS * 4 + (size_t)B * 2 * KV_BLOCK_BYTES + 256 + 128;      // (+ 128: the two launch counters, 64-byte aligned)
-}
-
-extern "C" int ophip_encoder_sync_timeouts(void) {         // launches whose bounded wait for the fused slab sum ran out since the library was loaded (0 = none)
-    unsigned v = 0;
-    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_kv_sync_timeouts), sizeof(v)) != hipSuccess) return -1;
-    return (int)v;
+    return 2 * (size_t)B * tiles * KV_PART_FLOATS * 4 + (size_t)B * 2 * KV_BLOCK_BYTES + 256;
 }
 
 extern "C" size_t ophip_encoder_x3w8_wpack_bytes(void) { return (size_t)NW * (MAIN_FRAGS + KV_FRAGS) * 1024 + 4 * C * 4; }
 
 namespace {
-bool fused_kvsum_enabled() {
-    static const bool on = [] { const char* e = getenv("OPHIP_ENC_FUSED_KVSUM"); return !(e && e[0] == '0'); }();
-    return on;
-}
-int cu_count_cached() {
-    static const int n = [] {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
-        return p.multiProcessorCount;
-    }();
-    return n;
-}
 // kv_mode: 0 = this call projects its own K, V (kv_reduce), sums the slabs (kv_sum) and applies; 1 = the slabs are there (the previous
 // layer's fused tail wrote them): kv_sum + apply; 2 = the summed K^T V / Ksum block is there (ophip_encoder_kv_first_x3w8 ran): apply only.
 // only_kv: stop after kv_reduce + kv_sum (the body of ophip_encoder_kv_first_x3w8; y3d / y2d / wpack_next unused).
@@ -639,15 +505,7 @@ int layer_x3w8(const float* x3d, const float* x2d, float* y3d, float* y2d, int B
         else { OPHIP_LAUNCH("kv_reduce", stream, enc_x3w8_kernel<true>, dim3(t3 + t2, B), dim3(512), LDS_BYTES, stream, ka); }
         OPHIP_CHECK_LAUNCH();
     }
-    // The slab sum inside the consuming launch (fused_kv_sum) when every workgroup of that launch is resident at once -- one workgroup
-    // per CU, so B x tiles <= CUs: c1 and c2 at B = 1, not c4 or a batch of 32 -- and the slabs come from the previous layer's fused tail
-    // (kv_mode 1: layers 1 .. n - 1 of a chain; the first layer's sum runs off the critical path anyway).  OPHIP_ENC_FUSED_KVSUM=0: never.
-    unsigned* sync = reinterpret_cast<unsigned*>(kv + (size_t)B * 2 * KV_BLOCK_BYTES);
-    sync = reinterpret_cast<unsigned*>((reinterpret_cast<uintptr_t>(sync) + 63) & ~(uintptr_t)63);
-    aa.red_partial = nullptr; aa.red_kv = nullptr; aa.red_count = nullptr;
-    aa.zero_count = sync + (slot ^ 1);                    // the next launch of the chain counts on the other slot's word
-    const bool fuse_sum = fused_kvsum_enabled() && kv_mode == 1 && !only_kv && (long long)B * (t3 + t2) <= cu_count_cached();
-    if (kv_mode != 2 && !fuse_sum) {
+    if (kv_mode != 2) {
         KvSumArgs sa;
         sa.partial = partial; sa.kv = kv; sa.tiles[0] = t3; sa.tiles[1] = t2;
         static_assert(KV_PART_FLOATS % (4 * KVS_L) == 0, "a slab is a whole number of 64-float chunks");
@@ -659,7 +517,6 @@ int layer_x3w8(const float* x3d, const float* x2d, float* y3d, float* y2d, int B
     aa.kv[1] = kv + (is_cross ? 0 : KV_BLOCK_BYTES);
     aa.wkv = nullptr;
     aa.partial = partial_next;
-    if (fuse_sum) { aa.red_partial = partial; aa.red_kv = kv; aa.red_count = sync + slot; }
     if (wpack_next) aa.wkv = reinterpret_cast<const bf16x8*>(wpack_next) + (size_t)NW * MAIN_FRAGS * 64;
     if (mask2d) { OPHIP_LAUNCH("attn_apply", stream, (enc_x3w8_kernel<false, true>), dim3(t3 + t2, B), dim3(512), LDS_BYTES, stream, aa); }
     else { OPHIP_LAUNCH("attn_apply", stream, enc_x3w8_kernel<false>, dim3(t3 + t2, B), dim3(512), LDS_BYTES, stream, aa); }

@@ -14,7 +14,7 @@ import torch
 
 _LIB_PATH = os.environ.get("OPHIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libonepose_hip.so")   # OPHIP_LIB: A/B builds
 _lib = None
-ABI_VERSION = 4         # include/onepose_hip.h OPHIP_ABI_VERSION: what FrameDesc / FrameLayout / _SIGNATURES below are written for
+ABI_VERSION = 3         # include/onepose_hip.h OPHIP_ABI_VERSION: what FrameDesc / FrameLayout / _SIGNATURES below are written for
 
 c_f = ctypes.c_void_p      # device float*
 c_i = ctypes.c_int
@@ -73,7 +73,6 @@ _SIGNATURES = {
     "ophip_encoder_x3w8_wpack_bytes": (ctypes.c_size_t, []),
     "ophip_encoder_layer_x3w8": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_i, c_i, c_i, c_f, ctypes.c_void_p]),
     "ophip_encoder_kv_first_x3w8": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_i, c_f, c_f, ctypes.c_void_p]),
-    "ophip_encoder_sync_timeouts": (c_i, []),
     "ophip_encoder_layer_x3w8_frag": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_i, c_i, c_i, c_f, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "ophip_coarse_frag_planes": (c_i, [c_f, c_i, c_i, c_i, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]),
     "ophip_coarse_workspace_floats": (ctypes.c_size_t, [c_i, c_i, c_i]),
