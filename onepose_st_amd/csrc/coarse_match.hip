@@ -630,16 +630,20 @@ constexpr int CONF_ROWS_MAX = 512;              // OPHIP_CONF_ROWS_RT (run time)
                                                 // Round 4, c2, in the pipeline (frames/s, 100 steps, interleaved, two boxes): rows 32 / 48 / 64 / 80 / 96 at CONF_RB 2 and 4 all within
                                                 // the +-3 % run-to-run spread (1 428-1 472), 128 and 256 worse (the pass, 143 / 275 us alone, becomes the frame's longest kernel)
 #ifndef OPHIP_CONF_RB
-#define OPHIP_CONF_RB 2
+#define OPHIP_CONF_RB 1
 #endif
 constexpr int CONF_RB = OPHIP_CONF_RB;          // rows per pipeline stage (two stages in flight): what a workgroup keeps in flight is 2 * CONF_RB * CONF_U KiB per wave
 #ifndef OPHIP_CONF_U
-#define OPHIP_CONF_U 3
+#define OPHIP_CONF_U 1
 #endif
 // float4 groups per thread per row => a span of <= 1024 CONF_U columns.  Alone at c2: 2 -> 94 us (123 VGPRs), 3 -> 90 us (164), 4 -> 87 us (212).
 // Beside the previous frame's fine stage (whose waves hold 256 registers, two per SIMD: a wave of this pass enters a SIMD in place of one
 // of them) 2 and 3 measure the same within noise (1355 against 1330 frames/s over four runs each, fine stage 292 us in both traces): the
 // bytes a wave keeps in flight per register it holds are the same.
+// End of round 4: CONF_U 1 and CONF_RB 1 (52 registers instead of 138).  The pass runs in the window where the previous frame's fine stage
+// holds every register of every SIMD it sits on and gets the slots that stage's retiring workgroups leave: at 52 registers four of its waves
+// fit where one did.  Interleaved whole-process runs, c2, 100 steps, three boxes: 1 438 -> 1 491, 1 484 -> 1 489, 1 510 -> 1 538 (medians of
+// 3, 4 and 8 rounds); the intermediate settings (U 1 / RB 2: 63 registers, U 2 / RB 1: 86) fall between.
 constexpr int CONF_U = OPHIP_CONF_U;
 
 template <bool VEC, bool FAST>
