@@ -64,19 +64,23 @@ def attn_apply_flops(n_tokens: int, fused_kv: bool, n_layers: int = 6, C: int = 
     return float(n_tokens) * per_tok
 
 
-def rank_report(rows, world: int, frames_expected: int) -> dict:
+def rank_report(rows, world: int, frames_expected: int, poses_expected: int = -1) -> dict:
     """What rank 0 prints about EVERY rank, so that a --gpus N line checks itself: `rows` = the all-gathered per-rank records
-    [rank, frames finished, own seconds of the timed region, own PnP ceiling in frames/s, local rank / device index].  `reporting` must
-    equal `expected` and every rank must have finished its frames; `value_sum_of_ranks` (each rank's own rate, summed) against the
-    line's `value` (all frames / slowest rank's time) shows how uneven the ranks were.  Reference pattern: the driver-side fan-out and
+    [rank, frames FINISHED inside the timed region (counted where a frame's results reach the host), own seconds of the timed region, own
+    PnP ceiling in frames/s, local rank / device index, poses JOINED inside the timed region].  `reporting` must equal `expected` and every
+    rank must have finished its frames (and joined as many poses when host PnP is on: poses_expected >= 0); `value_sum_of_ranks` (each
+    rank's own rate, summed) against the line's `value` (all frames / slowest rank's time) shows how uneven the ranks were.  Every rank
+    evaluates the same gathered rows and exits non-zero on a shortfall (bench.py main).  Reference pattern: the driver-side fan-out and
     gather of inference_OnePosePlus.py:81-98."""
     per = []
     for r in rows:
         rk, frames, secs, ceil_, dev_ix = (float(x) for x in r[:5])
-        per.append({"rank": int(rk), "device": int(dev_ix), "frames": int(frames), "seconds": secs,
+        poses = int(r[5]) if len(r) > 5 else -1
+        per.append({"rank": int(rk), "device": int(dev_ix), "frames": int(frames), "poses": poses, "seconds": secs,
                     "value": (frames / secs) if secs > 0 else None, "pnp_ceiling_fps": ceil_ if ceil_ > 0 else None})
     per.sort(key=lambda d: d["rank"])
-    ok = (len(per) == world and [d["rank"] for d in per] == list(range(world)) and all(d["frames"] == frames_expected for d in per))
+    ok = (len(per) == world and [d["rank"] for d in per] == list(range(world)) and all(d["frames"] == frames_expected for d in per)
+          and (poses_expected < 0 or all(d["poses"] == poses_expected for d in per)))
     vals = [d["value"] for d in per if d["value"]]
     return {"expected": world, "reporting": len(per), "all_frames_done": bool(ok),
             "value_sum_of_ranks": sum(vals) if vals else None,
@@ -162,21 +166,27 @@ def main():
             dist.all_reduce(seen)
         sizes = torch.tensor([float(len(my_cpus)), float(pnp_threads), float(my_cpus[0])])
         # the per-rank report of the real line (rank_report below), filled with stand-in numbers: frames done, own seconds, own PnP ceiling
-        mine = torch.tensor([float(rank), float(args.steps * args.batch), 1.0 + 0.01 * rank, 1000.0 + rank, float(local)], dtype=torch.float64)
+        # (OPHIP_BENCH_PROBE_SHORT_RANK=r: rank r reports one frame fewer -- tests/test_launch.py checks that EVERY rank then exits non-zero)
+        short = 1.0 if os.environ.get("OPHIP_BENCH_PROBE_SHORT_RANK") == str(rank) else 0.0
+        mine = torch.tensor([float(rank), float(args.steps * args.batch) - short, 1.0 + 0.01 * rank, 1000.0 + rank, float(local),
+                             float(args.steps * args.batch)], dtype=torch.float64)
         if world > 1:
             gathered = [torch.zeros(3) for _ in range(world)]
             dist.all_gather(gathered, sizes)
-            reports = [torch.zeros(5, dtype=torch.float64) for _ in range(world)]
+            reports = [torch.zeros(6, dtype=torch.float64) for _ in range(world)]
             dist.all_gather(reports, mine)
         else:
             gathered, reports = [sizes], [mine]
+        rep = rank_report([r.tolist() for r in reports], world, args.steps * args.batch, args.steps * args.batch)
         if rank == 0:
             print(json.dumps({"probe": True, "n_gpus": world, "rank_sum": float(seen.item()), "local_rank": local,
                               "host_cores": [int(g[0]) for g in gathered], "pnp_threads": [int(g[1]) for g in gathered],
                               "first_cpu": [int(g[2]) for g in gathered],
-                              "ranks": rank_report(reports, world, args.steps * args.batch)}))
+                              "ranks": rep}))
         if world > 1:
             dist.destroy_process_group()
+        if not rep["all_frames_done"]:          # every rank holds the same gathered rows: all of them leave with an error
+            raise SystemExit(f"rank {rank}: not every rank finished its frames: {rep}")
         return
     from onepose_st_amd import hip
     from onepose_st_amd.config import default_config
@@ -274,6 +284,7 @@ def main():
     last_host = [None]      # the most recent frame's matches on the host: what the PnP-ceiling measurement replays
 
     inflight = []
+    done = {"frames": 0, "poses": 0}       # counted where it happens: frames whose results reached the host (complete), poses joined (join_poses)
 
     host_t = {"enqueue": 0.0, "wait": 0.0, "finish": 0.0, "submit": 0.0}       # host-side seconds, printed with OPHIP_BENCH_TRACE=1
 
@@ -295,6 +306,7 @@ def main():
                         pending.append(pool.submit(hst["mkpts_2d"][sel], hst["mkpts_3d_db"][sel]))
         data = pend.finish(on_host=submit)
         host_t["finish"] += time.perf_counter() - t          # (includes the submit since round 4)
+        done["frames"] += B
         return data
 
     # frames alternate over `--streams` HIP streams: consecutive frames are independent, so the single-workgroup
@@ -332,6 +344,7 @@ def main():
             return []
         pool.wait_all()
         out = [pool.result(tk) for tk in pending]
+        done["poses"] += len(out)
         pending.clear()
         return out
 
@@ -371,11 +384,15 @@ def main():
     n_inliers = int(poses[-1][1]) if poses else -1
 
     own_dt = [0.0]          # this rank's own seconds of the last timed region (before the max over ranks)
+    own_done = [0, 0]       # frames finished / poses joined by this rank INSIDE the last timed region (measured, not args.steps * B)
     HOT_STEPS = int(os.environ.get("OPHIP_BENCH_HOT_STEPS", "32"))          # untimed matcher-only frames right before every timed region (see timed_region)
 
-    def timed_region(active_pool):
-        """W warm-up + exactly K timed steps with `active_pool` solving the poses (None: matcher only); returns seconds (max over ranks)"""
+    def timed_region(active_pool, hot_steps=None):
+        """W warm-up + exactly K timed steps with `active_pool` solving the poses (None: matcher only); returns seconds (max over ranks).
+        hot_steps: untimed matcher-only frames right in front of the clock (default HOT_STEPS; 0 = the region starts on a GPU that has just
+        been idle for the warm-up's pose join: the post-idle clock transient is then INSIDE the timed steps, `value_no_hot_steps`)"""
         nonlocal pool
+        n_hot = HOT_STEPS if hot_steps is None else hot_steps
         pool = active_pool
         for i in range(args.warmup):
             step(i)
@@ -389,7 +406,7 @@ def main():
         # host PnP (nothing to join afterwards) bring it back to the state it holds in a running pipeline; then the barrier + synchronize the
         # contract asks for, and the clock starts on a GPU that has been idle for microseconds.  (Counted in setup_steps_untimed.)
         pool = None
-        for i in range(HOT_STEPS):
+        for i in range(n_hot):
             step(i)
         drain()
         pool = active_pool
@@ -398,6 +415,7 @@ def main():
         sync_all()
         for k in host_t:
             host_t[k] = 0.0
+        f0, p0 = done["frames"], done["poses"]
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(i)
@@ -409,6 +427,7 @@ def main():
         gc.enable()
         host_t["tail"] = dt_ - (t_gpu - t0)          # after the last frame left the GPU: its pose (and the final barrier)
         own_dt[0] = dt_
+        own_done[0], own_done[1] = done["frames"] - f0, done["poses"] - p0
         if dist_on:
             import torch.distributed as dist
             tt = torch.tensor([dt_], device=dev, dtype=torch.float64)
@@ -416,9 +435,33 @@ def main():
             dt_ = float(tt.item())
         return dt_
 
+    def dependent_region(active_pool, n):
+        """The reference's own loop (inference.py:148-190): ONE frame in flight -- frame t + 1 is enqueued only after frame t's pose has been
+        joined (its crop would come from that pose: pred_poses[id - 1] -> previous_pose_detect -> model -> ransac_PnP).  Same workload, same PnP
+        policy; returns (seconds for n frames, per-frame latencies enqueue -> pose in seconds).  A lone frame's kept-back fine stage goes
+        out with its wait (ophip_frame_wait), so there is no flush() round trip; the pose solve starts from the finish() callback."""
+        nonlocal pool
+        pool = active_pool
+        for i in range(4):                                # untimed: first-use costs of the depth-1 pattern
+            complete(model.enqueue_features(dict(obj_b), *batches[i % len(batches)], image_hw, host_copy=pool is not None, inputs_ready=image is None))
+            join_poses()
+        sync_all()
+        lat = []
+        t0 = time.perf_counter()
+        for i in range(n):
+            fc, ff = batches[i % len(batches)]
+            t1 = time.perf_counter()
+            with torch.cuda.stream(streams[0]):
+                pend = model.enqueue_features(dict(obj_b), fc, ff, image_hw, host_copy=pool is not None, inputs_ready=image is None and not args.inputs_behind)
+            complete(pend)
+            join_poses()
+            lat.append(time.perf_counter() - t1)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, lat
+
     # side measurements first (the other PnP policy, the matcher alone), the contract's region last with the kernel timing on
     other = {"reference": "adaptive", "adaptive": "reference"}[args.pnp_policy]
-    dt_other = dt_matcher = dt_cached = dt_lazy = lazy_reruns = None
+    dt_other = dt_matcher = dt_cached = dt_lazy = lazy_reruns = dt_nohot = dt_dep = lat_dep = dt_dep_cached = None
     if not args.main_region_only and args.precision != "f32":
         # SURVEY 8(d): the mode in which conf_matrix is not requested, reported beside the headline (which stays eager: the reference
         # writes the matrix every frame).  config["hip_conf_matrix"] = "lazy": nothing N x M is stored, match lists bit-identical
@@ -439,9 +482,16 @@ def main():
     if not args.main_region_only:
         dt_other = timed_region(pools[other]) if pools else None
         dt_matcher = timed_region(None)
-        model.cache_object = True                       # per-object cache of the keypoint encoding (config["hip_cache_object"]): a sequence's
-        dt_cached = timed_region(None)                  # frames share one resident object block; matcher only, to compare with dt_matcher
+        model.cache_object = True                       # per-object cache (config["hip_cache_object"]): keypoint encoding, first layer's 3D rows, layer 1's
+        dt_cached = timed_region(None)                  # 3D-source block -- a sequence's frames share one resident object block; matcher only, to compare with dt_matcher
+        if world == 1 and B == 1:
+            dt_dep_cached, _ = dependent_region(pools.get(args.pnp_policy), max(args.steps, 20))
         model.cache_object, model._obj_cache = False, None
+        if world == 1 and B == 1:
+            # the dependent sequence (one frame in flight): the number a user of the reference's inference.py loop sees
+            dt_dep, lat_dep = dependent_region(pools.get(args.pnp_policy), max(args.steps, 20))
+        # the same K steps WITHOUT the untimed hot frames in front of the clock: the post-idle clock transient inside the timed steps
+        dt_nohot = timed_region(pools.get(args.pnp_policy), hot_steps=0)
     # the timed launches carry a start / stop event pair filled with the dispatch's own timestamps (hipExtLaunchKernelGGL); such a launch
     # costs the stream a few us more than a plain one: timing all 6 launches of every frame took 9 % off `value`, every 11th launch
     # (coprime with the 6 layers, so every layer is sampled equally) ~2 %, with the same average
@@ -476,6 +526,7 @@ def main():
     thr0 = throttle_stat()
     dt = timed_region(pools.get(args.pnp_policy))
     dt_own = own_dt[0]
+    main_done = list(own_done)
     thr1 = throttle_stat()
     if tc0 is not None and rank == 0:
         tc1, wall = thread_cpu(), time.perf_counter() - t_wall0
@@ -488,6 +539,14 @@ def main():
               + f"; wall {1e6 * dt / args.steps:.0f}; after the last frame left the GPU {1e6 * host_t.get('tail', 0.0):.0f} us in all", file=sys.stderr)
     launches, kern_ms = hip.timing_read()
     hip.timing_select("")
+    sim_launches, sim_ms = 0, 0.0
+    if args.roofline_kernel == "conf":
+        # the N x M STAGE (similarity tiles + dual softmax): a second region of the same K steps with the tile kernel's launches
+        # bracketed, so that the line can divide the stage's algorithmic bytes by BOTH kernels' time (`stage_frac`)
+        hip.timing_select("sim_stats", every=1)
+        timed_region(pools.get(args.pnp_policy))
+        sim_launches, sim_ms = hip.timing_read()
+        hip.timing_select("")
 
     # The same kernel with the chip to itself: eight frames one at a time (enqueue, flush the kept-back fine stage, finish, synchronize), every
     # launch bracketed.  Since the end of round 4 the pipeline lets the encoder's first layer start beside the previous frame's last fine
@@ -565,7 +624,8 @@ def main():
         pass
 
     # every rank's own record travels to rank 0: the line then says how many ranks reported, what each did, and what the broadcast cost
-    mine = torch.tensor([float(rank), float(args.steps * B), float(dt_own), float(own_rate), float(local)], dtype=torch.float64, device=dev)
+    # (frames / poses: what this rank COUNTED inside the timed region -- a frame whose results reached the host, a pose that was joined)
+    mine = torch.tensor([float(rank), float(main_done[0]), float(dt_own), float(own_rate), float(local), float(main_done[1])], dtype=torch.float64, device=dev)
     if dist_on:
         import torch.distributed as dist
         rows = [torch.zeros_like(mine) for _ in range(world)]
@@ -573,12 +633,20 @@ def main():
         rows = [r.cpu().tolist() for r in rows]
     else:
         rows = [mine.cpu().tolist()]
-    ranks = rank_report(rows, world, args.steps * B)
-    if rank == 0 and not ranks["all_frames_done"]:
-        raise SystemExit(f"--gpus {world}: {ranks['reporting']} of {ranks['expected']} ranks reported / not every rank finished its frames: {ranks}")
+    ranks = rank_report(rows, world, args.steps * B, -1 if pools.get(args.pnp_policy) is None else args.steps * B)
+    if not ranks["all_frames_done"]:          # the verdict is the same on every rank (same gathered rows): all of them exit non-zero
+        if dist_on:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        raise SystemExit(f"--gpus {world} (rank {rank}): {ranks['reporting']} of {ranks['expected']} ranks reported / not every rank finished its frames: {ranks}")
 
     frames_total = world * args.steps * B
     value = frames_total / dt
+    # encoder FLOPs per frame with and without the frame-invariant share (first layer on the 3D stream: 16 C^2 + 2 C D per 3D
+    # point, its own K / V half 4 C^2 + 2 C D, and the 3D source's K / V of layer 1: 4 C^2 + 2 C D); utilisation stays on the UNCACHED figure
+    _C, _D = 256.0, 32.0
+    enc_flops_uncached = (n_points + M) * (6 * (16 * _C * _C + 2 * _C * _D) + 6 * (4 * _C * _C + 2 * _C * _D))
+    enc_flops_cached_share = n_points * ((16 * _C * _C + 2 * _C * _D) + 2 * (4 * _C * _C + 2 * _C * _D))
     avg_ms = kern_ms / max(launches, 1)
     flops = attn_apply_flops(B * (n_points + M), fused_kv=args.precision != "f32")
     achieved = flops / (avg_ms * 1e-3) / 1e12 if launches else 0.0
@@ -597,6 +665,12 @@ def main():
         "lazy_conf_frames_rerun_eagerly": lazy_reruns,
         "value_lazy_conf": (frames_total / dt_lazy) if dt_lazy else None,          # conf_matrix not materialised (hip_conf_matrix = "lazy"), same PnP policy as `value`
         "value_matcher_only_object_cached": (frames_total / dt_cached) if dt_cached else None,
+        "value_no_hot_steps": (frames_total / dt_nohot) if dt_nohot else None,          # same build, same K steps, OPHIP_BENCH_HOT_STEPS=0 for this region
+        # ONE frame in flight, frame t + 1 enqueued after frame t's pose is joined (the reference's loop, inference.py:148-190); latency = enqueue -> pose
+        "value_dependent_sequence": (len(lat_dep) / dt_dep) if dt_dep else None,
+        "latency_ms": ({"mean": 1e3 * sum(lat_dep) / len(lat_dep), "median": 1e3 * sorted(lat_dep)[len(lat_dep) // 2], "max": 1e3 * max(lat_dep),
+                        "frames": len(lat_dep)} if lat_dep else None),
+        "value_dependent_sequence_object_cached": (max(args.steps, 20) / dt_dep_cached) if dt_dep_cached else None,
         ("value_pnp_" + other): (frames_total / dt_other) if dt_other else None,
         "higher_is_better": True,
         "scaling": "weak",
@@ -619,6 +693,9 @@ def main():
             "streams": len(streams), "frames_in_flight": depth,
             "parallelism": f"frames sharded over {world} rank(s), one RCCL broadcast of weights + 3D block ({bcast_bytes} B)",
         },
+        "encoder_flops_per_frame": {"algorithmic_uncached": enc_flops_uncached, "frame_invariant_share_cached_by_hip_cache_object": enc_flops_cached_share,
+                                    "with_object_cache": enc_flops_uncached - enc_flops_cached_share,
+                                    "note": "roofline.* is computed on the uncached figure (SURVEY 8d); the headline `value` runs WITHOUT the cache"},
         "ranks": ranks,
         "broadcast": {"bytes": bcast_bytes, "ms": bcast_ms, "backend": (args.dist_backend if dist_on else None),
                       "gb_per_s": (bcast_bytes / bcast_ms / 1e6) if bcast_ms else None},
@@ -673,6 +750,12 @@ def main():
             "frac_of_measured_copy_rate": gbs / 6290.0,          # MI355X_MICROARCH.md: 6.29 TB/s float4 copy
             "traffic": None, "bytes_per_launch": kbytes,
             "stage_algorithmic_bytes": float(B) * ((n_points + M) * 256 * 2 + 4.0 * n_points * M),
+            # the honest figure for the stage: SURVEY 8d's algorithmic bytes (inputs once + ONE f32 write of the matrix) over the time of
+            # BOTH N x M kernels (similarity tiles + confidence pass), against 8 TB/s; `frac` above divides the confidence kernel's OWN
+            # bytes (S read + conf write = 2 x the algorithmic write) by its own time
+            "sim_tiles_avg_launch_ms": (sim_ms / sim_launches) if sim_launches else None,
+            "stage_frac": ((float(B) * ((n_points + M) * 256 * 2 + 4.0 * n_points * M)) / ((avg_ms + sim_ms / sim_launches) * 1e-3) / 1e9 / 8000.0)
+                          if (launches and sim_launches) else None,
             "launches": launches, "launches_sampled_every": time_every, "avg_launch_ms": avg_ms, "library_build_stamp": hip.build_stamp(),
         }
 

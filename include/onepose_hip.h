@@ -25,8 +25,11 @@ extern "C" {
  * compares the two before its first call.  History: 1 = rounds 1-2; 2 = round 3 (lazy_conf inside ophip_frame_desc, the extended
  * ophip_frame_layout_t, ophip_frame_wait takes the TICKET ophip_frame_enqueue returned (generation * 16 + slot, never below 16),
  * ophip_encoder_layer_x3 / ophip_fine_refine_x3 removed); 3 = round 4 (ophip_encoder_kv_first_x3w8 added, kv_from_prev = 2 accepted by the
- * x3w8 layer entry points: additive, but a binding that names the new symbol needs a library that has it). */
-#define OPHIP_ABI_VERSION 3
+ * x3w8 layer entry points: additive, but a binding that names the new symbol needs a library that has it); 4 = round 5 (the object cache:
+ * ophip_object_cache, ophip_encoder_object_x3w8, ophip_encoder_x3w8_kv_block_bytes, ophip_frame_enqueue_object; ophip_frame_layout's
+ * external_x3d takes 2 = "first layer cached as well"; ophip_frame_enqueue{,_padded} with an x3d_external issue the first layer's K / V
+ * half on s_main: additive otherwise). */
+#define OPHIP_ABI_VERSION 4
 int ophip_abi_version(void);
 /* host string: 16 hex digits of the sha256 over the sources this library was built from (the profiles/ pmc summaries record it;
  * bench.py quotes committed counter values only when they were taken on the running build) */
@@ -40,8 +43,10 @@ long long ophip_roctx_ranges(void);
 /* host query: CU count, LDS bytes per block, gcn arch name of the current device */
 int ophip_device_info(int* cu_count, int* lds_per_block, char* arch, int arch_len);
 
-/* Measurement hook (bench.py): select one kernel by name ("attn_apply", "kv_reduce", "kv_sum", "sim_stats",
- * "stat_combine", "conf", "select", "fine_refine", "pe_add_transpose", "kpt_stats", "kpt_encode"; "" = off).
+/* Measurement hook (bench.py): select one kernel by its launch name ("attn_apply", "kv_reduce", "kv_sum", "frag_planes", "sim_stats" (the
+ * similarity tiles: sim_frag / sim_stats kernels), "stat_combine", "conf", "select" (select_decide), "select_place", "fine_refine",
+ * "pe_add_transpose", "transpose_cl", "kpt_stats", "kpt_encode", "stem", "conv", "crop_resize", "fine2_gather", "fine2_attention",
+ * "fine2_match", "rows_linear", "rows_layernorm"; "" = off).
  * While selected, every launch of that kernel is bracketed by a hipEvent pair on its launch stream (at most 8192
  * launches between reads).  ophip_timing_read() synchronises those events, returns the launch count and the summed
  * device time, and clears the log. */
@@ -224,8 +229,9 @@ int ophip_fine_refine_bf16_scaled(const float* feat_f, long long fs_b, long long
  * result block, issued from C (csrc/frame.hip) instead of ~27 separate calls from the host language.
  * ophip_frame_desc: sizes, scalars and packed-weight pointers of the model (fixed per model and input shape).
  * ophip_frame_layout(): byte offsets of every intermediate and output inside ONE device block of `total` bytes
- *   (transpose_fine: the fine map arrives NCHW and needs the channels-last copy; external_x3d: the keypoint encoding is
- *   supplied by the caller -- a cached object block -- and stays read-only).
+ *   (transpose_fine: the fine map arrives NCHW and needs the channels-last copy; external_x3d: 1 = the keypoint encoding is
+ *   supplied by the caller -- a cached object block -- and stays read-only; 2 = so are the first encoder layer's 3D rows, see
+ *   ophip_object_cache below).
  * ophip_frame_enqueue(): enqueues the frame and returns; nothing is allocated or synchronised.  s_prep may be NULL (input
  *   kernels then run on s_main, behind everything queued there); host_dst receives the first host_bytes of the result block
  *   (>= 16: the match count; result_bytes: count | b_ids | mkpts3d | mkpts2d) by an asynchronous copy on s_copy.
@@ -240,8 +246,13 @@ int ophip_fine_refine_bf16_scaled(const float* feat_f, long long fs_b, long long
  *   frame with no successor is completed by ophip_frame_wait() on its ticket.  A throughput pipeline therefore keeps three frames in
  *   flight: enqueue t + 2, then wait for t.
  * ophip_frame_order_after_fine(stream): completes a kept-back fine stage of `stream` and makes `stream` wait for the fine stage of
- *   the last frame enqueued on it through this entry point (for callers that mix it with stage-by-stage calls and want attn_apply
- *   never to share the chip with it). */
+ *   the last frame enqueued on it through this entry point (for callers that mix it with stage-by-stage calls: what they queue next on
+ *   `stream` then starts behind that fine stage.  Inside the frame pipeline itself the next encoder does NOT wait for it any more --
+ *   since the end of round 4 its first layer takes the CUs the fine stage's last workgroups free; OPHIP_FRAME_FINE_WAIT=1 restores the wait).
+ * x3d_external (a cached keypoint encoding, read-only): the entry points that take it as a bare pointer know nothing about the stream
+ *   that wrote it, so they read it on s_main only (the first layer's K / V half, which otherwise runs ahead on s_prep, stays on s_main):
+ *   it must be complete with respect to s_main -- written on s_main, or behind an event s_main already waits on.  A caller that wants
+ *   the K / V half on s_prep passes the cache through ophip_frame_enqueue_object with its `ready` event. */
 typedef struct ophip_frame_desc {
     int B, N, M, hc, wc, hf, wf, cf;             /* cf: channels of the fine map (128) */
     int lazy_conf;                                /* 1: conf_matrix is not materialised (layout.conf = 0; result block int32 @4 = "re-run eagerly" flag) */
@@ -277,6 +288,38 @@ int ophip_frame_enqueue_padded(const ophip_frame_desc* desc, const ophip_frame_l
                                void* host_dst, size_t host_bytes, void* s_main, void* s_prep, void* s_fine, void* s_copy, int* slot);
 int ophip_frame_wait(int ticket);
 int ophip_frame_order_after_fine(void* compute_stream);
+
+/* Object cache ("kpt_encode and the first 3D self-layer are frame-invariant ... computed once per sequence and
+ * cached"; the reference keeps the object block resident across a sequence's frames, OnePosePlus_inference_dataset.py:157-169, and its
+ * first layer applies the layer to the 3D stream with itself as source, transformer.py:148-153, while the second layer's 2D update
+ * reads only that result as K / V, :154-159).  Per object and weight set, once:
+ *   x3d  [Bo][N][256]  the keypoint encoding, rows a2 + a3 (ophip_kpt_encode)
+ *   y3d0 [Bo][N][256]  the first encoder layer's 3D rows                                       } ophip_encoder_object_x3w8: the launches a frame
+ *   kv1  [Bo][ophip_encoder_x3w8_kv_block_bytes()]  phi(K)^T V | Ksum of those rows as layer 1's source } would run, on the 3D stream's workgroups only
+ * Bo = 1 with batch strides 0 when the whole batch shares one object (BASELINE config 3), else Bo = B.  A frame enqueued with the cache
+ * (ophip_frame_enqueue_object) runs layer 0 on the 2D stream alone and layer 1 with the cached rows / block; it is BIT-IDENTICAL to a
+ * frame without the cache (a workgroup's arithmetic does not depend on the others of its launch; the K^T V sum adds a stream's slabs in
+ * the same fixed order).  Needs n_coarse >= 2 and a first layer of kind "self" for y3d0 / kv1 (else pass them NULL: depth 1).
+ * workspace of ophip_encoder_object_x3w8: ophip_encoder_x3w8_workspace_bytes(Bo, N, 1) bytes of scratch.
+ * ready: a hipEvent_t recorded behind the kernels that wrote the buffers, or NULL when they are complete; ophip_frame_enqueue_object makes
+ * s_main AND s_prep wait for it before their first read (the first layer's K / V half runs on s_prep). */
+typedef struct ophip_object_cache {
+    const float* x3d;  long long x3d_bs;          /* batch stride in floats (0: shared); may be NULL when y3d0 / kv1 are given */
+    const float* y3d0; long long y3d0_bs;         /* or NULL: only the keypoint encoding is cached */
+    const void* kv1;   long long kv1_bs;          /* batch stride in BYTES (0: shared); 16-byte aligned */
+    void* ready;
+} ophip_object_cache;
+size_t ophip_encoder_x3w8_kv_block_bytes(void);
+int ophip_encoder_object_x3w8(const float* x3d, int Bo, int N, const void* wpack0, const void* wpack1, void* workspace,
+                              float* y3d0, void* kv1, void* stream);
+/* ophip_frame_enqueue_padded with the object's cache in place of x3d_external (the layout must have been made with external_x3d = 2
+ * when y3d0 / kv1 are given, 1 otherwise); query_mask / query_scale may be NULL. */
+int ophip_frame_enqueue_object(const ophip_frame_desc* desc, const ophip_frame_layout_t* layout, void* block,
+                               const float* feat_c, const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x,
+                               const float* keypoints3d, long long kpts_bstride, const float* desc3d_c, long long desc_c_bstride,
+                               const float* desc3d_f, long long desc_f_bstride, long long desc_f_cstride, const ophip_object_cache* object,
+                               const unsigned char* query_mask, const float* query_scale,
+                               void* host_dst, size_t host_bytes, void* s_main, void* s_prep, void* s_fine, void* s_copy, int* slot);
 
 /* Row f-1 -- ResNetFPN_8_2 image backbone (backbone/resnet.py:20-44 BasicBlock, :85-164; called at
  * OnePosePlusModel.py:121-131) as implicit-GEMM convolutions on the bf16 matrix pipe.

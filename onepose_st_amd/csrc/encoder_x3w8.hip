@@ -12,6 +12,7 @@
 //   * per-wave streams are 256 + 64 KiB (packing.pack_coarse_layer_x3w8): Q | merge | W0c0 | W2c0 | W0c1 | W2c1, then the next
 //     layer's K|V of head fw.
 #include "tile_x3.h"
+#include "x3w8_internal.h"
 #include <stdlib.h>
 
 namespace {
@@ -35,7 +36,7 @@ struct EncW8Args {
     int L[2];
     int tiles[2];
     const char* kv[2];
-    long long kvbs;
+    long long kvbs[2];         // per stream: batch stride of its K^T V block in bytes (0: one cached block shared by the whole batch)
     float srclen[2];
     const bf16x8* wmain;       // [8 waves][MAIN_FRAGS][64]
     const bf16x8* wkv;         // [8 waves][KV_FRAGS][64] consumed by the tail; NULL: no tail
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
     bf16x8 kvh[2], kvl[2];
     f32x4 ksm[2], g1[2], b1[2], g2[2], b2[2];
     if (!ONLY_KV) {
-        const char* kvb = a.kv[s] + (size_t)b * a.kvbs;
+        const char* kvb = a.kv[s] + (size_t)b * a.kvbs[s];
 #pragma unroll
         for (int vt = 0; vt < 2; ++vt) {
             kvh[vt] = *reinterpret_cast<const bf16x8*>(kvb + ((size_t)((fw * 2 + vt) * 2 + 0) * 64 + lane) * 16);
@@ -385,6 +386,7 @@ struct KvSumArgs {
     const float* partial;
     char* kv;
     int tiles[2];
+    long long kv_bs, kv_ss;    // bytes between the blocks of consecutive batch elements / of the two streams
 };
 
 constexpr int KVS_G = 64;          // tile groups per workgroup: a thread sums tiles g, g + 64, g + 128, ... (<= 3 at c2: all its loads in flight at once)
@@ -399,6 +401,7 @@ __global__ __launch_bounds__(1024) void kv_sum_w8_kernel(KvSumArgs a) {
     const int s = blockIdx.y & 1, b = blockIdx.y >> 1;
     const int ttot = a.tiles[0] + a.tiles[1];
     const int t0 = s ? a.tiles[0] : 0, nt = a.tiles[s];
+    if (nt == 0) return;                             // a stream that is not part of this launch (object cache: its block comes from the cache)
     const int e = (blockIdx.x * KVS_L + o) * 4;
     const float* p = a.partial + ((size_t)b * ttot + t0) * KV_PART_FLOATS + e;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(1024) void kv_sum_w8_kernel(KvSumArgs a) {
         f32x4 tot = red[0][o];
 #pragma unroll
         for (int k = 1; k < 8; ++k) tot += red[k][o];
-        char* blk = a.kv + ((size_t)b * 2 + s) * KV_BLOCK_BYTES;
+        char* blk = a.kv + (size_t)b * a.kv_bs + (size_t)s * a.kv_ss;
         if (e < NH * 1024) {
             const int ln = (e >> 2) & 63, vt = (e >> 8) & 1, dt = (e >> 9) & 1, head = e >> 10;
             bf16x4 vh, vl;
@@ -452,20 +455,47 @@ extern "C" size_t ophip_encoder_x3w8_workspace_bytes(int B, int L3d, int L2d) {
 extern "C" size_t ophip_encoder_x3w8_wpack_bytes(void) { return (size_t)NW * (MAIN_FRAGS + KV_FRAGS) * 1024 + 4 * C * 4; }
 
 namespace {
+// Object-cache options of a layer call (ophip_frame_enqueue_object / ophip_encoder_object_x3w8; all zero: the plain layer).
+//   streams:      bit 0 = the 3D stream's tiles run, bit 1 = the 2D stream's (0 = both).  A stream that is left out has no workgroups, no
+//                 K / V slabs and no K^T V sum in this call; the slabs of the streams that DO run are laid out compactly (tile index
+//                 inside the launch), so the layer that sums them must be told the same (`partial_streams`).
+//   partial_streams: which streams' slabs `partial` of THIS call holds (written by the previous layer's tail or by this call's kv_reduce).
+//   x3d_bs:       batch stride of x3d in floats (-1: dense; 0: one object block shared by the batch).
+//   kv3d / kv3d_bs: the summed K^T V / Ksum block of the 3D SOURCE for this layer, from the cache (bytes between batch elements; 0 = shared):
+//                 the stream that attends to the 3D source reads it instead of the workspace's block.
+//   kv_out / kv_out_bs: the 3D stream's summed block goes HERE instead of into the workspace (the cache build).
+struct X3Opts {
+    int streams = 0;
+    int partial_streams = 0;
+    long long x3d_bs = -1;
+    const void* kv3d = nullptr;
+    long long kv3d_bs = 0;
+    void* kv_out = nullptr;
+    long long kv_out_bs = 0;
+};
+
 // kv_mode: 0 = this call projects its own K, V (kv_reduce), sums the slabs (kv_sum) and applies; 1 = the slabs are there (the previous
 // layer's fused tail wrote them): kv_sum + apply; 2 = the summed K^T V / Ksum block is there (ophip_encoder_kv_first_x3w8 ran): apply only.
 // only_kv: stop after kv_reduce + kv_sum (the body of ophip_encoder_kv_first_x3w8; y3d / y2d / wpack_next unused).
+// sum_only: kv_sum of the slabs that are there and nothing else (the cache build's last step).
 int layer_x3w8(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
                const void* wpack, const void* wpack_next, int is_cross, int kv_mode, int slot,
-               void* workspace, void* stream_, void* frag3d, void* frag2d, const unsigned char* mask2d = nullptr, bool only_kv = false) {
-    if (!x3d || !x2d || !wpack || !workspace || (!only_kv && (!y3d || !y2d))) return ophip_bad_arg(__func__, "null pointer");
+               void* workspace, void* stream_, void* frag3d, void* frag2d, const unsigned char* mask2d = nullptr, bool only_kv = false,
+               const X3Opts& opt = X3Opts(), bool sum_only = false) {
+    const int run = opt.streams ? opt.streams : 3;              // streams whose tiles run in this call
+    const int have = opt.partial_streams ? opt.partial_streams : 3;      // streams whose slabs `partial` holds
+    const bool r3 = run & 1, r2 = run & 2;
+    if ((!sum_only && ((r3 && !x3d) || (r2 && !x2d))) || !wpack || !workspace || (!only_kv && !sum_only && ((r3 && !y3d) || (r2 && !y2d))))
+        return ophip_bad_arg(__func__, "null pointer");
     if (B < 1 || L3d < 1 || L2d < 1) return ophip_bad_arg(__func__, "B, L3d, L2d must be >= 1");
     if (slot != 0 && slot != 1) return ophip_bad_arg(__func__, "slot must be 0 or 1");
     if (kv_mode < 0 || kv_mode > 2) return ophip_bad_arg(__func__, "kv_from_prev must be 0, 1 or 2");
-    if (!only_kv && (x3d == y3d || x2d == y2d)) return ophip_bad_arg(__func__, "in-place layer is not supported (cross layers read the pre-update streams)");
+    if (!only_kv && !sum_only && ((r3 && x3d == y3d) || (r2 && x2d == y2d))) return ophip_bad_arg(__func__, "in-place layer is not supported (cross layers read the pre-update streams)");
     if (reinterpret_cast<uintptr_t>(wpack) & 15) return ophip_bad_arg(__func__, "wpack must be 16-byte aligned");
+    if (is_cross && run != 3 && !only_kv && !sum_only) return ophip_bad_arg(__func__, "a cross layer needs both streams");
     hipStream_t stream = (hipStream_t)stream_;
     const int t3 = (L3d + TOK - 1) / TOK, t2 = (L2d + TOK - 1) / TOK;
+    // the workspace is sized for both streams (ophip_encoder_x3w8_workspace_bytes); a launch that leaves one out uses the head of each slab area
     const size_t part_floats = (size_t)B * (t3 + t2) * KV_PART_FLOATS;
     float* partial = reinterpret_cast<float*>(workspace) + (size_t)slot * part_floats;
     float* partial_next = reinterpret_cast<float*>(workspace) + (size_t)(slot ^ 1) * part_floats;
@@ -482,11 +512,14 @@ int layer_x3w8(const float* x3d, const float* x2d, float* y3d, float* y2d, int B
         if (int rc = ophip_lds_attr(reinterpret_cast<const void*>(enc_x3w8_kernel<true, true>), LDS_BYTES, "hipFuncSetAttribute(enc_x3w8 kv masked)")) return rc;
     }
 
+    // tiles per stream of THIS call's launches (a stream that does not run has none: tile -> stream, token offsets and slab indices follow)
+    const int rt3 = r3 ? t3 : 0, rt2 = r2 ? t2 : 0;
     EncW8Args aa;
     aa.x[0] = x3d; aa.x[1] = x2d; aa.y[0] = y3d; aa.y[1] = y2d;
-    aa.xbs[0] = aa.ybs[0] = (long long)L3d * C; aa.xbs[1] = aa.ybs[1] = (long long)L2d * C;
-    aa.L[0] = L3d; aa.L[1] = L2d; aa.tiles[0] = t3; aa.tiles[1] = t2;
-    aa.kvbs = 2LL * KV_BLOCK_BYTES;
+    aa.xbs[0] = opt.x3d_bs >= 0 ? opt.x3d_bs : (long long)L3d * C;
+    aa.ybs[0] = (long long)L3d * C; aa.xbs[1] = aa.ybs[1] = (long long)L2d * C;
+    aa.L[0] = L3d; aa.L[1] = L2d; aa.tiles[0] = rt3; aa.tiles[1] = rt2;
+    aa.kvbs[0] = aa.kvbs[1] = 2LL * KV_BLOCK_BYTES;
     aa.srclen[0] = (float)(is_cross ? L2d : L3d);
     aa.srclen[1] = (float)(is_cross ? L3d : L2d);
     aa.wmain = wmain; aa.ln = ln;
@@ -494,32 +527,44 @@ int layer_x3w8(const float* x3d, const float* x2d, float* y3d, float* y2d, int B
     aa.frag[0] = static_cast<char*>(frag3d); aa.frag[1] = static_cast<char*>(frag2d);
     aa.frag_rows[0] = (L3d + 127) / 128 * 128; aa.frag_rows[1] = (L2d + 127) / 128 * 128;
     aa.mask2d = mask2d;
-    if (kv_mode == 0) {
+    if (kv_mode == 0 && !sum_only) {
         EncW8Args ka = aa;
         ka.kv[0] = ka.kv[1] = nullptr;
         ka.frag[0] = ka.frag[1] = nullptr;
         ka.wkv = wkv_own;
         ka.partial = partial;
         ka.stamps = nullptr;
-        if (mask2d) { OPHIP_LAUNCH("kv_reduce", stream, (enc_x3w8_kernel<true, true>), dim3(t3 + t2, B), dim3(512), LDS_BYTES, stream, ka); }
-        else { OPHIP_LAUNCH("kv_reduce", stream, enc_x3w8_kernel<true>, dim3(t3 + t2, B), dim3(512), LDS_BYTES, stream, ka); }
+        if (mask2d) { OPHIP_LAUNCH("kv_reduce", stream, (enc_x3w8_kernel<true, true>), dim3(rt3 + rt2, B), dim3(512), LDS_BYTES, stream, ka); }
+        else { OPHIP_LAUNCH("kv_reduce", stream, enc_x3w8_kernel<true>, dim3(rt3 + rt2, B), dim3(512), LDS_BYTES, stream, ka); }
         OPHIP_CHECK_LAUNCH();
     }
     if (kv_mode != 2) {
+        // the slabs `partial` holds: written by this call's kv_reduce (the streams that run) or by the previous layer's tail (`have`)
+        const int hs = kv_mode == 0 ? run : have;
         KvSumArgs sa;
-        sa.partial = partial; sa.kv = kv; sa.tiles[0] = t3; sa.tiles[1] = t2;
+        sa.partial = partial; sa.kv = kv; sa.tiles[0] = (hs & 1) ? t3 : 0; sa.tiles[1] = (hs & 2) ? t2 : 0;
+        sa.kv_bs = 2LL * KV_BLOCK_BYTES; sa.kv_ss = KV_BLOCK_BYTES;
+        if (opt.kv_out) {                                 // the cache build: the 3D stream's block leaves the workspace
+            if (hs != 1) return ophip_bad_arg(__func__, "kv_out needs a 3D-only call");
+            sa.kv = static_cast<char*>(opt.kv_out); sa.kv_bs = opt.kv_out_bs; sa.kv_ss = 0;
+        }
         static_assert(KV_PART_FLOATS % (4 * KVS_L) == 0, "a slab is a whole number of 64-float chunks");
         OPHIP_LAUNCH("kv_sum", stream, kv_sum_w8_kernel, dim3(KV_PART_FLOATS / (4 * KVS_L), 2 * B), dim3(KVS_G * KVS_L), 0, stream, sa);
         OPHIP_CHECK_LAUNCH();
     }
-    if (only_kv) return 0;
+    if (only_kv || sum_only) return 0;
     aa.kv[0] = kv + (is_cross ? KV_BLOCK_BYTES : 0);
     aa.kv[1] = kv + (is_cross ? 0 : KV_BLOCK_BYTES);
+    if (opt.kv3d) {                                       // the 3D source's block from the cache: read by the stream that attends to it
+        const int rd = is_cross ? 1 : 0;
+        aa.kv[rd] = static_cast<const char*>(opt.kv3d);
+        aa.kvbs[rd] = opt.kv3d_bs;
+    }
     aa.wkv = nullptr;
     aa.partial = partial_next;
     if (wpack_next) aa.wkv = reinterpret_cast<const bf16x8*>(wpack_next) + (size_t)NW * MAIN_FRAGS * 64;
-    if (mask2d) { OPHIP_LAUNCH("attn_apply", stream, (enc_x3w8_kernel<false, true>), dim3(t3 + t2, B), dim3(512), LDS_BYTES, stream, aa); }
-    else { OPHIP_LAUNCH("attn_apply", stream, enc_x3w8_kernel<false>, dim3(t3 + t2, B), dim3(512), LDS_BYTES, stream, aa); }
+    if (mask2d) { OPHIP_LAUNCH("attn_apply", stream, (enc_x3w8_kernel<false, true>), dim3(rt3 + rt2, B), dim3(512), LDS_BYTES, stream, aa); }
+    else { OPHIP_LAUNCH("attn_apply", stream, enc_x3w8_kernel<false>, dim3(rt3 + rt2, B), dim3(512), LDS_BYTES, stream, aa); }
     OPHIP_CHECK_LAUNCH();
     return 0;
 }
@@ -558,4 +603,56 @@ extern "C" int ophip_encoder_layer_x3w8_masked(const float* x3d, const float* x2
 extern "C" int ophip_encoder_kv_first_x3w8(const float* x3d, const float* x2d, int B, int L3d, int L2d, const void* wpack, int slot,
                                            void* workspace, const unsigned char* mask2d, void* stream) {
     return layer_x3w8(x3d, x2d, nullptr, nullptr, B, L3d, L2d, wpack, nullptr, 0, 0, slot, workspace, stream, nullptr, nullptr, mask2d, true);
+}
+
+// ---- object cache ("kpt_encode and the first 3D self-layer are frame-invariant ... computed once per
+//      sequence and cached"; the reference keeps the object block resident, OnePosePlus_inference_dataset.py:157-169) -------------------
+// With a first layer of kind "self" the 3D stream's first-layer output depends on the object block and the weights only
+// (transformer.py:148-153), and so does the K^T V / Ksum block of those rows as the SOURCE of the second layer (:154-159).
+// ophip_encoder_object_x3w8 computes both with the very launches a frame would run -- kv_reduce / kv_sum / attn_apply restricted to the 3D
+// stream's workgroups; a workgroup's arithmetic does not depend on which other workgroups share its launch, and kv_sum adds a stream's
+// slabs in the same fixed order -- so a frame that uses the cache is bit-identical to one that does not.
+//   x3d [Bo][N][256]: the keypoint encoding (ophip_kpt_encode); y3d0 [Bo][N][256]: layer 0's rows; kv1 [Bo][ophip_encoder_x3w8_kv_block_bytes()]:
+//   the summed block of layer 1's 3D source; workspace: ophip_encoder_x3w8_workspace_bytes(Bo, N, 1) bytes (scratch).
+extern "C" size_t ophip_encoder_x3w8_kv_block_bytes(void) { return KV_BLOCK_BYTES; }
+
+extern "C" int ophip_encoder_object_x3w8(const float* x3d, int Bo, int N, const void* wpack0, const void* wpack1, void* workspace,
+                                         float* y3d0, void* kv1, void* stream) {
+    if (!x3d || !wpack0 || !wpack1 || !workspace || !y3d0 || !kv1) return ophip_bad_arg(__func__, "null pointer");
+    if (reinterpret_cast<uintptr_t>(kv1) & 15) return ophip_bad_arg(__func__, "kv1 must be 16-byte aligned");
+    X3Opts o;
+    o.streams = 1;
+    // layer 0 on the 3D stream alone: its own K / V (kv_reduce + kv_sum), then the layer; the tail leaves layer 1's slabs of these rows
+    if (int rc = layer_x3w8(x3d, nullptr, y3d0, nullptr, Bo, N, 1, wpack0, wpack1, 0, 0, 0, workspace, stream, nullptr, nullptr, nullptr, false, o)) return rc;
+    // their fixed-order sum = the 3D source's block of layer 1 (slot 1: where layer 0's tail wrote)
+    X3Opts s;
+    s.partial_streams = 1;
+    s.kv_out = kv1; s.kv_out_bs = KV_BLOCK_BYTES;
+    return layer_x3w8(x3d, nullptr, nullptr, nullptr, Bo, N, 1, wpack1, nullptr, 0, 1, 1, workspace, stream, nullptr, nullptr, nullptr, false, s, true);
+}
+
+// The layer calls of a frame that uses the cache (csrc/frame.hip).  first: layer 0 on the 2D stream alone (kv_mode as in the plain call: 0
+// = with its own K / V half, 2 = ophip_encoder_kv_first_object_x3w8 ran); second: layer 1 on both streams, its 3D rows and the 3D source's
+// block from the cache.
+int ophip_x3w8_object_first(const float* x2d, float* y2d, int B, int L3d, int L2d, const void* wpack, const void* wpack_next, int kv_mode,
+                            void* workspace, const unsigned char* mask2d, bool only_kv, void* stream) {
+    X3Opts o;
+    o.streams = 2;
+    return layer_x3w8(nullptr, x2d, nullptr, y2d, B, L3d, L2d, wpack, wpack_next, 0, kv_mode, 0, workspace, stream, nullptr, nullptr, mask2d, only_kv, o);
+}
+int ophip_x3w8_object_second(const float* y3d0, long long y3d0_bs, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
+                             const void* wpack, const void* wpack_next, int is_cross, const void* kv1, long long kv1_bs,
+                             void* workspace, void* frag3d, void* frag2d, const unsigned char* mask2d, void* stream) {
+    X3Opts o;
+    o.partial_streams = 2;
+    o.x3d_bs = y3d0_bs;
+    o.kv3d = kv1; o.kv3d_bs = kv1_bs;
+    return layer_x3w8(y3d0, x2d, y3d, y2d, B, L3d, L2d, wpack, wpack_next, is_cross, 1, 1, workspace, stream, frag3d, frag2d, mask2d, false, o);
+}
+int ophip_x3w8_layer_bs(const float* x3d, long long x3d_bs, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
+                        const void* wpack, const void* wpack_next, int is_cross, int kv_mode, int slot,
+                        void* workspace, void* frag3d, void* frag2d, const unsigned char* mask2d, bool only_kv, void* stream) {
+    X3Opts o;
+    o.x3d_bs = x3d_bs;
+    return layer_x3w8(x3d, x2d, y3d, y2d, B, L3d, L2d, wpack, wpack_next, is_cross, kv_mode, slot, workspace, stream, frag3d, frag2d, mask2d, only_kv, o);
 }

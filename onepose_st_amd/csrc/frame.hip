@@ -6,6 +6,7 @@
 // Host code only: every kernel is launched through the stage entry points of this library.
 #include "tile.h"
 #include "onepose_hip.h"
+#include "x3w8_internal.h"
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -104,9 +105,9 @@ int launch_fine_job(int dev, Slot& s, hipEvent_t after = nullptr) {
 }
 
 // OPHIP_FRAME_DEFER_FINE=0: the fine stage follows its own frame's selection at once (the round-2 order)
-// OPHIP_FRAME_KV_FIRST: where the first encoder layer's K / V half is issued (see ophip_frame_enqueue_padded): "prep" (1), "main" (2), "off" (0).
-// Default: "prep" when the kept-back fine stage runs on the compute stream (there the compute stream's next free point is BEHIND that fine
-// stage; the input stream runs beside it), "main" otherwise.
+// OPHIP_FRAME_KV_FIRST: where the first encoder layer's K / V half is issued (see frame_enqueue_impl): "prep" (1), "main" (2), "off" (0).
+// Default: "prep" -- behind the input kernels on their stream, beside whatever runs when they run.  (A padded frame's half, and the half
+// of a frame whose cached encoding came in as a bare pointer, stay on the compute stream whatever this says.)
 bool fine_on_main_enabled();
 int kv_first_mode() {
     static const int mode = [] {
@@ -150,6 +151,9 @@ extern "C" int ophip_frame_layout(const ophip_frame_desc* d, int transpose_fine,
     auto take = [&](size_t bytes) { const size_t at = o; o = up256(o + bytes); return at; };
     L->x2d = take(B * M * C * 4);
     L->ffcl = transpose_fine ? take(B * (size_t)d->hf * d->wf * d->cf * 4) : 0;
+    if (external_x3d < 0 || external_x3d > 2) return ophip_bad_arg(__func__, "external_x3d must be 0, 1 or 2");
+    if (external_x3d == 2 && (d->n_coarse < 2 || (d->coarse_cross_bits & 1u)))
+        return ophip_bad_arg(__func__, "a cached first layer needs n_coarse >= 2 and a first layer of kind \"self\"");
     L->x3d = external_x3d ? 0 : take(B * N * C * 4);
     L->y3d = take(B * N * C * 4);
     L->y2d = take(B * M * C * 4);
@@ -169,23 +173,38 @@ extern "C" int ophip_frame_layout(const ophip_frame_desc* d, int transpose_fine,
     L->total = o;
     L->result_bytes = 16 + 28 * cap;
     // where the encoder's final rows end up (the ping-pong of ophip_frame_enqueue): what a caller needs to materialise a lazy conf_matrix
+    // (plain / cached encoding: layer 0 writes y3d, layer 1 z3d (resp. back into x3d), ...; cached first layer: layer 1 writes y3d, layer 2 z3d, ...)
     const size_t z3 = external_x3d ? L->z3d : L->x3d;
-    L->feat3d_out = (d->n_coarse % 2 == 0) ? z3 : L->y3d;
+    if (external_x3d == 2) L->feat3d_out = (d->n_coarse % 2 == 0) ? L->y3d : z3;
+    else L->feat3d_out = (d->n_coarse % 2 == 0) ? z3 : L->y3d;
     L->feat2d_out = (d->n_coarse % 2 == 0) ? L->x2d : L->y2d;
     return 0;
 }
 
-extern "C" int ophip_frame_enqueue_padded(const ophip_frame_desc* d, const ophip_frame_layout_t* L, void* blob_,
-                                          const float* feat_c, const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x,
-                                          const float* kpts, long long kpts_bs, const float* desc_c, long long desc_c_bs,
-                                          const float* desc_f, long long desc_f_bs, long long desc_f_cs, const float* x3d_external,
-                                          const unsigned char* qmask, const float* qscale,
-                                          void* host_dst, size_t host_bytes, void* s_main_, void* s_prep_, void* s_fine_, void* s_copy_,
-                                          int* slot_out) {
+namespace {
+// obj: the object's cache or NULL.  ext_main_only: the cache came in as a bare x3d_external pointer (ophip_frame_enqueue{,_padded}): nothing is
+// known about the stream that wrote it, so it is read on s_main only (see the header).
+int frame_enqueue_impl(const ophip_frame_desc* d, const ophip_frame_layout_t* L, void* blob_,
+                       const float* feat_c, const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x,
+                       const float* kpts, long long kpts_bs, const float* desc_c, long long desc_c_bs,
+                       const float* desc_f, long long desc_f_bs, long long desc_f_cs, const ophip_object_cache* obj, bool ext_main_only,
+                       const unsigned char* qmask, const float* qscale,
+                       void* host_dst, size_t host_bytes, void* s_main_, void* s_prep_, void* s_fine_, void* s_copy_,
+                       int* slot_out) {
     if (!d || !L || !blob_ || !feat_c || !feat_f || !kpts || !desc_c || !desc_f || !host_dst || !s_fine_ || !s_copy_ || !slot_out)
         return ophip_bad_arg(__func__, "null pointer");
     if (host_bytes < 16 || host_bytes > L->result_bytes) return ophip_bad_arg(__func__, "host_bytes");
-    if ((L->x3d == 0) != (x3d_external != nullptr)) return ophip_bad_arg(__func__, "x3d_external does not match the layout");
+    const bool deep = obj && obj->y3d0;                      // the first layer's 3D rows and layer 1's 3D-source block come from the cache
+    const float* x3d_external = (obj && !deep) ? obj->x3d : nullptr;
+    const long long x3d_ext_bs = obj ? obj->x3d_bs : -1;
+    if (obj && !deep && !obj->x3d) return ophip_bad_arg(__func__, "object cache without buffers");
+    if (deep && (!obj->kv1 || (reinterpret_cast<uintptr_t>(obj->kv1) & 15))) return ophip_bad_arg(__func__, "object cache: kv1 missing or not 16-byte aligned");
+    if (deep && (d->n_coarse < 2 || (d->coarse_cross_bits & 1u))) return ophip_bad_arg(__func__, "a cached first layer needs n_coarse >= 2 and a first layer of kind \"self\"");
+    if ((L->x3d == 0) != (obj != nullptr)) return ophip_bad_arg(__func__, "x3d_external / object cache does not match the layout");
+    {   // which of the two external layouts the block was laid out for (they differ in where the final 3D rows end up)
+        const size_t want = deep ? ((d->n_coarse % 2 == 0) ? L->y3d : L->z3d) : ((d->n_coarse % 2 == 0) ? (obj ? L->z3d : L->x3d) : L->y3d);
+        if (L->feat3d_out != want) return ophip_bad_arg(__func__, "layout was made for another external_x3d mode");
+    }
     char* blob = static_cast<char*>(blob_);
     hipStream_t s_main = (hipStream_t)s_main_, s_prep = (hipStream_t)s_prep_, s_fine = (hipStream_t)s_fine_, s_copy = (hipStream_t)s_copy_;
     const int B = d->B, N = d->N, M = d->M, cap = B * N;
@@ -273,8 +292,12 @@ extern "C" int ophip_frame_enqueue_padded(const ophip_frame_desc* d, const ophip
         ff = F(L->ffcl);
         fs_b = (long long)d->hf * d->wf * d->cf; fs_c = 1; fs_y = (long long)d->wf * d->cf; fs_x = d->cf;
     }
-    float* x3d = x3d_external ? const_cast<float*>(x3d_external) : F(L->x3d);
-    if (!x3d_external) {
+    if (obj && obj->ready) {                                // the cache's buffers: complete before either stream's first read of them
+        FR_HIP(hipStreamWaitEvent(s_main, (hipEvent_t)obj->ready, 0), "hipStreamWaitEvent(object cache)");
+        if (s_prep) FR_HIP(hipStreamWaitEvent(s_prep, (hipEvent_t)obj->ready, 0), "hipStreamWaitEvent(object cache, input stream)");
+    }
+    float* x3d = x3d_external ? const_cast<float*>(x3d_external) : (deep ? nullptr : F(L->x3d));
+    if (!obj) {
         if (d->w_kpt) FR_CHECK(ophip_kpt_encode(kpts, kpts_bs, desc_c, desc_c_bs, d->w_kpt, F(L->stats), x3d, B, N, sin));
         else {
             if (B > 1 && desc_c_bs == 0) return ophip_bad_arg(__func__, "shared descriptors need the keypoint encoder");
@@ -289,19 +312,25 @@ extern "C" int ophip_frame_enqueue_padded(const ophip_frame_desc* d, const ophip
     const int kv_first = kv_first_mode();
     const bool kv_hoisted = kv_first != 0 && d->n_coarse > 0;
     // (a padded frame's cell mask is made by the caller on the compute stream just before this call: its K / V half stays on that stream)
-    const bool kv_on_prep = kv_first == 1 && s_prep && !qmask;
-    if (kv_hoisted && kv_on_prep)
-        FR_CHECK(ophip_encoder_kv_first_x3w8(x3d, x2d, B, N, M, d->w_coarse[0], 0, blob + L->enc_ws, qmask, s_prep));
+    // (a cached encoding that came in as a bare pointer is read on the compute stream only: ext_main_only; with a cached first layer the
+    //  half covers the 2D stream alone and reads nothing of the cache)
+    const bool kv_on_prep = kv_first == 1 && s_prep && !qmask && !(x3d_external && ext_main_only);
+    auto kv_first_half = [&](hipStream_t on) -> int {
+        if (deep) return ophip_x3w8_object_first(x2d, nullptr, B, N, M, d->w_coarse[0], nullptr, 0, blob + L->enc_ws, qmask, true, on);
+        if (x3d_external) return ophip_x3w8_layer_bs(x3d, x3d_ext_bs, x2d, nullptr, nullptr, B, N, M, d->w_coarse[0], nullptr, 0, 0, 0, blob + L->enc_ws,
+                                                     nullptr, nullptr, qmask, true, on);
+        return ophip_encoder_kv_first_x3w8(x3d, x2d, B, N, M, d->w_coarse[0], 0, blob + L->enc_ws, qmask, on);
+    };
+    if (kv_hoisted && kv_on_prep) FR_CHECK(kv_first_half(s_prep));
     if (s_prep) {
         FR_HIP(hipEventRecord(slot->prep_done, s_prep), "hipEventRecord(prep)");
         FR_HIP(hipStreamWaitEvent(s_main, slot->prep_done, 0), "hipStreamWaitEvent(prep)");
     }
-    if (kv_hoisted && !kv_on_prep)
-        FR_CHECK(ophip_encoder_kv_first_x3w8(x3d, x2d, B, N, M, d->w_coarse[0], 0, blob + L->enc_ws, qmask, s_main));
+    if (kv_hoisted && !kv_on_prep) FR_CHECK(kv_first_half(s_main));
     // ---- a4-a6: coarse encoder (OPHIP_FRAME_FINE_WAIT=1: behind the previous frame's fine stage) ----------------------------------
     if (prev_fine && fine_wait_enabled()) FR_HIP(hipStreamWaitEvent(s_main, prev_fine, 0), "hipStreamWaitEvent(previous fine)");      // (a no-op when it ran on s_main)
     float *y3d = F(L->y3d), *y2d = F(L->y2d), *y2 = y2d, *x2 = x2d;
-    float* z3d = x3d_external ? F(L->z3d) : x3d;          // a cached encoding is read-only: ping-pong between y and z
+    float* z3d = obj ? F(L->z3d) : x3d;                   // a cached encoding is read-only: ping-pong between y and z
     float *x3 = x3d, *y3 = y3d;
     // the last layer also writes its output as the similarity kernel's operand fragments (into the coarse workspace): no
     // frag_planes launch in front of the similarity tiles
@@ -309,15 +338,36 @@ extern "C" int ophip_frame_enqueue_padded(const ophip_frame_desc* d, const ophip
     FR_CHECK(ophip_coarse_frag_planes(F(L->cws), B, N, M, &planes3d, &planes2d));
     for (int li = 0; li < d->n_coarse; ++li) {
         const void* nxt = li + 1 < d->n_coarse ? d->w_coarse[li + 1] : nullptr;
-        if (qmask)      // padded query cells (query_image_mask): the masked layer; the similarity stage then derives its operand fragments itself
-            FR_CHECK(ophip_encoder_layer_x3w8_masked(x3, x2, y3, y2, B, N, M, d->w_coarse[li], nxt, (d->coarse_cross_bits >> li) & 1, li > 0 ? 1 : (kv_hoisted ? 2 : 0), li & 1,
+        const int is_cross = (d->coarse_cross_bits >> li) & 1;
+        const int kv_mode = li > 0 ? 1 : (kv_hoisted ? 2 : 0);
+        const bool last = li + 1 == d->n_coarse;
+        void* f3 = (last && !qmask) ? planes3d : nullptr;      // (the masked layer has no fragment-writing form: the similarity stage derives them)
+        void* f2 = (last && !qmask) ? planes2d : nullptr;
+        if (deep && li == 0) {
+            // layer 0 on the 2D stream alone; the 3D stream's rows of this layer are the cache's
+            FR_CHECK(ophip_x3w8_object_first(x2, y2, B, N, M, d->w_coarse[0], nxt, kv_mode, blob + L->enc_ws, qmask, false, s_main));
+            x3 = const_cast<float*>(obj->y3d0);
+            y3 = y3d;
+            float* t2 = x2; x2 = y2; y2 = t2;
+            continue;
+        }
+        if (deep && li == 1) {
+            FR_CHECK(ophip_x3w8_object_second(x3, obj->y3d0_bs, x2, y3, y2, B, N, M, d->w_coarse[1], nxt, is_cross, obj->kv1, obj->kv1_bs,
+                                              blob + L->enc_ws, f3, f2, qmask, s_main));
+            x3 = y3; y3 = z3d;
+            float* t2 = x2; x2 = y2; y2 = t2;
+            continue;
+        }
+        if (x3d_external && li == 0)      // the cached encoding with its own batch stride (0: one object shared by the batch)
+            FR_CHECK(ophip_x3w8_layer_bs(x3, x3d_ext_bs, x2, y3, y2, B, N, M, d->w_coarse[li], nxt, is_cross, kv_mode, 0, blob + L->enc_ws, f3, f2, qmask, false, s_main));
+        else if (qmask)      // padded query cells (query_image_mask): the masked layer; the similarity stage then derives its operand fragments itself
+            FR_CHECK(ophip_encoder_layer_x3w8_masked(x3, x2, y3, y2, B, N, M, d->w_coarse[li], nxt, is_cross, kv_mode, li & 1,
                                                      blob + L->enc_ws, qmask, s_main));
-        else if (li + 1 == d->n_coarse)
-            FR_CHECK(ophip_encoder_layer_x3w8_frag(x3, x2, y3, y2, B, N, M, d->w_coarse[li], nxt, (d->coarse_cross_bits >> li) & 1, li > 0 ? 1 : (kv_hoisted ? 2 : 0), li & 1,
+        else if (last)
+            FR_CHECK(ophip_encoder_layer_x3w8_frag(x3, x2, y3, y2, B, N, M, d->w_coarse[li], nxt, is_cross, kv_mode, li & 1,
                                                    blob + L->enc_ws, planes3d, planes2d, s_main));
         else
-        FR_CHECK(ophip_encoder_layer_x3w8(x3, x2, y3, y2, B, N, M, d->w_coarse[li], nxt, (d->coarse_cross_bits >> li) & 1, li > 0 ? 1 : (kv_hoisted ? 2 : 0), li & 1,
-                                          blob + L->enc_ws, s_main));
+            FR_CHECK(ophip_encoder_layer_x3w8(x3, x2, y3, y2, B, N, M, d->w_coarse[li], nxt, is_cross, kv_mode, li & 1, blob + L->enc_ws, s_main));
         float* nx3 = y3;
         y3 = li == 0 ? z3d : x3;
         x3 = nx3;
@@ -425,6 +475,20 @@ extern "C" int ophip_frame_enqueue_padded(const ophip_frame_desc* d, const ophip
     return 0;
 }
 
+}  // namespace
+
+extern "C" int ophip_frame_enqueue_padded(const ophip_frame_desc* d, const ophip_frame_layout_t* L, void* blob,
+                                          const float* feat_c, const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x,
+                                          const float* kpts, long long kpts_bs, const float* desc_c, long long desc_c_bs,
+                                          const float* desc_f, long long desc_f_bs, long long desc_f_cs, const float* x3d_external,
+                                          const unsigned char* qmask, const float* qscale,
+                                          void* host_dst, size_t host_bytes, void* s_main, void* s_prep, void* s_fine, void* s_copy, int* slot_out) {
+    ophip_object_cache oc{};
+    oc.x3d = x3d_external; oc.x3d_bs = -1;                 // dense [B][N][256]
+    return frame_enqueue_impl(d, L, blob, feat_c, feat_f, fs_b, fs_c, fs_y, fs_x, kpts, kpts_bs, desc_c, desc_c_bs, desc_f, desc_f_bs, desc_f_cs,
+                              x3d_external ? &oc : nullptr, true, qmask, qscale, host_dst, host_bytes, s_main, s_prep, s_fine, s_copy, slot_out);
+}
+
 extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_layout_t* L, void* blob,
                                    const float* feat_c, const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x,
                                    const float* kpts, long long kpts_bs, const float* desc_c, long long desc_c_bs,
@@ -432,6 +496,17 @@ extern "C" int ophip_frame_enqueue(const ophip_frame_desc* d, const ophip_frame_
                                    void* host_dst, size_t host_bytes, void* s_main, void* s_prep, void* s_fine, void* s_copy, int* slot_out) {
     return ophip_frame_enqueue_padded(d, L, blob, feat_c, feat_f, fs_b, fs_c, fs_y, fs_x, kpts, kpts_bs, desc_c, desc_c_bs, desc_f, desc_f_bs, desc_f_cs,
                                       x3d_external, nullptr, nullptr, host_dst, host_bytes, s_main, s_prep, s_fine, s_copy, slot_out);
+}
+
+extern "C" int ophip_frame_enqueue_object(const ophip_frame_desc* d, const ophip_frame_layout_t* L, void* blob,
+                                          const float* feat_c, const float* feat_f, long long fs_b, long long fs_c, long long fs_y, long long fs_x,
+                                          const float* kpts, long long kpts_bs, const float* desc_c, long long desc_c_bs,
+                                          const float* desc_f, long long desc_f_bs, long long desc_f_cs, const ophip_object_cache* object,
+                                          const unsigned char* qmask, const float* qscale,
+                                          void* host_dst, size_t host_bytes, void* s_main, void* s_prep, void* s_fine, void* s_copy, int* slot_out) {
+    if (object && !object->x3d && !object->y3d0) return ophip_bad_arg(__func__, "object cache without buffers");
+    return frame_enqueue_impl(d, L, blob, feat_c, feat_f, fs_b, fs_c, fs_y, fs_x, kpts, kpts_bs, desc_c, desc_c_bs, desc_f, desc_f_bs, desc_f_cs,
+                              object, false, qmask, qscale, host_dst, host_bytes, s_main, s_prep, s_fine, s_copy, slot_out);
 }
 
 extern "C" int ophip_frame_wait(int ticket) {

@@ -32,9 +32,9 @@
 #include <mutex>
 #include <thread>
 #include <unordered_map>
+#include <semaphore.h>          // (POSIX, not Linux-only: the pool's sem_t is used on every build)
 #if defined(__linux__)
 #include <sched.h>
-#include <semaphore.h>
 #include <sys/resource.h>
 #include <sys/syscall.h>
 #include <unistd.h>

@@ -14,7 +14,7 @@ import torch
 
 _LIB_PATH = os.environ.get("OPHIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libonepose_hip.so")   # OPHIP_LIB: A/B builds
 _lib = None
-ABI_VERSION = 3         # include/onepose_hip.h OPHIP_ABI_VERSION: what FrameDesc / FrameLayout / _SIGNATURES below are written for
+ABI_VERSION = 4         # include/onepose_hip.h OPHIP_ABI_VERSION: what FrameDesc / FrameLayout / _SIGNATURES below are written for
 
 c_f = ctypes.c_void_p      # device float*
 c_i = ctypes.c_int
@@ -39,6 +39,13 @@ class FrameLayout(ctypes.Structure):
                                                "result", "i_ids", "j_ids", "m_bids", "gt_mask", "mconf", "mkc", "expec", "feat3d_out", "feat2d_out")]
 
 
+class ObjectCache(ctypes.Structure):
+    """``ophip_object_cache``: per-object buffers of the frame-invariant encoder work (keypoint encoding, first layer's 3D rows, layer 1's
+    K^T V | Ksum block of the 3D source) + the event behind the kernels that wrote them"""
+    _fields_ = [("x3d", ctypes.c_void_p), ("x3d_bs", c_ll), ("y3d0", ctypes.c_void_p), ("y3d0_bs", c_ll),
+                ("kv1", ctypes.c_void_p), ("kv1_bs", c_ll), ("ready", ctypes.c_void_p)]
+
+
 _SIGNATURES = {
     "ophip_abi_version": (c_i, []),
     "ophip_build_stamp": (ctypes.c_char_p, []),
@@ -59,6 +66,12 @@ _SIGNATURES = {
                                          c_f, c_f, c_ll, c_ll, c_ll, c_ll, c_f, c_ll, c_f, c_ll, c_f, c_ll, c_ll, c_f, c_f, c_f,
                                          ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                          ctypes.POINTER(c_i)]),
+    "ophip_frame_enqueue_object": (c_i, [ctypes.POINTER(FrameDesc), ctypes.POINTER(FrameLayout), ctypes.c_void_p,
+                                         c_f, c_f, c_ll, c_ll, c_ll, c_ll, c_f, c_ll, c_f, c_ll, c_f, c_ll, c_ll, ctypes.POINTER(ObjectCache), c_f, c_f,
+                                         ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.POINTER(c_i)]),
+    "ophip_encoder_x3w8_kv_block_bytes": (ctypes.c_size_t, []),
+    "ophip_encoder_object_x3w8": (c_i, [c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_f, ctypes.c_void_p]),
     "ophip_frame_wait": (c_i, [c_i]),
     "ophip_frame_order_after_fine": (c_i, [ctypes.c_void_p]),
     "ophip_pe_add_transpose": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_void_p]),

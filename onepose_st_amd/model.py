@@ -181,18 +181,43 @@ class OnePosePlus_model(nn.Module):
     # ------------------------------------------------------------------------------------------
     # device-side weight blocks (re-packed when parameters change or move)
     # ------------------------------------------------------------------------------------------
-    _PARAM_REWALK = 64          # frames between two full walks of the module tree in _weights()
+    _PARAM_REWALK = 64          # frames between two full walks of the module tree in _weights() (a backstop: see _matcher_params)
 
     def _matcher_params(self):
         """The parameters whose packed copies the kernels read, as a list that is NOT rebuilt on every frame: walking the module tree
         (``named_parameters``: 145 tensors below ~40 modules) cost ~100 us of a 690 us frame period -- a third of the host time of an
-        enqueue -- for a question whose answer changes when a user edits the model.  The list is rebuilt every ``_PARAM_REWALK`` frames and
-        whenever ``_apply`` (``.to`` / ``.cuda`` / ``.float``) or ``load_state_dict`` ran; a parameter that is written in place, moved or
-        re-assigned inside an existing tensor is caught on the very next frame by the (data_ptr, _version) key below; only module surgery
-        (replacing a sub-module or a Parameter object) between two frames can go unseen, for at most ``_PARAM_REWALK`` frames."""
+        enqueue -- for a question whose answer changes when a user edits the model.  The list is rebuilt every ``_PARAM_REWALK`` frames,
+        whenever ``_apply`` (``.to`` / ``.cuda`` / ``.float``) or ``load_state_dict`` ran, and whenever the tree itself changed: beside the
+        list the cache keeps every (module, name, Parameter) and (parent, name, sub-module) edge it was built from and re-checks their
+        identity on each frame (~190 dictionary look-ups, ~15 us), so a replaced Parameter (``layer.q_proj.weight = nn.Parameter(...)``,
+        ``load_state_dict(assign=True)`` on a sub-module, ``parametrize``) or a replaced sub-module is seen on the very next frame; a
+        parameter that is written in place or moved is caught by the (data_ptr, _version) key of ``_weights``."""
         c = self.__dict__.get("_param_cache")
+        if c is not None and c[1] > 0:
+            for mod, name, p in c[2]:
+                if mod._parameters.get(name) is not p:
+                    c = None
+                    break
+            else:
+                for parent, name, child in c[3]:
+                    if parent._modules.get(name) is not child:
+                        c = None
+                        break
         if c is None or c[1] <= 0:
-            c = self.__dict__["_param_cache"] = [[p for n, p in self.named_parameters() if not n.startswith("backbone.")], self._PARAM_REWALK]
+            pedges, medges, plist = [], [], []
+            stack = [(n, m) for n, m in self._modules.items() if n != "backbone" and m is not None]
+            medges += [(self, n, m) for n, m in stack]
+            while stack:
+                _, mod = stack.pop()
+                for n, p in mod._parameters.items():
+                    if p is not None:
+                        pedges.append((mod, n, p))
+                for n, ch in mod._modules.items():
+                    if ch is not None:
+                        medges.append((mod, n, ch))
+                        stack.append((n, ch))
+            plist = [p for n, p in self.named_parameters() if not n.startswith("backbone.")]
+            c = self.__dict__["_param_cache"] = [plist, self._PARAM_REWALK, pedges, medges]
         c[1] -= 1
         return c[0]
 
@@ -360,27 +385,12 @@ class OnePosePlus_model(nn.Module):
                 and len(self.loftr_coarse.layer_names) <= 16):
             x3d_ext = None
             if self.cache_object:
-                # the reference keeps the object block resident across frames (OnePosePlus_inference_dataset.py:157-169): its keypoint encoding
-                # (rows a2 + a3) is computed once per (object tensors, weights) and handed to the frame call as an external input.  A MISS
-                # computes it here, with the same two kernels the frame call would run, and then takes the one-call path like a hit
-                # (until round 4 a miss fell back to the stage-by-stage host path).
-                ckey = (str(dev), B, N, kpts_d.data_ptr(), kpts_d._version, desc_in_d.data_ptr(), desc_in_d._version, id(W))
-                if self._obj_cache is None or self._obj_cache[0] != ckey:
-                    x3d_new = torch.empty(B, N, C, **f32)
-                    if self.kpt_3d_pos_encoding is not None:
-                        stats = torch.empty(4 * B + 4, **f32)
-                        lib_call("ophip_kpt_encode", P(kpts_d), bstride(kpts_d), P(desc_in_d), bstride(desc_in_d), P(W["kpt"]),
-                                 P(stats), P(x3d_new), B, N, hip.stream_handle())
-                    else:
-                        src = desc_in_d if desc_in_d.shape[0] == B else desc_in_d.expand(B, -1, -1).contiguous()
-                        lib_call("ophip_transpose_cl", P(src), P(x3d_new), B, C, N, hip.stream_handle())
-                    ev = torch.cuda.Event()
-                    ev.record(main)
-                    self._obj_cache = (ckey, x3d_new, ev, kpts_d, desc_in_d)          # the key's tensors stay alive with the entry
-                x3d_ext = self._obj_cache[1]
-                main.wait_event(self._obj_cache[2])
-                if inputs_ready:                                      # the first layer's K / V half reads the cached encoding on the input stream
-                    self._side_stream(self._prep_streams, fkey, dev).wait_event(self._obj_cache[2])
+                # the reference keeps the object block resident across frames (OnePosePlus_inference_dataset.py:157-169): what depends on it
+                # and the weights alone is computed once per (object tensors, weights) and handed to the frame call -- the keypoint encoding
+                # (rows a2 + a3) and, with a first layer of kind "self", that layer's 3D rows and the K^T V | Ksum block of those rows as the
+                # second layer's source (transformer.py:148-159; ophip_encoder_object_x3w8: the frame's own launches on the 3D stream's
+                # workgroups, so a cached frame is bit-identical).  One entry serves the whole batch when it shares one object (config 3).
+                x3d_ext = self._object_cache_entry(kpts_d, desc_in_d, W, dev, B, N, main)
             return self._enqueue_frame_call(data, feat_c, feat_f, kpts_d, desc_in_d, desc_fine_d, x3d_ext, W, dev, main, fkey,
                                             B, N, M, hc, wc, hf, wf, host_copy, inputs_ready, lazy, rerun, qmask, qscale)
         if fkey in self._frame_call_pending:                          # order this frame's encoder behind the C path's last fine stage
@@ -427,10 +437,9 @@ class OnePosePlus_model(nn.Module):
             if self.cache_object:
                 # the reference keeps the object block resident across frames (OnePosePlus_inference_dataset.py:157-169); its encoding
                 # is recomputed only when the tensors (or the weights) change
-                ckey = (str(dev), B, N, kpts_d.data_ptr(), kpts_d._version, desc_in_d.data_ptr(), desc_in_d._version, id(W))
-                if self._obj_cache is not None and self._obj_cache[0] == ckey:
-                    x3d = self._obj_cache[1]
-                    torch.cuda.current_stream(dev).wait_event(self._obj_cache[2])
+                ent = self._object_cache_entry(kpts_d, desc_in_d, W, dev, B, N, torch.cuda.current_stream(dev))
+                torch.cuda.current_stream(dev).wait_event(ent["ev"])
+                x3d = ent["x3d"] if ent["x3d"].shape[0] == B else ent["x3d"].expand(B, -1, -1).contiguous()
             if x3d is None:
                 x3d = torch.empty(B, N, C, **f32)
                 if self.kpt_3d_pos_encoding is not None:
@@ -440,10 +449,6 @@ class OnePosePlus_model(nn.Module):
                 else:
                     src = desc_in_d if desc_in_d.shape[0] == B else desc_in_d.expand(B, -1, -1).contiguous()
                     lib_call("ophip_transpose_cl", P(src), P(x3d), B, C, N, S_in)
-                if self.cache_object:
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    self._obj_cache = (ckey, x3d, ev, kpts_d, desc_in_d)          # the key's tensors stay alive with the entry
             if sprep is not None:
                 prep_done = torch.cuda.Event()
                 prep_done.record()
@@ -587,6 +592,43 @@ class OnePosePlus_model(nn.Module):
         return pend
 
 
+    def _object_cache_entry(self, kpts_d, desc_in_d, W, dev, B, N, stream):
+        """The object's cache entry ``{"x3d", "y3d0", "kv1", "ev"}`` (``ophip_object_cache``), built on a miss on ``stream`` with the kernels a
+        frame would run.  Keyed on the object tensors' storage + version and the packed weights; ``Bo`` = 1 rows when the batch shares one
+        object block (stride-0 expand / batch-1 tensors under a larger query batch), else B."""
+        lib_call, P = hip.call, hip.ptr
+        shared = B > 1 and kpts_d.shape[0] == 1 and desc_in_d.shape[0] == 1
+        Bo = 1 if shared else B
+        names = self.loftr_coarse.layer_names
+        deep = (self.precision == "bf16x3" and len(names) >= 2 and names[0] == "self"
+                and os.environ.get("OPHIP_OBJECT_CACHE_DEPTH", "2") != "1")
+        ckey = (str(dev), Bo, N, kpts_d.data_ptr(), kpts_d._version, desc_in_d.data_ptr(), desc_in_d._version, id(W), deep)
+        ent = self._obj_cache
+        if ent is not None and ent["key"] == ckey:
+            return ent
+        f32 = dict(device=dev, dtype=torch.float32)
+        with torch.cuda.stream(stream):
+            x3d = torch.empty(Bo, N, 256, **f32)
+            if self.kpt_3d_pos_encoding is not None:
+                stats = torch.empty(4 * Bo + 4, **f32)
+                lib_call("ophip_kpt_encode", P(kpts_d), 0 if kpts_d.shape[0] == 1 else kpts_d.stride(0), P(desc_in_d),
+                         0 if desc_in_d.shape[0] == 1 else desc_in_d.stride(0), P(W["kpt"]), P(stats), P(x3d), Bo, N, hip.stream_handle())
+            else:
+                src = desc_in_d if desc_in_d.shape[0] == Bo else desc_in_d.expand(Bo, -1, -1).contiguous()
+                lib_call("ophip_transpose_cl", P(src), P(x3d), Bo, 256, N, hip.stream_handle())
+            y3d0 = kv1 = None
+            if deep:
+                lib = hip.load()
+                y3d0 = torch.empty(Bo, N, 256, **f32)
+                kv1 = torch.empty(Bo, lib.ophip_encoder_x3w8_kv_block_bytes(), device=dev, dtype=torch.uint8)
+                ws = torch.empty(lib.ophip_encoder_x3w8_workspace_bytes(Bo, N, 1), device=dev, dtype=torch.uint8)
+                lib_call("ophip_encoder_object_x3w8", P(x3d), Bo, N, P(W["coarse_x3"][0], None), P(W["coarse_x3"][1], None), P(ws, None),
+                         P(y3d0), P(kv1, None), hip.stream_handle())
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        self._obj_cache = ent = {"key": ckey, "x3d": x3d, "y3d0": y3d0, "kv1": kv1, "ev": ev, "keep": (kpts_d, desc_in_d, W)}      # the key's tensors stay alive with the entry
+        return ent
+
     def flush(self):
         """End of a sequence: no further frame is coming on the current stream, so the last frame's kept-back fine stage (it would otherwise
         go out with the next ``enqueue`` or at its ``finish()``) is launched now, behind its own selection.  Optional -- ``finish()`` does it
@@ -617,7 +659,8 @@ class OnePosePlus_model(nn.Module):
         cf_ch = ff.shape[1]
         cm, lf = cfg["coarse_matching"], cfg["loftr_fine"]
         img_h = data["q_hw_i"][0]
-        pkey = (str(dev), B, N, M, hc, wc, hf, wf, cf_ch, bool(transpose_fine), x3d_ext is not None, int(img_h), id(W), bool(lazy))
+        ext_mode = 0 if x3d_ext is None else (2 if x3d_ext["y3d0"] is not None else 1)      # ophip_frame_layout's external_x3d
+        pkey = (str(dev), B, N, M, hc, wc, hf, wf, cf_ch, bool(transpose_fine), ext_mode, int(img_h), id(W), bool(lazy))
         plan = self._frame_plans.get(pkey)
         if plan is None:
             d = hip.FrameDesc()
@@ -638,7 +681,7 @@ class OnePosePlus_model(nn.Module):
                 d.w_coarse[li] = W["coarse_x3"][li].data_ptr()
             d.w_fine = W["fine_bf16"].data_ptr()
             L = hip.FrameLayout()
-            hip.call("ophip_frame_layout", ctypes.byref(d), 1 if transpose_fine else 0, 1 if x3d_ext is not None else 0, ctypes.byref(L))
+            hip.call("ophip_frame_layout", ctypes.byref(d), 1 if transpose_fine else 0, ext_mode, ctypes.byref(L))
             if len(self._frame_plans) >= 8:
                 old_id = self._frame_plans.pop(next(iter(self._frame_plans)))[2]
                 self._plan_ids.discard(old_id)
@@ -685,9 +728,11 @@ class OnePosePlus_model(nn.Module):
             # longer takes the model off the one-call path -- and the library adds a roctx range per stage and kernel (OPHIP_ROCTX=1).
             with self.profiler.record_function("LoFTR/coarse-matching/get_coarse_match"), \
                     self.profiler.record_function("LoFTR/coarse-matching/get_coarse_match/argmax-conf"):
-                slot = torch.ops.onepose_hip.frame_enqueue(plan_id, blob, fc, ff, list(fs), kpts_d, desc_in_d, desc_fine_d, x3d_ext, pin, nbytes,
+                oc = x3d_ext or {"x3d": None, "y3d0": None, "kv1": None, "ev": None}
+                slot = torch.ops.onepose_hip.frame_enqueue(plan_id, blob, fc, ff, list(fs), kpts_d, desc_in_d, desc_fine_d, oc["x3d"], pin, nbytes,
                                                            main.cuda_stream, sprep.cuda_stream if sprep is not None else 0,
-                                                           sfine.cuda_stream, scopy.cuda_stream, qmask, qscale)
+                                                           sfine.cuda_stream, scopy.cuda_stream, qmask, qscale, oc["y3d0"], oc["kv1"],
+                                                           oc["ev"].cuda_event if oc["ev"] is not None else 0)
         except Exception:
             # part of the frame may be queued on the side streams already: nothing may touch the block or the pinned buffer again
             # before those streams are idle

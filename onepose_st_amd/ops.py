@@ -43,7 +43,8 @@ _lib.define("fine_refine_bf16(Tensor feat_f_cl, Tensor desc3d_f, Tensor b_ids, T
             "Tensor wpack, int nlayers, int cross_bits, bool encoder_enable, int nsplit, int wc, int stride, float fine_scale) -> (Tensor, Tensor)")
 _lib.define("frame_enqueue(int plan, Tensor(a!) block, Tensor feat_c, Tensor feat_f, int[] fine_strides, Tensor keypoints3d, "
             "Tensor desc3d_c, Tensor desc3d_f, Tensor? x3d_external, Tensor(b!) host_dst, int host_bytes, "
-            "int s_main, int s_prep, int s_fine, int s_copy, Tensor? query_mask=None, Tensor? query_scale=None) -> int")
+            "int s_main, int s_prep, int s_fine, int s_copy, Tensor? query_mask=None, Tensor? query_scale=None, "
+            "Tensor? y3d0=None, Tensor? kv1=None, int object_ready=0) -> int")
 
 
 def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -157,9 +158,12 @@ def drop_frame_plans(pids):
 
 
 def _frame_enqueue(plan, block, feat_c, feat_f, fine_strides, keypoints3d, desc3d_c, desc3d_f, x3d_external, host_dst, host_bytes,
-                   s_main, s_prep, s_fine, s_copy, query_mask=None, query_scale=None):
-    """rows a1-a11 of one frame (``ophip_frame_enqueue_padded``; ``query_mask [B, M]`` uint8 / ``query_scale [B, 2]`` float32: the
-    reference's optional inputs of padded / resized query images); returns the wait ticket (``ophip_frame_wait``)."""
+                   s_main, s_prep, s_fine, s_copy, query_mask=None, query_scale=None, y3d0=None, kv1=None, object_ready=0):
+    """rows a1-a11 of one frame (``ophip_frame_enqueue_object``; ``query_mask [B, M]`` uint8 / ``query_scale [B, 2]`` float32: the
+    reference's optional inputs of padded / resized query images); returns the wait ticket (``ophip_frame_wait``).
+    Object cache (``ophip_object_cache``): ``x3d_external [Bo, N, 256]`` the keypoint encoding, ``y3d0 [Bo, N, 256]`` the first encoder
+    layer's 3D rows and ``kv1 [Bo, kv_block_bytes]`` (uint8) layer 1's block of the 3D source (both or neither), ``Bo`` = 1 (one object
+    shared by the batch) or B; ``object_ready``: raw handle of the event behind the kernels that wrote them (0: they are complete)."""
     if plan not in _frame_plans:
         raise ValueError(f"frame plan {plan} is not registered (ops.register_frame_plan)")
     d, L = _frame_plans[plan][:2]
@@ -177,9 +181,28 @@ def _frame_enqueue(plan, block, feat_c, feat_f, fine_strides, keypoints3d, desc3
         raise ValueError("query_mask: contiguous uint8 [B, M]")
     if query_scale is not None and (query_scale.dtype != torch.float32 or tuple(query_scale.shape) != (d.B, 2) or not query_scale.is_contiguous()):
         raise ValueError("query_scale: contiguous float32 [B, 2]")
-    hip.call("ophip_frame_enqueue_padded", ctypes.byref(d), ctypes.byref(L), vp(block.data_ptr()),
+    oc = None
+    if x3d_external is not None or y3d0 is not None:
+        if (y3d0 is None) != (kv1 is None):
+            raise ValueError("y3d0 and kv1 go together")
+        oc = hip.ObjectCache()
+        for t, name in ((x3d_external, "x3d_external"), (y3d0, "y3d0")):
+            if t is not None and (t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.dim() != 3
+                                  or t.shape[0] not in (1, d.B) or tuple(t.shape[1:]) != (d.N, 256)):
+                raise ValueError(f"{name}: contiguous float32 [1 or B, N, 256] on the HIP device")
+        if x3d_external is not None:
+            oc.x3d, oc.x3d_bs = x3d_external.data_ptr(), (0 if (x3d_external.shape[0] == 1 and d.B > 1) else d.N * 256)
+        if y3d0 is not None:
+            kvb = hip.load().ophip_encoder_x3w8_kv_block_bytes()
+            if kv1.dtype != torch.uint8 or not kv1.is_cuda or not kv1.is_contiguous() or tuple(kv1.shape) != (y3d0.shape[0], kvb):
+                raise ValueError(f"kv1: contiguous uint8 [{y3d0.shape[0]}, {kvb}] on the HIP device")
+            shared = y3d0.shape[0] == 1 and d.B > 1
+            oc.y3d0, oc.y3d0_bs = y3d0.data_ptr(), (0 if shared else d.N * 256)
+            oc.kv1, oc.kv1_bs = kv1.data_ptr(), (0 if shared else kvb)
+        oc.ready = int(object_ready) or None
+    hip.call("ophip_frame_enqueue_object", ctypes.byref(d), ctypes.byref(L), vp(block.data_ptr()),
              hip.ptr(feat_c), hip.ptr(feat_f), fs[0], fs[1], fs[2], fs[3], hip.ptr(keypoints3d), _bstride(keypoints3d),
-             hip.ptr(desc3d_c), _bstride(desc3d_c), hip.ptr(desc3d_f), _bstride(desc3d_f), desc3d_f.stride(1), hip.ptr(x3d_external),
+             hip.ptr(desc3d_c), _bstride(desc3d_c), hip.ptr(desc3d_f), _bstride(desc3d_f), desc3d_f.stride(1), ctypes.byref(oc) if oc is not None else None,
              hip.ptr(query_mask, torch.uint8), hip.ptr(query_scale), vp(host_dst.data_ptr()), int(host_bytes), vp(s_main), vp(s_prep) if s_prep else None, vp(s_fine), vp(s_copy), ctypes.byref(slot))
     return slot.value
 

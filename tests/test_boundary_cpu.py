@@ -54,9 +54,9 @@ def test_cabi_exports_every_declared_symbol():
     lib = ctypes.CDLL(hip.library_path())
     for name in declared:
         assert hasattr(lib, name), name
-    assert hip.load().ophip_abi_version() == hip.ABI_VERSION == 3
+    assert hip.load().ophip_abi_version() == hip.ABI_VERSION == 4
     header = open(os.path.join(REPO, "include", "onepose_hip.h")).read()
-    assert "#define OPHIP_ABI_VERSION 3" in header          # header, library and binding carry the same number
+    assert "#define OPHIP_ABI_VERSION 4" in header          # header, library and binding carry the same number
     assert hip.load().ophip_encoder_workspace_floats(1, 7000, 4800) == (219 + 150 + 2) * 8448
 
 
@@ -167,8 +167,8 @@ def test_frame_layout_is_aligned_and_disjoint():
 
 def test_packed_weights_follow_the_parameters_without_walking_the_module_tree_every_frame(sd, cfg):
     """model._weights: the device-side weight blocks are re-packed when a parameter changes; the per-frame check reads (data_ptr, _version) of
-    a cached parameter list (the module-tree walk cost a third of an enqueue's host time), rebuilt after ``load_state_dict`` / ``_apply`` and
-    every ``_PARAM_REWALK`` frames."""
+    a cached parameter list (the module-tree walk cost a third of an enqueue's host time), rebuilt after ``load_state_dict`` / ``_apply``,
+    every ``_PARAM_REWALK`` frames, and as soon as a Parameter object or a sub-module of the matcher was replaced (identity check of the edges)."""
     m = OnePosePlus_model(cfg).eval()
     m.load_state_dict(sd)
     cpu = torch.device("cpu")
@@ -188,12 +188,16 @@ def test_packed_weights_follow_the_parameters_without_walking_the_module_tree_ev
     m.load_state_dict(sd)                                              # copies in place AND drops the cached list
     w2 = m._weights(cpu)
     assert w2 is not w1 and torch.equal(w2["coarse_x3"][0], w0["coarse_x3"][0])
-    m.loftr_coarse.layers[0].q_proj.weight = torch.nn.Parameter(p.detach() * 3.0)       # module surgery: seen after at most _PARAM_REWALK frames
-    seen = None
-    for i in range(m._PARAM_REWALK + 1):
-        if m._weights(cpu) is not w2:
-            seen = i
-            break
-    assert seen is not None and seen <= m._PARAM_REWALK
+    m.loftr_coarse.layers[0].q_proj.weight = torch.nn.Parameter(p.detach() * 3.0)       # module surgery: a replaced Parameter object ...
+    w3 = m._weights(cpu)
+    assert w3 is not w2 and not torch.equal(w3["coarse_x3"][0], w2["coarse_x3"][0])      # ... is seen on the very next frame (identity of the tree's edges)
+    import copy
+    new_layer = copy.deepcopy(m.loftr_coarse.layers[1])
+    with torch.no_grad():
+        new_layer.merge.weight.mul_(0.5)
+    m.loftr_coarse.layers[1] = new_layer                                                 # a replaced sub-module as well
+    w4 = m._weights(cpu)
+    assert w4 is not w3 and not torch.equal(w4["coarse_x3"][1], w3["coarse_x3"][1])
+    assert m._weights(cpu) is w4
     m.double()                                                         # _apply drops the list as well
     assert m.__dict__["_param_cache"] is None

@@ -724,7 +724,19 @@ def test_c3_batch32_matches_single_frame_runs(sd, cfg, dev):
         for k in ("i_ids", "j_ids", "mconf", "mkpts_query_f", "mkpts_3d_db", "expec_f"):
             assert torch.equal(data[k][sel], one[k]), (b, k)
     assert torch.equal(data["conf_matrix"][5], singles[order[5]]["conf_matrix"][0])
+    # the same batch with the object cache: the shared block's first-layer rows are computed ONCE (one row set, stride 0), bit-identical
+    keep = {k: data[k].clone() for k in ("b_ids", "i_ids", "j_ids", "mconf", "mkpts_query_f", "expec_f")}
     del data, singles
+    torch.cuda.empty_cache()
+    ccfg = copy.deepcopy(cfg)
+    ccfg["hip_cache_object"] = True
+    mc = _model(sd, ccfg, dev, "bf16x3")
+    data = {k: d[k] for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db")}
+    mc.forward_features(data, d["feat_c"], d["feat_f"], batch["image_hw"])
+    assert mc._obj_cache["y3d0"].shape[0] == 1
+    for k, v in keep.items():
+        assert torch.equal(data[k], v), ("object cache", k)
+    del data
 
 
 def test_fine_disabled_and_encoder_disabled(sd, cfg, dev):
@@ -925,9 +937,12 @@ print(json.dumps(out))
     assert res["1"] == res["0"]
 
 
-def test_object_cache_is_bit_identical(sd, cfg, dev):
-    """config["hip_cache_object"]: the keypoint encoding (rows a2 + a3) of a resident object block is computed once and re-used
-    by the following frames -- same results bit for bit as the uncached model; a changed block (or an in-place edit) re-encodes."""
+def test_object_cache_is_bit_identical(sd, cfg, dev, monkeypatch):
+    """config["hip_cache_object"]: what depends on the resident object block and the weights alone -- the keypoint encoding (rows a2 + a3),
+    the first encoder layer's 3D rows and the K^T V | Ksum block of those rows as the second layer's source (transformer.py:148-159) -- is
+    computed once and re-used by the following frames: same results bit for bit as the uncached model, at both cache depths, pipelined with
+    the input kernels on their side stream, for a batch that shares one object (computed ONCE, stride 0), for a batch of distinct objects and
+    for a padded frame; a changed block (or an in-place edit) rebuilds the entry."""
     import copy
     frames = [make_synthetic_inputs(sd, n_points=1100, image_hw=(128, 192), n_plant=400, seed=41, config=cfg, frame=f) for f in range(3)]
     obj = {k: frames[0][k].to(dev) for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db")}
@@ -951,11 +966,75 @@ def test_object_cache_is_bit_identical(sd, cfg, dev):
             assert torch.equal(a[k], b[k]), k
     assert ops.CALLS["frame_enqueue"] == n_calls + 6            # the cache MISS (first frame) takes the one-call frame path like the hits
     entry = cached._obj_cache
-    assert entry is not None
+    assert entry is not None and entry["y3d0"] is not None and entry["kv1"] is not None       # first layer "self": the deep entry
+    assert tuple(entry["y3d0"].shape) == (1, 1100, 256)
     d = dict(obj)
     cached.forward_features(d, frames[0]["feat_c"].to(dev), frames[0]["feat_f"].to(dev), frames[0]["image_hw"])
-    assert cached._obj_cache is entry                           # same block: the cached encoding was used
-    obj["keypoints3d"].mul_(1.5)                               # in-place edit bumps the version: re-encode
+    assert cached._obj_cache is entry                           # same block: the cached entry was used
+    # the cached rows ARE the uncached first layer's 3D rows: ophip_encoder_object_x3w8 against the plain layer call on both streams
+    W = cached._weights(dev)
+    lib = hip.load()
+    P = hip.ptr
+    x2 = torch.randn(1, 24 * 16, 256, device=dev)
+    y3, y2 = torch.empty_like(entry["x3d"]), torch.empty_like(x2)
+    ws = torch.empty(lib.ophip_encoder_x3w8_workspace_bytes(1, 1100, 24 * 16), device=dev, dtype=torch.uint8)
+    hip.call("ophip_encoder_layer_x3w8", P(entry["x3d"]), P(x2), P(y3), P(y2), 1, 1100, 24 * 16, P(W["coarse_x3"][0], None), P(W["coarse_x3"][1], None),
+             0, 0, 0, P(ws, None), hip.stream_handle())
+    torch.cuda.synchronize()
+    assert torch.equal(y3, entry["y3d0"])
+    # the encoding alone (depth 1), and both depths pipelined with the input kernels (and the first layer's K / V half) on the side stream
+    for depth in ("1", "2"):
+        monkeypatch.setenv("OPHIP_OBJECT_CACHE_DEPTH", depth)
+        cached._obj_cache = None
+        pend, outs = [], []
+        for f in frames:
+            dd = dict(obj)
+            pend.append((dd, cached.enqueue_features(dd, f["feat_c"].to(dev), f["feat_f"].to(dev), f["image_hw"], inputs_ready=True)))
+        for dd, p in pend:
+            p.finish()
+            outs.append(dd)
+        assert (cached._obj_cache["y3d0"] is None) == (depth == "1")
+        for f, dd in zip(frames, outs):
+            a = dict(obj)
+            plain.forward_features(a, f["feat_c"].to(dev), f["feat_f"].to(dev), f["image_hw"])
+            for k in keys:
+                assert torch.equal(a[k], dd[k]), (depth, k)
+    monkeypatch.delenv("OPHIP_OBJECT_CACHE_DEPTH")
+    # a batch of three frames sharing ONE object block (stride-0 expand: one entry of one row set) and a batch of two distinct objects
+    B = 3
+    fc = torch.cat([f["feat_c"] for f in frames]).to(dev)
+    ff = torch.cat([f["feat_f"] for f in frames]).to(dev)
+    shared = {k: v.expand(B, *v.shape[1:]) for k, v in obj.items()}
+    cached._obj_cache = None
+    a, b = dict(shared), dict(shared)
+    plain.forward_features(a, fc, ff, frames[0]["image_hw"])
+    cached.forward_features(b, fc, ff, frames[0]["image_hw"])
+    assert cached._obj_cache["y3d0"].shape[0] == 1 and len(a["i_ids"]) > 600
+    for k in keys + ("b_ids",):
+        assert torch.equal(a[k], b[k]), ("shared", k)
+    other = make_synthetic_inputs(sd, n_points=1100, image_hw=(128, 192), n_plant=400, seed=77, config=cfg, frame=0)
+    two = {k: torch.cat([frames[0][k], other[k]]).to(dev) for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db")}
+    fc2 = torch.cat([frames[0]["feat_c"], other["feat_c"]]).to(dev)
+    ff2 = torch.cat([frames[0]["feat_f"], other["feat_f"]]).to(dev)
+    a, b = dict(two), dict(two)
+    plain.forward_features(a, fc2, ff2, frames[0]["image_hw"])
+    cached.forward_features(b, fc2, ff2, frames[0]["image_hw"])
+    assert cached._obj_cache["y3d0"].shape[0] == 2
+    for k in keys + ("b_ids",):
+        assert torch.equal(a[k], b[k]), ("two objects", k)
+    # a padded query image (query_image_mask): the mask touches the 2D stream only, the cached 3D rows stay valid
+    hc, wc = 128 // 8, 192 // 8
+    qm = torch.ones(1, hc, wc, dtype=torch.bool)
+    qm[:, :, wc - 5:] = False
+    a, b = dict(obj), dict(obj)
+    a["query_image_mask"] = b["query_image_mask"] = qm.to(dev)
+    plain.forward_features(a, frames[2]["feat_c"].to(dev), frames[2]["feat_f"].to(dev), frames[2]["image_hw"])
+    cached.forward_features(b, frames[2]["feat_c"].to(dev), frames[2]["feat_f"].to(dev), frames[2]["image_hw"])
+    assert len(a["i_ids"]) > 100
+    for k in keys:
+        assert torch.equal(a[k], b[k]), ("masked", k)
+    entry = cached._obj_cache
+    obj["keypoints3d"].mul_(1.5)                               # in-place edit bumps the version: rebuild
     a, b = dict(obj), dict(obj)
     plain.forward_features(a, frames[1]["feat_c"].to(dev), frames[1]["feat_f"].to(dev), frames[1]["image_hw"])
     cached.forward_features(b, frames[1]["feat_c"].to(dev), frames[1]["feat_f"].to(dev), frames[1]["image_hw"])

@@ -99,3 +99,32 @@ def test_rank_report_flags_a_missing_or_short_rank():
     dup = [list(r) for r in full]
     dup[3][0] = 2
     assert not bench.rank_report(dup, 4, 20)["all_frames_done"]                           # two records from one rank
+
+
+def test_rank_report_counts_poses_when_host_pnp_is_on():
+    sys.path.insert(0, REPO)
+    import bench
+    full = [[r, 20, 0.017, 1900.0, r, 20] for r in range(2)]
+    assert bench.rank_report(full, 2, 20, 20)["all_frames_done"]
+    lost = [list(r) for r in full]
+    lost[1][5] = 19                                                                       # a pose that was never joined
+    assert not bench.rank_report(lost, 2, 20, 20)["all_frames_done"]
+    assert bench.rank_report(lost, 2, 20)["all_frames_done"]                              # matcher only: poses are not expected
+
+
+def test_a_short_rank_makes_every_rank_exit_nonzero():
+    """The per-rank record carries what the rank COUNTED (frames whose results reached the host), every rank evaluates the same gathered rows,
+    and a shortfall on one rank ends all of them with an error -- not only rank 0 (launch probe over gloo, world 2, rank 1 one frame short)."""
+    env = dict(os.environ, OPHIP_BENCH_LAUNCH_PROBE="1", OPHIP_BENCH_PROBE_SHORT_RANK="1", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    procs = []
+    port = 29500 + (os.getpid() % 2000)
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", LOCAL_WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                 TORCHELASTIC_RUN_ID="probe")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--share-device", "--dist-backend", "gloo",
+                                       "--steps", "3", "--warmup", "0"], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert [p.returncode != 0 for p in procs] == [True, True], [o[1][-500:] for o in outs]
+    assert "not every rank finished its frames" in outs[0][1] and "not every rank finished its frames" in outs[1][1]
