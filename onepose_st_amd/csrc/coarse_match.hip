@@ -297,44 +297,6 @@ __device__ __forceinline__ bool xcd_tile(int ntr, int ntc, int& ti, int& tj) {
     return true;
 }
 
-// vector-ALU cross-lane moves (DPP / permlane swaps: no LDS crossbar round trip)
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-// over the 32 lanes that share lane >> 5, result in all of them: xor 1, 2 (quad permutes), 4 (half mirror of uniform quads),
-// 8 (mirror of uniform halves), 16 (v_permlane16_swap)
-__device__ __forceinline__ float half_sum_dpp(float v) {
-    v += dpp_f<0xB1>(v);
-    v += dpp_f<0x4E>(v);
-    v += dpp_f<0x141>(v);
-    v += dpp_f<0x140>(v);
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    const unsigned a0 = a[0], a1 = a[1];
-    return __builtin_bit_cast(float, a0) + __builtin_bit_cast(float, a1);
-}
-__device__ __forceinline__ float wave_max_dpp(float v) {
-    v = fmaxf(v, dpp_f<0xB1>(v));
-    v = fmaxf(v, dpp_f<0x4E>(v));
-    v = fmaxf(v, dpp_f<0x141>(v));
-    v = fmaxf(v, dpp_f<0x140>(v));
-    unsigned u = __builtin_bit_cast(unsigned, v);
-    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    const unsigned a0 = a[0], a1 = a[1];
-    v = fmaxf(__builtin_bit_cast(float, a0), __builtin_bit_cast(float, a1));
-    u = __builtin_bit_cast(unsigned, v);
-    auto c = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    const unsigned c0 = c[0], c1 = c[1];
-    return fmaxf(__builtin_bit_cast(float, c0), __builtin_bit_cast(float, c1));
-}
-__device__ __forceinline__ float swap32_sum(float v) {              // v(lane) + v(lane ^ 32)
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    auto c = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    const unsigned c0 = c[0], c1 = c[1];
-    return __builtin_bit_cast(float, c0) + __builtin_bit_cast(float, c1);
-}
-
 constexpr int FLD = 132;                                             // S staging pitch of sim_frag: rows stay 16-byte aligned
 constexpr int FRAG_CHUNK_BYTES = 16384;                              // one k-step: 16 fragments, A 8 KiB, B 8 KiB; four buffers
 constexpr size_t SIM_FRAG_STAGE = (size_t)TM * FLD * sizeof(float);  // 67 584

@@ -41,7 +41,8 @@ struct FineBArgs {
     const float* feat_f; long long fs_b, fs_c, fs_y, fs_x; int hf, wf;
     const float* desc_f; long long ds_b, ds_c;
     const long long *b_ids, *i_ids, *j_ids;
-    const int* count;
+    const int* count; int cap;   // device-side match count; capacity of the id lists (the grid covers it)
+    int stagger, ncu;            // experiment (OPHIP_FINE_STAGGER): units of ~4 k cycles by which workgroups ncu .. 2 ncu - 1 (the second one of each CU) start late
     const float* mkq_c;
     const char* wpack;           // nlayers x (2 * W_ELEMS * 2 + 4 * CF * 4) bytes
     int nlayers; unsigned cross_bits; int enc_enable;
@@ -138,6 +139,48 @@ __device__ __forceinline__ f32x16 attend_match(f32x16& qt, const f32x16& kt, con
     }
     __builtin_amdgcn_wave_barrier();              // the strip is rewritten by this wave's next match
     return out;
+}
+
+// ---- last stage of a match, from the residual registers (fine_matching.py:28-110) ------------------------------------------------
+// sim[r] = <f3d, win[r]> / sqrt(128) over the 25 window tokens -> softmax -> expectation and standard deviation on the normalised grid.
+// Every wave holds features 32 ft .. 32 ft + 31 of its 32 tokens as a D[feature][token] tile (lane (r = token, h): register 4g + j = feature
+// 8g + 4h + j); the 3D token's values sit in lanes 25 (h = 0) and 57 (h = 1): v_readlane hands them to every lane, a lane forms the partial
+// dot product of ITS token over its 16 features, the two lane halves are added by v_permlane32_swap, and the four feature-tile waves'
+// partials meet in LDS behind one barrier.  (Until round 4 one wave per match walked the staged f32 rows: 25 lanes x 32 dependent LDS
+// reads + seven ds_bpermute butterflies = 6-8 k cycles of a 118 k-cycle workgroup, profiles/r04_stamps_fine_pair.txt "end".)
+__device__ __forceinline__ float corr_partial(const f32x16& x, int lane) {
+#pragma clang fp contract(off)
+    float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[reg]), TOK3D));
+        const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[reg]), 32 + TOK3D));
+        p0 = __builtin_fmaf(x[reg], a0, p0);
+        p1 = __builtin_fmaf(x[reg], a1, p1);
+    }
+    return swap32_sum((lane >> 5) ? p1 : p0);
+}
+// `part`: the four waves' partials of this match's tokens, part[ft * pstride + r]
+__device__ __forceinline__ void expect_store(const FineBArgs& p, int k, const float* part, int pstride, int lane) {
+#pragma clang fp contract(off)
+    float t = -INFINITY;
+    if (lane < WIN) {
+        const float dot = (part[lane] + part[pstride + lane]) + (part[2 * pstride + lane] + part[3 * pstride + lane]);
+        t = dot * 0.08838834764831845f;              // 1 / sqrt(128)
+    }
+    const float m = wave_max_dpp(t);
+    const float e = lane < WIN ? expf(t - m) : 0.f;
+    const float sum = wave_sum_dpp(e);
+    const float pr = e / sum;
+    const float gx = (float)(lane % 5 - 2) * 0.5f, gy = (float)(lane / 5 - 2) * 0.5f;
+    const float ex = wave_sum_dpp(pr * gx), ey = wave_sum_dpp(pr * gy);
+    const float ex2 = wave_sum_dpp(pr * gx * gx), ey2 = wave_sum_dpp(pr * gy * gy);
+    if (lane == 0) {
+        const float vx = ex2 - ex * ex, vy = ey2 - ey * ey;
+        const float sd = sqrtf(fmaxf(vx, 1e-10f)) + sqrtf(fmaxf(vy, 1e-10f));
+        p.expec_f[3 * k] = ex; p.expec_f[3 * k + 1] = ey; p.expec_f[3 * k + 2] = sd;
+        store_fine_keypoint(p, k, ex, ey);
+    }
 }
 
 // f32 staging image [64][128], 16-byte chunks swizzled like the planes (32 chunks per row)
@@ -400,14 +443,14 @@ __global__ __launch_bounds__(NM * 256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_refi
         OPHIP_STAMP(p.stamps, blockIdx.x, 9 + 8 * l);
     }
 
-    // ---- final f32 features to the staging image, then correlation -> softmax -> expectation -------------------
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        f32x4 v = {xres[4 * g], xres[4 * g + 1], xres[4 * g + 2], xres[4 * g + 3]};
-        *reinterpret_cast<f32x4*>(stage + stage_off(32 * tt + r, 8 * ft + 2 * g + h)) = v;
-    }
-    __syncthreads();
+    // ---- correlation -> softmax -> expectation from the residual registers (the f32 staging image only for the debug outputs) ----------
     if (p.dbg_win) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = {xres[4 * g], xres[4 * g + 1], xres[4 * g + 2], xres[4 * g + 3]};
+            *reinterpret_cast<f32x4*>(stage + stage_off(32 * tt + r, 8 * ft + 2 * g + h)) = v;
+        }
+        __syncthreads();
         for (int mi = 0; mi < NM; ++mi) {
             const int k = k0 + mi;
             if (k >= total) break;
@@ -417,36 +460,14 @@ __global__ __launch_bounds__(NM * 256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_refi
             }
             if (tid < CF) p.dbg_f3[(size_t)k * CF + tid] = *reinterpret_cast<const float*>(stage + stage_off(32 * mi + TOK3D, tid >> 2) + 4 * (tid & 3));
         }
+        __syncthreads();                             // the partials below share the staging image's LDS
     }
-    if (ft == 0 && k0 + tt < total) {
-        const int k = k0 + tt, base = 32 * tt;
-        float t = -INFINITY;
-        if (lane < WIN) {
-            float dot = 0.f;
-            for (int c4 = 0; c4 < CF / 4; ++c4) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(stage + stage_off(base + TOK3D, c4));
-                const f32x4 bq = *reinterpret_cast<const f32x4*>(stage + stage_off(base + lane, c4));
-                dot += a[0] * bq[0];
-                dot += a[1] * bq[1];
-                dot += a[2] * bq[2];
-                dot += a[3] * bq[3];
-            }
-            t = dot * 0.08838834764831845f;              // 1 / sqrt(128)
-        }
-        const float m = wave_max(t);
-        const float e = lane < WIN ? expf(t - m) : 0.f;
-        const float sum = wave_sum(e);
-        const float pr = e / sum;
-        const float gx = (float)(lane % 5 - 2) * 0.5f, gy = (float)(lane / 5 - 2) * 0.5f;
-        const float ex = wave_sum(pr * gx), ey = wave_sum(pr * gy);
-        const float ex2 = wave_sum(pr * gx * gx), ey2 = wave_sum(pr * gy * gy);
-        if (lane == 0) {
-            const float vx = ex2 - ex * ex, vy = ey2 - ey * ey;
-            const float sd = sqrtf(fmaxf(vx, 1e-10f)) + sqrtf(fmaxf(vy, 1e-10f));
-            p.expec_f[3 * k] = ex; p.expec_f[3 * k + 1] = ey; p.expec_f[3 * k + 2] = sd;
-            store_fine_keypoint(p, k, ex, ey);
-        }
+    {
+        const float pp = corr_partial(xres, lane);
+        if (h == 0) scratch[ft * (32 * NM) + 32 * tt + r] = pp;
     }
+    __syncthreads();
+    if (ft == 0 && k0 + tt < total) expect_store(p, k0 + tt, scratch + 32 * tt, 32 * NM, lane);
     OPHIP_STAMP(p.stamps, blockIdx.x, 31);
 }
 
@@ -512,10 +533,17 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_pair_kern
     float* scratch = reinterpret_cast<float*>(smem + 4 * XB);
     static_assert(PL == 1 || PL == 2, "one or two planes");
     const int k0 = 2 * blockIdx.x;
+    // the ids of both matches travel WITH the count (the lists are capacity-sized and the grid covers the capacity, so the reads are in
+    // bounds whatever the count turns out to be): one round trip to memory in front of the gather instead of two
+    const bool in1 = k0 + 1 < p.cap;
+    const int b0 = (int)p.b_ids[k0], i30 = (int)p.i_ids[k0], j0 = (int)p.j_ids[k0];
+    const int b1_ = in1 ? (int)p.b_ids[k0 + 1] : 0, i31_ = in1 ? (int)p.i_ids[k0 + 1] : 0, j1_ = in1 ? (int)p.j_ids[k0 + 1] : 0;
     const int total = *p.count;
     if (k0 >= total) return;
     const int tid = threadIdx.x, lane = tid & 63, ft = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
+    if (p.stagger > 0 && (int)blockIdx.x >= p.ncu && (int)blockIdx.x < 2 * p.ncu)
+        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(64);
     OPHIP_STAMP(p.stamps, blockIdx.x, 0);
 
     const int nl = p.enc_enable ? p.nlayers : 0;
@@ -531,8 +559,7 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_pair_kern
 
     // ---- gather both matches into the f32 staging image (all loads issued before the first LDS write) -------------------
     const bool live1 = k0 + 1 < total;
-    const int b0 = (int)p.b_ids[k0], i30 = (int)p.i_ids[k0], j0 = (int)p.j_ids[k0];
-    const int b1 = live1 ? (int)p.b_ids[k0 + 1] : 0, i31 = live1 ? (int)p.i_ids[k0 + 1] : 0, j1 = live1 ? (int)p.j_ids[k0 + 1] : 0;
+    const int b1 = live1 ? b1_ : 0, i31 = live1 ? i31_ : 0, j1 = live1 ? j1_ : 0;
     const int cy0 = p.stride * (j0 / p.wc), cx0 = p.stride * (j0 % p.wc);
     const int cy1 = p.stride * (j1 / p.wc), cx1 = p.stride * (j1 % p.wc);
 #define PLIVE(mi) ((mi) ? live1 : true)
@@ -717,16 +744,16 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_pair_kern
         OPHIP_STAMP(p.stamps, blockIdx.x, 9 + 8 * l);
     }
 
-    // ---- final f32 features to the staging image (Y half: idle), then correlation -> softmax -> expectation -------------------
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 v = {xres[tt][4 * g], xres[tt][4 * g + 1], xres[tt][4 * g + 2], xres[tt][4 * g + 3]};
-            *reinterpret_cast<f32x4*>(stage + stage_off(32 * tt + r, 8 * ft + 2 * g + h)) = v;
-        }
-    __syncthreads();
+    // ---- correlation -> softmax -> expectation from the residual registers (the f32 staging image only for the debug outputs) ----------
     if (p.dbg_win) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {xres[tt][4 * g], xres[tt][4 * g + 1], xres[tt][4 * g + 2], xres[tt][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(stage + stage_off(32 * tt + r, 8 * ft + 2 * g + h)) = v;
+            }
+        __syncthreads();
         for (int mi = 0; mi < 2; ++mi) {
             const int k = k0 + mi;
             if (k >= total) break;
@@ -737,35 +764,13 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(2, 2) void fine_pair_kern
             if (tid < CF) p.dbg_f3[(size_t)k * CF + tid] = *reinterpret_cast<const float*>(stage + stage_off(32 * mi + TOK3D, tid >> 2) + 4 * (tid & 3));
         }
     }
-    if (ft < 2 && k0 + ft < total) {             // wave 0 finishes match k0, wave 1 match k0 + 1
-        const int k = k0 + ft, base = 32 * ft;
-        float t = -INFINITY;
-        if (lane < WIN) {
-            float dot = 0.f;
-            for (int c4 = 0; c4 < CF / 4; ++c4) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(stage + stage_off(base + TOK3D, c4));
-                const f32x4 bq = *reinterpret_cast<const f32x4*>(stage + stage_off(base + lane, c4));
-                dot += a[0] * bq[0];
-                dot += a[1] * bq[1];
-                dot += a[2] * bq[2];
-                dot += a[3] * bq[3];
-            }
-            t = dot * 0.08838834764831845f;              // 1 / sqrt(128)
-        }
-        const float m = wave_max(t);
-        const float e = lane < WIN ? expf(t - m) : 0.f;
-        const float sum = wave_sum(e);
-        const float pr = e / sum;
-        const float gx = (float)(lane % 5 - 2) * 0.5f, gy = (float)(lane / 5 - 2) * 0.5f;
-        const float ex = wave_sum(pr * gx), ey = wave_sum(pr * gy);
-        const float ex2 = wave_sum(pr * gx * gx), ey2 = wave_sum(pr * gy * gy);
-        if (lane == 0) {
-            const float vx = ex2 - ex * ex, vy = ey2 - ey * ey;
-            const float sd = sqrtf(fmaxf(vx, 1e-10f)) + sqrtf(fmaxf(vy, 1e-10f));
-            p.expec_f[3 * k] = ex; p.expec_f[3 * k + 1] = ey; p.expec_f[3 * k + 2] = sd;
-            store_fine_keypoint(p, k, ex, ey);
-        }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const float pp = corr_partial(xres[tt], lane);
+        if (h == 0) scratch[ft * 64 + 32 * tt + r] = pp;         // (the LayerNorm exchange is done with: the layer's last barrier is behind us)
     }
+    __syncthreads();
+    if (ft < 2 && k0 + ft < total) expect_store(p, k0 + ft, scratch + 32 * ft, 64, lane);      // wave 0 finishes match k0, wave 1 match k0 + 1
     OPHIP_STAMP(p.stamps, blockIdx.x, 31);
 }
 
@@ -796,7 +801,10 @@ int fine_bf16(const float* feat_f, long long fs_b, long long fs_c, long long fs_
     FineBArgs a;
     a.feat_f = feat_f; a.fs_b = fs_b; a.fs_c = fs_c; a.fs_y = fs_y; a.fs_x = fs_x; a.hf = hf; a.wf = wf;
     a.desc_f = desc3d_f; a.ds_b = ds_b; a.ds_c = ds_c;
-    a.b_ids = b_ids; a.i_ids = i_ids; a.j_ids = j_ids; a.count = count; a.mkq_c = mkpts_c;
+    a.b_ids = b_ids; a.i_ids = i_ids; a.j_ids = j_ids; a.count = count; a.cap = max_matches; a.mkq_c = mkpts_c;
+    static const int stagger = [] { const char* e = getenv("OPHIP_FINE_STAGGER"); return e ? atoi(e) : 0; }();
+    a.stagger = stagger; a.ncu = 256;
+    if (stagger > 0) { int dev = 0, n = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) a.ncu = n; }
     a.wpack = reinterpret_cast<const char*>(wpack); a.nlayers = nlayers; a.cross_bits = cross_bits; a.enc_enable = encoder_enable;
     a.wc = wc; a.stride = stride; a.fine_scale = fine_scale; a.qscale = query_scale;
     a.expec_f = expec_f; a.mkq_f = mkpts_f; a.dbg_win = dbg_win; a.dbg_f3 = dbg_f3;

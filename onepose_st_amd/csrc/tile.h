@@ -117,6 +117,49 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// vector-ALU cross-lane moves (DPP / permlane swaps: no LDS crossbar round trip)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// over the 32 lanes that share lane >> 5, result in all of them: xor 1, 2 (quad permutes), 4 (half mirror of uniform quads),
+// 8 (mirror of uniform halves), 16 (v_permlane16_swap)
+__device__ __forceinline__ float half_sum_dpp(float v) {
+    v += dpp_f<0xB1>(v);
+    v += dpp_f<0x4E>(v);
+    v += dpp_f<0x141>(v);
+    v += dpp_f<0x140>(v);
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const unsigned a0 = a[0], a1 = a[1];
+    return __builtin_bit_cast(float, a0) + __builtin_bit_cast(float, a1);
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    unsigned u = __builtin_bit_cast(unsigned, v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const unsigned a0 = a[0], a1 = a[1];
+    v = fmaxf(__builtin_bit_cast(float, a0), __builtin_bit_cast(float, a1));
+    u = __builtin_bit_cast(unsigned, v);
+    auto c = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned c0 = c[0], c1 = c[1];
+    return fmaxf(__builtin_bit_cast(float, c0), __builtin_bit_cast(float, c1));
+}
+__device__ __forceinline__ float swap32_sum(float v) {              // v(lane) + v(lane ^ 32)
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto c = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned c0 = c[0], c1 = c[1];
+    return __builtin_bit_cast(float, c0) + __builtin_bit_cast(float, c1);
+}
+
+__device__ __forceinline__ float wave_sum_dpp(float v) {               // sum over the 64 lanes, result in all of them (same moves as wave_max_dpp)
+    v = half_sum_dpp(v);
+    return swap32_sum(v);
+}
+
 // Row-wise LayerNorm over an LDS image [32][C] (row stride ld).  Wave w of 4 normalises rows
 // 8w..8w+7; two-pass (mean, then centred second moment), biased variance, eps inside the sqrt.
 // AFFINE: y = xhat * gamma + beta.  RELU: max(y, 0) (the keypoint encoder's IN + ReLU).

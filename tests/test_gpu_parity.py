@@ -731,7 +731,9 @@ def test_c3_batch32_matches_single_frame_runs(sd, cfg, dev):
     ccfg = copy.deepcopy(cfg)
     ccfg["hip_cache_object"] = True
     mc = _model(sd, ccfg, dev, "bf16x3")
-    data = {k: d[k] for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db")}
+    # (expanded ON the device: stride-0 views of one resident block, what bench.py's config-3 leg passes; `.to(dev)` of a host-side expand
+    #  above materialised 32 copies, which the plain run treats as 32 objects)
+    data = {k: frames[0][k].to(dev).expand(B, *frames[0][k].shape[1:]) for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db")}
     mc.forward_features(data, d["feat_c"], d["feat_f"], batch["image_hw"])
     assert mc._obj_cache["y3d0"].shape[0] == 1
     for k, v in keep.items():
