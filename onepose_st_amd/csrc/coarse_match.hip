@@ -532,6 +532,230 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_frag_kerne
 }
 
 
+// ---- round 5: the same tile with THREE workgroups per CU ------------------------------------------------------------------------------
+// sim_frag_kernel holds 69.7 KB of LDS (four 16 KiB operand buffers, overlaid by the 67.6 KB staging image of the whole tile): two
+// workgroups per CU.  Its stamps (profiles/r02-r04) show a k-loop at the matrix pipe's rate and an epilogue of the same length that no
+// matrix work covers, and 2 090 tiles on 512 slots are 4.08 rounds that cost 5.  This form keeps the tile, the wave split and the
+// arithmetic and cuts the LDS to 51.3 KB -- THREE operand buffers (chunks two k-steps ahead instead of three) and a staging image of HALF
+// the tile (64 rows) that the two row halves pass through one after the other -- so that three workgroups share a CU (138 registers: the
+// register file allows it): a third wave per SIMD to run its k-loop under the other two's epilogues, and 768 slots (2.72 rounds that cost 3).
+//   MODE 0 / 1 as sim_frag_kernel (1: statistics only, the lazy form's first pass).  The fast pass accumulates row and column sums in the
+//   association of sim_frag_kernel (rows rg + 8 it in the same order, the same DPP and cross-wave sums), so its statistics are bit-identical;
+//   the exact pass (edge tiles, tiles with a row or column > 59 below the tile maximum) merges a column's two halves as (max, sum) partials.
+constexpr int F3_BUFS = 3;
+constexpr int F3_HALF = TM / 2;                                          // rows per staging pass
+constexpr size_t SIM_F3_STAGE = (size_t)F3_HALF * FLD * sizeof(float);   // 33 792
+constexpr size_t SIM_F3_LDS = (size_t)F3_BUFS * FRAG_CHUNK_BYTES + 4 * 128 * sizeof(float) + 64;      // 51 264
+static_assert(SIM_F3_STAGE <= (size_t)F3_BUFS * FRAG_CHUNK_BYTES, "the half-tile staging image overlays the operand buffers");
+
+template <int NS, int MODE>
+__global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(3, 3) void sim_frag3_kernel(SimFragArgs p) {
+    static_assert(MODE == 0 || MODE == 1, "the candidate pass of the lazy form stays on sim_frag_kernel<NS, 2>");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int ti, tj;
+    if (!xcd_tile(p.ntr, p.ntc, ti, tj)) return;
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
+    const int i0 = ti * TM, j0 = tj * TN;
+    const int nta = 4 * p.ntr, ntb = 4 * p.ntc;
+    const char* ga = p.a + ((size_t)b * nta + 4 * ti + wave) * 32768 + 16 * lane;
+    const char* gb = p.b + ((size_t)b * ntb + 4 * tj + wave) * 32768 + 16 * lane;
+    auto issue = [&](int s, int buf) {
+        char* la = smem + buf * FRAG_CHUNK_BYTES + wave * 2048;
+        char* lb = la + 8192;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            if (NS == 1 && f) continue;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + (size_t)(2 * s + f) * 1024),
+                                             (__attribute__((address_space(3))) void*)(la + f * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + (size_t)(2 * s + f) * 1024),
+                                             (__attribute__((address_space(3))) void*)(lb + f * 1024), 16, 0, 0);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = zero16();
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    OPHIP_STAMP(p.stamps, wg, 0);
+    constexpr int NKS = C / 16, G = NS == 3 ? 4 : 2;
+    issue(0, 0);
+    issue(1, 1);
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+        // chunk s has landed for this wave (chunk s + 1 may stay in flight), then for all waves; every wave is done reading buffer
+        // (s + 2) % 3 = chunk s - 1's.  One asm statement with a memory clobber (see sim_frag_kernel)
+        if (s + 1 < NKS) { if (G == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (s + 2 < NKS) issue(s + 2, (s + 2) % F3_BUFS);
+        const char* base = smem + (s % F3_BUFS) * FRAG_CHUNK_BYTES + 16 * lane;
+        bf16x8 fah[2], fal[2], fbh[2], fbl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const char* pa = base + (2 * wr + t) * 2048;
+            const char* pb = base + 8192 + (2 * wc + t) * 2048;
+            fah[t] = *reinterpret_cast<const bf16x8*>(pa);
+            fbh[t] = *reinterpret_cast<const bf16x8*>(pb);
+            fal[t] = (NS == 3) ? *reinterpret_cast<const bf16x8*>(pa + 1024) : zero_bf8();
+            fbl[t] = (NS == 3) ? *reinterpret_cast<const bf16x8*>(pb + 1024) : zero_bf8();
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) acc[x][y] = mma_bf16<NS>(fah[x], fal[x], fbh[y], fbl[y], acc[x][y]);
+    }
+    OPHIP_STAMP(p.stamps, wg, 1);
+
+    // ---- epilogue ---------------------------------------------------------------------------------------------------------
+    float* St = reinterpret_cast<float*>(smem);                        // [64][FLD]: one row half of the tile at a time
+    float* csw = reinterpret_cast<float*>(smem + F3_BUFS * FRAG_CHUNK_BYTES);      // [4 (wave)][128]
+    float* wmx = csw + 512;
+    int* slow = reinterpret_cast<int*>(wmx + 4);
+    const float inv_temp = 1.0f / p.temp;
+    const bool edge = (i0 + TM > p.N) || (j0 + TN > p.M);
+    float vmax = -INFINITY;
+    float pad[2] = {0.f, 0.f};
+    if (p.colmask) {
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int col = j0 + 64 * wc + 32 * y + r;
+            pad[y] = (col < p.M && !p.colmask[(size_t)b * p.M + col]) ? -1e9f : 0.f;
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float sv = acc[x][y][reg] * inv_temp + pad[y];      // (the scaled value stays in the accumulator: staged once or twice below)
+                acc[x][y][reg] = sv;
+                vmax = fmaxf(vmax, sv);
+            }
+    const float mw = wave_max_dpp(vmax);
+    if (lane == 0) { wmx[wave] = mw; slow[wave] = 0; }
+    __syncthreads();                                  // also: every wave is done reading the operand buffers that St overlays
+    OPHIP_STAMP(p.stamps, wg, 2);
+    const float m = fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3]));
+    const bool fast = !edge && (m - m == 0.f);
+    const int c4 = tid & 31, rg = tid >> 5;
+    auto stage_half = [&](int half) {                 // the two waves that hold rows 64 half .. 64 half + 63 write them into St
+        if (wr == half) {
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) St[(32 * x + acc_row(reg, h)) * FLD + 64 * wc + 32 * y + r] = acc[x][y][reg];
+        }
+    };
+    float colacc[4] = {0.f, 0.f, 0.f, 0.f};
+    float mine[2] = {1.f, 1.f};
+    float* conf = (MODE == 0) ? p.conf + (size_t)b * p.N * p.M : nullptr;
+    const bool vec = (p.M & 3) == 0;
+    if (MODE == 0 || fast) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            stage_half(half);
+            __syncthreads();
+#pragma unroll 4
+            for (int it = 0; it < 8; ++it) {
+                const int row = rg + 8 * it;
+                const int gi = i0 + F3_HALF * half + row, gj = j0 + 4 * c4;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(St + row * FLD + 4 * c4);
+                if (MODE == 0 && gi < p.N && gj < p.M) {
+                    if (vec) {
+                        *reinterpret_cast<f32x4*>(conf + (size_t)gi * p.M + gj) = v;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (gj + e < p.M) conf[(size_t)gi * p.M + gj + e] = v[e];
+                    }
+                }
+                if (fast) {
+                    const float e0 = __expf(v[0] - m), e1 = __expf(v[1] - m), e2 = __expf(v[2] - m), e3 = __expf(v[3] - m);
+                    colacc[0] += e0; colacc[1] += e1; colacc[2] += e2; colacc[3] += e3;
+                    const float rs = half_sum_dpp((e0 + e1) + (e2 + e3));
+                    mine[half] = (c4 == it) ? rs : mine[half];            // lane c4 < 8 keeps the sum of row 64 half + rg + 8 c4
+                }
+            }
+            __syncthreads();                          // the image is rewritten by the other half (or by the exact pass)
+        }
+    }
+    OPHIP_STAMP(p.stamps, wg, 3);
+    constexpr float TINY = 1e-26f;
+    if (fast) {
+        const f32x4 cs = {swap32_sum(colacc[0]), swap32_sum(colacc[1]), swap32_sum(colacc[2]), swap32_sum(colacc[3])};
+        if (lane < 32) *reinterpret_cast<f32x4*>(csw + wave * 128 + 4 * c4) = cs;
+        if (!__all(mine[0] >= TINY && mine[1] >= TINY) && lane == 0) slow[wave] = 1;
+    }
+    __syncthreads();
+    float ctot = 1.f;
+    if (fast && tid < 128) {
+        ctot = (csw[tid] + csw[128 + tid]) + (csw[256 + tid] + csw[384 + tid]);
+        if (!(ctot >= TINY)) slow[0] = 1;
+    }
+    __syncthreads();
+    if (fast && (slow[0] | slow[1] | slow[2] | slow[3]) == 0) {
+        if (c4 < 8) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                float* o = p.rowpart + (((size_t)b * p.ntc + tj) * p.N + i0 + F3_HALF * half + rg + 8 * c4) * 2;
+                o[0] = m; o[1] = mine[half];
+            }
+        }
+        if (tid < 128) {
+            float* o = p.colpart + (((size_t)b * p.ntr + ti) * p.M + j0 + tid) * 2;
+            o[0] = m; o[1] = ctot;
+        }
+    } else {
+        // exact pass, half by half: rows as in tile_stats_lds (two lanes per row, even / odd columns, true row maximum); a column's two
+        // halves are (max, sum) partials of their own, merged in row order
+        const int idx = tid >> 1, par = tid & 1;
+        float cm = -INFINITY, ce = 0.f;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            stage_half(half);
+            __syncthreads();
+            if (tid < 2 * F3_HALF) {                  // 64 rows x 2 lanes
+                const int ncol = min(TN, p.M - j0);
+                float mr = -INFINITY, er = 0.f;
+                for (int q = 0; q < TN / 2; ++q) if (2 * q + par < ncol) mr = fmaxf(mr, St[idx * FLD + 2 * q + par]);
+                if (mr != -INFINITY)
+                    for (int q = 0; q < TN / 2; ++q) if (2 * q + par < ncol) er += __expf(St[idx * FLD + 2 * q + par] - mr);
+                const float m2 = __shfl_xor(mr, 1, 64), e2 = __shfl_xor(er, 1, 64);
+                float ma = par ? m2 : mr, ea = par ? e2 : er, mb = par ? mr : m2, eb = par ? er : e2;      // even lane's part first
+                merge_ms(ma, ea, mb, eb);
+                const int gi = i0 + F3_HALF * half + idx;
+                if (par == 0 && gi < p.N) {
+                    float* o = p.rowpart + (((size_t)b * p.ntc + tj) * p.N + gi) * 2;
+                    o[0] = ma; o[1] = ea;
+                }
+            }
+            {                                         // 128 columns x 2 lanes: rows par, par + 2, ... of this half
+                const int nrow = min(F3_HALF, p.N - i0 - F3_HALF * half);
+                float mc = -INFINITY, ec = 0.f;
+                for (int q = 0; q < F3_HALF / 2; ++q) if (2 * q + par < nrow) mc = fmaxf(mc, St[(2 * q + par) * FLD + idx]);
+                if (mc != -INFINITY)
+                    for (int q = 0; q < F3_HALF / 2; ++q) if (2 * q + par < nrow) ec += __expf(St[(2 * q + par) * FLD + idx] - mc);
+                merge_ms(cm, ce, mc, ec);
+            }
+            __syncthreads();
+        }
+        const float m2 = __shfl_xor(cm, 1, 64), e2 = __shfl_xor(ce, 1, 64);
+        float ma = par ? m2 : cm, ea = par ? e2 : ce, mb = par ? cm : m2, eb = par ? ce : e2;
+        merge_ms(ma, ea, mb, eb);
+        if (par == 0 && j0 + idx < p.M) {
+            float* o = p.colpart + (((size_t)b * p.ntr + ti) * p.M + j0 + idx) * 2;
+            o[0] = ma; o[1] = ea;
+        }
+    }
+    OPHIP_STAMP(p.stamps, wg, 4);
+}
+
+
 struct CombineArgs {
     const float *rowpart, *colpart;
     float *rowstat, *colstat;     // [B][N][2], [B][M][2]
@@ -999,9 +1223,19 @@ int coarse_impl(int parts, int border_mode, int wi, double temp_eps,
             if (int rc = ophip_lds_attr(reinterpret_cast<const void*>(sim_frag_kernel<NS_, MODE_>), SIM_FRAG_LDS, "hipFuncSetAttribute(sim_frag)")) return rc; \
             OPHIP_LAUNCH(NAME_, stream, (sim_frag_kernel<NS_, MODE_>), dim3(8 * per_xcd, B), dim3(256), SIM_FRAG_LDS, stream, sf);    \
         }
+        // OPHIP_SIM_TILE=2: round 2-4's kernel (two workgroups per CU, four operand buffers); default 3: three per CU (sim_frag3_kernel)
+        static const bool tile3 = [] { const char* e = getenv("OPHIP_SIM_TILE"); return !(e && e[0] == '2'); }();
+#define OPHIP_SIM3_CASE(NS_, MODE_)                                                                                                \
+        {                                                                                                                          \
+            if (int rc = ophip_lds_attr(reinterpret_cast<const void*>(sim_frag3_kernel<NS_, MODE_>), SIM_F3_LDS, "hipFuncSetAttribute(sim_frag3)")) return rc; \
+            OPHIP_LAUNCH("sim_stats", stream, (sim_frag3_kernel<NS_, MODE_>), dim3(8 * per_xcd, B), dim3(256), SIM_F3_LDS, stream, sf);  \
+        }
         if (!do_sim) {}
+        else if (tile3 && lazy) { if (nsplit == 3) OPHIP_SIM3_CASE(3, 1) else OPHIP_SIM3_CASE(1, 1) }
+        else if (tile3) { if (nsplit == 3) OPHIP_SIM3_CASE(3, 0) else OPHIP_SIM3_CASE(1, 0) }
         else if (lazy) { if (nsplit == 3) OPHIP_SIM_CASE(3, 1, "sim_stats") else OPHIP_SIM_CASE(1, 1, "sim_stats") }
         else { if (nsplit == 3) OPHIP_SIM_CASE(3, 0, "sim_stats") else OPHIP_SIM_CASE(1, 0, "sim_stats") }
+#undef OPHIP_SIM3_CASE
         OPHIP_CHECK_LAUNCH();
     } else if (do_sim) {
         SimArgs sa{feat3d, feat2d, conf, rowpart, colpart, N, M, ntr, ntc, (float)(temperature + temp_eps), ophip_stamp_buffer(), qmask};

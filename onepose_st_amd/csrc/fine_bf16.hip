@@ -153,10 +153,12 @@ __device__ __forceinline__ float corr_partial(const f32x16& x, int lane) {
     float p0 = 0.f, p1 = 0.f;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-        const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[reg]), TOK3D));
-        const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[reg]), 32 + TOK3D));
-        p0 = __builtin_fmaf(x[reg], a0, p0);
-        p1 = __builtin_fmaf(x[reg], a1, p1);
+        const float xv = x[reg];                     // (a bit_cast applied to a vector ELEMENT reads element 0 on hipcc 7.2: copy first, as in tile_x3.h)
+        const int xi = __builtin_bit_cast(int, xv);
+        const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, TOK3D));
+        const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 32 + TOK3D));
+        p0 = __builtin_fmaf(xv, a0, p0);
+        p1 = __builtin_fmaf(xv, a1, p1);
     }
     return swap32_sum((lane >> 5) ? p1 : p0);
 }

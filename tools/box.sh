@@ -14,6 +14,7 @@
 #   ab:<rounds>:<steps>:<variant>[:<variant>...]   interleaved A/B of bench.py (main region only); a variant is "-" (shipped build) or a
 #                    comma-separated list of NAME=VALUE environment assignments (OPHIP_LIB=onepose_st_amd/lib/variants/lib....so picks a variant build)
 #   py:<script>[:<arg>...]   python3 <script> <args> > <out>/<script name>.txt   (tools/micro drivers, one-off timings)
+#   epy:<NAME=VALUE[,NAME=VALUE...]>:<script>[:<arg>...]   the same with environment assignments (kernel variants behind an environment switch)
 set -o pipefail
 cd ${GRAFT_REPO_ROOT:-$(dirname $0)/..}
 export TMPDIR=/tmp
@@ -100,6 +101,11 @@ for step in "$@"; do
       n=$(basename ${A[0]} .py)
       timeout -k 10 400 python3 "${A[@]}" > $O/$n.txt 2>&1 || { tail -8 $O/$n.txt; exit 1; }
       tail -40 $O/$n.txt ;;
+    epy:*)
+      IFS=: read -r -a A <<< "${step#epy:}"
+      e="${A[0]//,/ }"; n=$(basename ${A[1]} .py)_$(echo "${A[0]}" | tr -c 'A-Za-z0-9\n' '_')
+      env $e timeout -k 10 400 python3 "${A[@]:1}" > $O/$n.txt 2>&1 || { tail -8 $O/$n.txt; exit 1; }
+      echo "[${A[0]}]"; tail -20 $O/$n.txt ;;
     *) echo "unknown step $step"; exit 2 ;;
   esac
 done
