@@ -539,15 +539,21 @@ def main():
               + f"; wall {1e6 * dt / args.steps:.0f}; after the last frame left the GPU {1e6 * host_t.get('tail', 0.0):.0f} us in all", file=sys.stderr)
     launches, kern_ms = hip.timing_read()
     hip.timing_select("")
-    sim_launches, sim_ms = 0, 0.0
+    stage_kernels = {}
     if args.roofline_kernel == "conf":
-        # the N x M STAGE (similarity tiles + dual softmax): a second region of the same K steps with the tile kernel's launches
-        # bracketed, so that the line can divide the stage's algorithmic bytes by BOTH kernels' time (`stage_frac`)
-        hip.timing_select("sim_stats", every=1)
-        timed_region(pools.get(args.pnp_policy))
-        sim_launches, sim_ms = hip.timing_read()
-        hip.timing_select("")
-
+        # the N x M STAGE (similarity tiles + dual softmax): further regions of the same K steps, each with one of the stage's
+        # kernels bracketed, so that the line can divide the stage's algorithmic bytes by the time of ALL its N x M kernels (`stage_frac`).
+        # One-pass form: sim_stats (tiles, S stored) + conf (in-place conversion); two-pass form (ophip_coarse_two_pass: large N x M):
+        # sim_stats (statistics only) + sim_conf (tiles again, every confidence written once) and no conf launch.
+        if launches:
+            stage_kernels["conf"] = kern_ms / launches
+        for nm in ("sim_stats", "sim_conf", "stat_combine"):
+            hip.timing_select(nm, every=1)
+            timed_region(pools.get(args.pnp_policy))
+            n_, ms_ = hip.timing_read()
+            hip.timing_select("")
+            if n_:
+                stage_kernels[nm] = ms_ / n_
     # The same kernel with the chip to itself: eight frames one at a time (enqueue, flush the kept-back fine stage, finish, synchronize), every
     # launch bracketed.  Since the end of round 4 the pipeline lets the encoder's first layer start beside the previous frame's last fine
     # workgroups and the next frame's input kernels run beside the last layers (both raise frames/s and lengthen the launches they
@@ -744,8 +750,15 @@ def main():
         # printed beside it: the similarity kernel's store of S is the pass the fused design would not need.
         kbytes = 2.0 * 4.0 * B * n_points * M
         gbs = kbytes / (avg_ms * 1e-3) / 1e9 if launches else 0.0
+        kname = "conf_kernel<true, true> (dual-softmax product in log form + candidate tracking: reads S, writes conf_matrix)"
+        if not launches and "sim_conf" in stage_kernels:
+            # two-pass form: no conf_kernel; the kernel that writes the matrix is the second tile pass (operand fragments in, ONE f32 write out)
+            kbytes = float(B) * ((n_points + M) * 256 * 2 * 2 + 4.0 * n_points * M)
+            avg_ms = stage_kernels["sim_conf"]
+            gbs = kbytes / (avg_ms * 1e-3) / 1e9
+            kname = "sim_frag_kernel<3, 3> (second tile pass of the two-pass form: recomputes S on the matrix pipe, writes every confidence once)"
         result["roofline"] = {
-            "kernel": "conf_kernel<true, true> (dual-softmax product in log form + candidate tracking: reads S, writes conf_matrix)",
+            "kernel": kname,
             "bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
             "frac_of_measured_copy_rate": gbs / 6290.0,          # MI355X_MICROARCH.md: 6.29 TB/s float4 copy
             "traffic": None, "bytes_per_launch": kbytes,
@@ -753,9 +766,12 @@ def main():
             # the honest figure for the stage: SURVEY 8d's algorithmic bytes (inputs once + ONE f32 write of the matrix) over the time of
             # BOTH N x M kernels (similarity tiles + confidence pass), against 8 TB/s; `frac` above divides the confidence kernel's OWN
             # bytes (S read + conf write = 2 x the algorithmic write) by its own time
-            "sim_tiles_avg_launch_ms": (sim_ms / sim_launches) if sim_launches else None,
-            "stage_frac": ((float(B) * ((n_points + M) * 256 * 2 + 4.0 * n_points * M)) / ((avg_ms + sim_ms / sim_launches) * 1e-3) / 1e9 / 8000.0)
-                          if (launches and sim_launches) else None,
+            "stage_kernels_avg_launch_ms": stage_kernels,
+            "stage_form": ("two passes over the tiles (statistics, then every confidence written once; no S store)" if "sim_conf" in stage_kernels
+                           else "one tile pass that stores S + in-place conversion pass"),
+            "stage_ms": sum(stage_kernels.values()) if stage_kernels else None,
+            "stage_frac": ((float(B) * ((n_points + M) * 256 * 2 + 4.0 * n_points * M)) / (sum(stage_kernels.values()) * 1e-3) / 1e9 / 8000.0)
+                          if stage_kernels else None,
             "launches": launches, "launches_sampled_every": time_every, "avg_launch_ms": avg_ms, "library_build_stamp": hip.build_stamp(),
         }
 

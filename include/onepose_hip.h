@@ -300,7 +300,9 @@ int ophip_frame_order_after_fine(void* compute_stream);
  * (ophip_frame_enqueue_object) runs layer 0 on the 2D stream alone and layer 1 with the cached rows / block; it is BIT-IDENTICAL to a
  * frame without the cache (a workgroup's arithmetic does not depend on the others of its launch; the K^T V sum adds a stream's slabs in
  * the same fixed order).  Needs n_coarse >= 2 and a first layer of kind "self" for y3d0 / kv1 (else pass them NULL: depth 1).
- * workspace of ophip_encoder_object_x3w8: ophip_encoder_x3w8_workspace_bytes(Bo, N, 1) bytes of scratch.
+ * workspace of ophip_encoder_object_x3w8: ophip_encoder_x3w8_workspace_bytes(Bo, N, 1) bytes of scratch.  masked_frames: 1 = build the
+ * entry for frames that carry a query_mask (they run both streams through the masked instantiation of the layer kernel, whose rounding
+ * need not equal the plain one's: an entry built the same way keeps the bit-identity); a caller with both kinds of frames keeps two entries.
  * ready: a hipEvent_t recorded behind the kernels that wrote the buffers, or NULL when they are complete; ophip_frame_enqueue_object makes
  * s_main AND s_prep wait for it before their first read (the first layer's K / V half runs on s_prep). */
 typedef struct ophip_object_cache {
@@ -311,7 +313,7 @@ typedef struct ophip_object_cache {
 } ophip_object_cache;
 size_t ophip_encoder_x3w8_kv_block_bytes(void);
 int ophip_encoder_object_x3w8(const float* x3d, int Bo, int N, const void* wpack0, const void* wpack1, void* workspace,
-                              float* y3d0, void* kv1, void* stream);
+                              float* y3d0, void* kv1, int masked_frames, void* stream);
 /* ophip_frame_enqueue_padded with the object's cache in place of x3d_external (the layout must have been made with external_x3d = 2
  * when y3d0 / kv1 are given, 1 otherwise); query_mask / query_scale may be NULL. */
 int ophip_frame_enqueue_object(const ophip_frame_desc* desc, const ophip_frame_layout_t* layout, void* block,

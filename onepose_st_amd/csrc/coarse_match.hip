@@ -16,6 +16,7 @@
 //                 empty), mutual test, first-true-j semantics on exact ties, compaction in ascending (b, i)
 #include "tile_bf16.h"
 #include "onepose_hip.h"
+#include "x3w8_internal.h"
 #include <math.h>
 #include <stdlib.h>
 
@@ -304,6 +305,8 @@ constexpr size_t SIM_FRAG_LDS = SIM_FRAG_STAGE + 4 * 128 * sizeof(float) + 64;
 
 // MODE 0: the scaled S tile goes to the conf buffer and into the (max, sum exp) partials (the eager form: conf_kernel follows);
 // MODE 1: partials only, nothing stored (first pass of the lazy form: conf_matrix is not materialised);
+// MODE 3: MODE 2 that ALSO stores every confidence: the second pass of the eager form's two-pass variant (large N x M: S is never written
+//         and re-read, conf_matrix is written once -- SURVEY 8d's algorithmic traffic; coarse_impl's `two_pass`);
 // MODE 2: second pass of the lazy form: the tile is recomputed, turned into confidences with the merged statistics -- the very
 //         expression of conf_kernel, so every value is bit-identical to the eager form's -- and only what the selection consumes
 //         leaves the chip: per (row, column tile) the best candidate above the threshold (value, lowest j, tie count) and the
@@ -400,7 +403,7 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_frag_kerne
                 St[(64 * wr + 32 * x + acc_row(reg, h)) * FLD + 64 * wc + 32 * y + r] = sv;
                 vmax = fmaxf(vmax, sv);
             }
-    if (MODE == 2) {
+    if (MODE >= 2) {
         unsigned long long* bestk = reinterpret_cast<unsigned long long*>(smem + SIM_FRAG_STAGE);     // [128] (value bits << 32) | ~j : max = best value, lowest j
         int* tiecnt = reinterpret_cast<int*>(bestk + 128);                                             // [128]
         if (tid < 128) { bestk[tid] = 0ull; tiecnt[tid] = 0; }
@@ -411,6 +414,8 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_frag_kerne
         const float* clg = p.collog + (size_t)b * p.M;
         const float* rlg = p.rowlog + (size_t)b * p.N;
         unsigned* cb = p.colmax_bits + (size_t)b * p.M;
+        float* confb = (MODE == 3) ? p.conf + (size_t)b * p.N * p.M : nullptr;
+        const bool vec = (p.M & 3) == 0;
         float cmv[4], clv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -426,13 +431,15 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_frag_kerne
                 if (gi >= p.N) continue;
                 const float rm = rst[2 * gi], rl = rlg[gi];
                 const f32x4 v = *reinterpret_cast<const f32x4*>(St + row * FLD + 4 * c4);
+                f32x4 cv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int gj = j0 + 4 * c4 + e;
                     const float t = ((v[e] - cmv[e]) - clv[e]) + ((v[e] - rm) - rl);
-                    if (t > p.logthr_lo && gj < p.M) {
+                    if ((MODE == 3 && !count_ties) || (t > p.logthr_lo && gj < p.M)) {
                         const float c = __expf(t);
-                        if (c > p.thr) {
+                        cv[e] = c;
+                        if (c > p.thr && gj < p.M) {
                             any = true;
                             const unsigned long long key = ((unsigned long long)__float_as_uint(c) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)gj);
                             if (!count_ties) {
@@ -442,6 +449,16 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_frag_kerne
                                 atomicAdd(tiecnt + row, 1);
                             }
                         }
+                    }
+                }
+                if (MODE == 3 && !count_ties) {
+                    const int gj = j0 + 4 * c4;
+                    if (vec) {
+                        if (gj < p.M) __builtin_nontemporal_store(cv, reinterpret_cast<f32x4*>(confb + (size_t)gi * p.M + gj));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (gj + e < p.M) confb[(size_t)gi * p.M + gj + e] = cv[e];
                     }
                 }
             }
@@ -1154,6 +1171,20 @@ CoarseWs coarse_ws(int B, int N, int M) {
 
 extern "C" size_t ophip_coarse_workspace_floats(int B, int N, int M) { return coarse_ws(B, N, M).total; }
 
+// Which form the eager confidence matrix takes in the bf16 modes (internal; csrc/frame.hip orders its streams by it):
+//   one pass  (default at c2): similarity tiles store S, conf_kernel turns it into confidences in place -- S written, read and rewritten
+//             (3 N x M passes over HBM), but the read-modify-write pass needs no matrix pipe and runs beside the previous frame's fine stage;
+//   two passes: statistics tiles, then tiles again that write every confidence once (1 N x M pass, 2 x the tile arithmetic).
+// OPHIP_COARSE_TWO_PASS = 0 / 1 forces one form; default: two passes from `OPHIP_COARSE_TWO_PASS_MIN` (default 2^27 = 134 M) matrix elements
+// per frame on -- BASELINE config 4 (15 000 x 19 200 = 288 M) yes, config 2 (33.6 M) no; see DESIGN.md for the measurement behind it.
+bool ophip_coarse_two_pass(int B, int N, int M) {
+    (void)B;
+    static const int forced = [] { const char* e = getenv("OPHIP_COARSE_TWO_PASS"); return e && e[0] ? atoi(e) : -1; }();
+    static const long long min_elems = [] { const char* e = getenv("OPHIP_COARSE_TWO_PASS_MIN"); return e && e[0] ? atoll(e) : (1LL << 27); }();
+    if (forced >= 0) return forced != 0;
+    return (long long)N * M >= min_elems;
+}
+
 namespace {
 // where the fragment planes of the bf16 modes live inside the workspace (behind the partials; 64-byte aligned)
 void frag_plane_ptrs(float* workspace, int B, int N, int M, char** a, char** b) {
@@ -1204,7 +1235,10 @@ int coarse_impl(int parts, int border_mode, int wi, double temp_eps,
     float* collog = workspace + ws.collog;
 
     // bf16 modes: fragment planes + LDS-DMA tile kernel; exact-f32 mode: the f32-MFMA tile kernel (true maxima, libm)
-    const int sel_nspan = lazy ? ntc : nspan;
+    // two_pass (eager form, bf16 modes): statistics pass without a store, then a second tile pass that writes every confidence ONCE
+    // (sim_frag_kernel<NS, 3>) -- no S store, no read-modify-write pass over the matrix (ophip_coarse_two_pass())
+    const bool two_pass = !lazy && nsplit != 0 && ophip_coarse_two_pass(B, N, M);
+    const int sel_nspan = (lazy || two_pass) ? ntc : nspan;
     SimFragArgs sf{};
     const int per_xcd = ((ntr + 7) / 8) * ntc;
     const bool do_sim = (parts & 5) != 0, do_conf = (parts & 9) != 0;
@@ -1231,9 +1265,9 @@ int coarse_impl(int parts, int border_mode, int wi, double temp_eps,
             OPHIP_LAUNCH("sim_stats", stream, (sim_frag3_kernel<NS_, MODE_>), dim3(8 * per_xcd, B), dim3(256), SIM_F3_LDS, stream, sf);  \
         }
         if (!do_sim) {}
-        else if (tile3 && lazy) { if (nsplit == 3) OPHIP_SIM3_CASE(3, 1) else OPHIP_SIM3_CASE(1, 1) }
+        else if (tile3 && (lazy || two_pass)) { if (nsplit == 3) OPHIP_SIM3_CASE(3, 1) else OPHIP_SIM3_CASE(1, 1) }
         else if (tile3) { if (nsplit == 3) OPHIP_SIM3_CASE(3, 0) else OPHIP_SIM3_CASE(1, 0) }
-        else if (lazy) { if (nsplit == 3) OPHIP_SIM_CASE(3, 1, "sim_stats") else OPHIP_SIM_CASE(1, 1, "sim_stats") }
+        else if (lazy || two_pass) { if (nsplit == 3) OPHIP_SIM_CASE(3, 1, "sim_stats") else OPHIP_SIM_CASE(1, 1, "sim_stats") }
         else { if (nsplit == 3) OPHIP_SIM_CASE(3, 0, "sim_stats") else OPHIP_SIM_CASE(1, 0, "sim_stats") }
 #undef OPHIP_SIM3_CASE
         OPHIP_CHECK_LAUNCH();
@@ -1247,7 +1281,8 @@ int coarse_impl(int parts, int border_mode, int wi, double temp_eps,
         OPHIP_CHECK_LAUNCH();
     }
     if (do_conf) {
-        CombineArgs ca{rowpart, colpart, rowstat, colstat, reinterpret_cast<unsigned*>(colmax), N, M, ntr, ntc, lazy ? rowlog : nullptr, lazy ? collog : nullptr, lazy ? count + 1 : nullptr};
+        const bool logs = lazy || two_pass;
+        CombineArgs ca{rowpart, colpart, rowstat, colstat, reinterpret_cast<unsigned*>(colmax), N, M, ntr, ntc, logs ? rowlog : nullptr, logs ? collog : nullptr, lazy ? count + 1 : nullptr};
         OPHIP_LAUNCH("stat_combine", stream, stat_combine_kernel, dim3((N + M + 31) / 32, B), dim3(256), 0, stream, ca);
         OPHIP_CHECK_LAUNCH();
     }
@@ -1256,8 +1291,13 @@ int coarse_impl(int parts, int border_mode, int wi, double temp_eps,
         if (nsplit == 3) OPHIP_SIM_CASE(3, 2, "sim_cand") else OPHIP_SIM_CASE(1, 2, "sim_cand")
         OPHIP_CHECK_LAUNCH();
     }
+    if (do_conf && two_pass) {
+        // the same second look, and every confidence is stored: conf_matrix written once, nothing read back
+        if (nsplit == 3) OPHIP_SIM_CASE(3, 3, "sim_conf") else OPHIP_SIM_CASE(1, 3, "sim_conf")
+        OPHIP_CHECK_LAUNCH();
+    }
 #undef OPHIP_SIM_CASE
-    if (do_conf && !lazy) {
+    if (do_conf && !lazy && !two_pass) {
         ConfArgs fa{conf, rowstat, colstat, rowbest, reinterpret_cast<unsigned*>(colmax), N, M, nspan, spanw, nrb, thr, conf_rows};
         const size_t clds = (size_t)14 * conf_rows * sizeof(float);
         const bool vec = M % 4 == 0, fast = nsplit != 0;

@@ -616,14 +616,19 @@ extern "C" int ophip_encoder_kv_first_x3w8(const float* x3d, const float* x2d, i
 //   the summed block of layer 1's 3D source; workspace: ophip_encoder_x3w8_workspace_bytes(Bo, N, 1) bytes (scratch).
 extern "C" size_t ophip_encoder_x3w8_kv_block_bytes(void) { return KV_BLOCK_BYTES; }
 
+//   masked_frames: 1 = the entry is for frames with a query mask (ophip_frame_enqueue_object with query_mask).  The mask touches the 2D
+//   stream only, but a masked frame runs BOTH streams through the masked instantiation of the kernels, which need not round like the plain
+//   one (different code, different contraction choices): the entry is then built with that instantiation too (the mask pointer it is given
+//   is never dereferenced for 3D workgroups), and stays bit-identical to the uncached masked frame.  Keep one entry per kind.
 extern "C" int ophip_encoder_object_x3w8(const float* x3d, int Bo, int N, const void* wpack0, const void* wpack1, void* workspace,
-                                         float* y3d0, void* kv1, void* stream) {
+                                         float* y3d0, void* kv1, int masked_frames, void* stream) {
     if (!x3d || !wpack0 || !wpack1 || !workspace || !y3d0 || !kv1) return ophip_bad_arg(__func__, "null pointer");
     if (reinterpret_cast<uintptr_t>(kv1) & 15) return ophip_bad_arg(__func__, "kv1 must be 16-byte aligned");
+    const unsigned char* mk = masked_frames ? reinterpret_cast<const unsigned char*>(x3d) : nullptr;      // selects the instantiation; never read (3D tiles only)
     X3Opts o;
     o.streams = 1;
     // layer 0 on the 3D stream alone: its own K / V (kv_reduce + kv_sum), then the layer; the tail leaves layer 1's slabs of these rows
-    if (int rc = layer_x3w8(x3d, nullptr, y3d0, nullptr, Bo, N, 1, wpack0, wpack1, 0, 0, 0, workspace, stream, nullptr, nullptr, nullptr, false, o)) return rc;
+    if (int rc = layer_x3w8(x3d, nullptr, y3d0, nullptr, Bo, N, 1, wpack0, wpack1, 0, 0, 0, workspace, stream, nullptr, nullptr, mk, false, o)) return rc;
     // their fixed-order sum = the 3D source's block of layer 1 (slot 1: where layer 0's tail wrote)
     X3Opts s;
     s.partial_streams = 1;

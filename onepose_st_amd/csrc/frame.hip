@@ -383,6 +383,9 @@ int frame_enqueue_impl(const ophip_frame_desc* d, const ophip_frame_layout_t* L,
     float* mk2d = F(L->result + 16 + 20 * (size_t)cap);
     unsigned char* gt_mask = reinterpret_cast<unsigned char*>(blob + L->gt_mask);
     const int nsplit_flags = qmask ? 3 : (3 | OPHIP_COARSE_PLANES_READY);
+    // (the eager form's two-pass variant -- large N x M, ophip_coarse_two_pass -- has a second matrix-bound tile pass like the lazy form:
+    //  both tile passes stay on the compute stream in front of the kept-back fine stage)
+    const bool tiles_twice = d->lazy_conf || ophip_coarse_two_pass(B, N, M);
     if (!defer)
     FR_CHECK(ophip_coarse_match_masked(x3, x2, kpts, kpts_bs, B, N, M, d->wc, d->temperature, d->thr, d->border_rm, d->scale_c, conf, cws,
                                        b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count,
@@ -399,7 +402,7 @@ int frame_enqueue_impl(const ophip_frame_desc* d, const ophip_frame_layout_t* L,
         // (Fine stage on the compute stream and the HBM-bound half on the side stream instead: the same within noise.)
         FR_CHECK(ophip_coarse_match_masked(x3, x2, kpts, kpts_bs, B, N, M, d->wc, d->temperature, d->thr, d->border_rm, d->scale_c, conf, cws,
                                            b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count,
-                                           nsplit_flags, d->lazy_conf ? 1 : 4, qmask, qscale, s_main));      // (lazy form: its candidate pass is a second matrix-bound tile pass)
+                                           nsplit_flags, tiles_twice ? 1 : 4, qmask, qscale, s_main));      // (lazy / two-pass form: the second tile pass is matrix-bound too)
         FR_HIP(hipEventRecord(slot->enc_done, s_main), "hipEventRecord(similarity)");
         // Which of the two halves that follow the similarity tiles stays on the compute stream (OPHIP_FRAME_FINE_ON_MAIN, default 0):
         //   0: this frame's HBM-bound half (statistics merge, conf, selection) does; the previous frame's fine stage runs on the side stream.
@@ -407,12 +410,12 @@ int frame_enqueue_impl(const ophip_frame_desc* d, const ophip_frame_layout_t* L,
         //      cross-stream event) and the HBM-bound half goes to the side stream.  Measured in round 3 (equal) and again in round 4 with
         //      the two-kernel selection: 1 362 against 1 391 frames/s, three interleaved 100-step runs each -- the side stream's kernels
         //      start 10-17 us later behind THEIR cross-stream edge and the fine stage, first in its queue, takes the chip before them.
-        const bool fine_on_main = fine_on_main_enabled() && !d->lazy_conf;
+        const bool fine_on_main = fine_on_main_enabled() && !tiles_twice;
         const hipStream_t s_tail = fine_on_main ? s_fine : s_main;          // where this frame's merge / conf / selection run
         if (fine_on_main) FR_HIP(hipStreamWaitEvent(s_tail, slot->enc_done, 0), "hipStreamWaitEvent(similarity)");
         FR_CHECK(ophip_coarse_match_masked(x3, x2, kpts, kpts_bs, B, N, M, d->wc, d->temperature, d->thr, d->border_rm, d->scale_c, conf, cws,
                                            b_ids, I64(L->i_ids), I64(L->j_ids), F(L->mconf), mk3d, F(L->mkc), I64(L->m_bids), gt_mask, count,
-                                           nsplit_flags, d->lazy_conf ? 2 : (8 | 2), qmask, qscale, s_tail));
+                                           nsplit_flags, tiles_twice ? 2 : (8 | 2), qmask, qscale, s_tail));
         FR_HIP(hipEventRecord(slot->coarse_done, s_tail), "hipEventRecord(coarse)");
         // the kept-back fine stage of the previous frame, behind this frame's similarity tiles and beside the rest.  Submitted AFTER this
         // frame's confidence pass and selection, so that those are in their hardware queue first (HIP maps streams onto a few hardware

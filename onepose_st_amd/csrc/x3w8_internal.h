@@ -16,3 +16,7 @@ int ophip_x3w8_object_second(const float* y3d0, long long y3d0_bs, const float* 
 int ophip_x3w8_layer_bs(const float* x3d, long long x3d_bs, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
                         const void* wpack, const void* wpack_next, int is_cross, int kv_mode, int slot,
                         void* workspace, void* frag3d, void* frag2d, const unsigned char* mask2d, bool only_kv, void* stream);
+
+// coarse matching, eager form in the bf16 modes: true = statistics pass + a second tile pass that writes every confidence once
+// (csrc/coarse_match.hip ophip_coarse_two_pass: by matrix size / OPHIP_COARSE_TWO_PASS); false = similarity store + in-place conversion pass
+bool ophip_coarse_two_pass(int B, int N, int M);

@@ -71,7 +71,7 @@ _SIGNATURES = {
                                          ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                          ctypes.POINTER(c_i)]),
     "ophip_encoder_x3w8_kv_block_bytes": (ctypes.c_size_t, []),
-    "ophip_encoder_object_x3w8": (c_i, [c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_f, ctypes.c_void_p]),
+    "ophip_encoder_object_x3w8": (c_i, [c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_i, ctypes.c_void_p]),
     "ophip_frame_wait": (c_i, [c_i]),
     "ophip_frame_order_after_fine": (c_i, [ctypes.c_void_p]),
     "ophip_pe_add_transpose": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_void_p]),

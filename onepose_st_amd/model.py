@@ -390,7 +390,7 @@ class OnePosePlus_model(nn.Module):
                 # (rows a2 + a3) and, with a first layer of kind "self", that layer's 3D rows and the K^T V | Ksum block of those rows as the
                 # second layer's source (transformer.py:148-159; ophip_encoder_object_x3w8: the frame's own launches on the 3D stream's
                 # workgroups, so a cached frame is bit-identical).  One entry serves the whole batch when it shares one object (config 3).
-                x3d_ext = self._object_cache_entry(kpts_d, desc_in_d, W, dev, B, N, main)
+                x3d_ext = self._object_cache_entry(kpts_d, desc_in_d, W, dev, B, N, main, masked=qmask is not None)
             return self._enqueue_frame_call(data, feat_c, feat_f, kpts_d, desc_in_d, desc_fine_d, x3d_ext, W, dev, main, fkey,
                                             B, N, M, hc, wc, hf, wf, host_copy, inputs_ready, lazy, rerun, qmask, qscale)
         if fkey in self._frame_call_pending:                          # order this frame's encoder behind the C path's last fine stage
@@ -592,7 +592,7 @@ class OnePosePlus_model(nn.Module):
         return pend
 
 
-    def _object_cache_entry(self, kpts_d, desc_in_d, W, dev, B, N, stream):
+    def _object_cache_entry(self, kpts_d, desc_in_d, W, dev, B, N, stream, masked=False):
         """The object's cache entry ``{"x3d", "y3d0", "kv1", "ev"}`` (``ophip_object_cache``), built on a miss on ``stream`` with the kernels a
         frame would run.  Keyed on the object tensors' storage + version and the packed weights; ``Bo`` = 1 rows when the batch shares one
         object block (stride-0 expand / batch-1 tensors under a larger query batch), else B."""
@@ -602,7 +602,9 @@ class OnePosePlus_model(nn.Module):
         names = self.loftr_coarse.layer_names
         deep = (self.precision == "bf16x3" and len(names) >= 2 and names[0] == "self"
                 and os.environ.get("OPHIP_OBJECT_CACHE_DEPTH", "2") != "1")
-        ckey = (str(dev), Bo, N, kpts_d.data_ptr(), kpts_d._version, desc_in_d.data_ptr(), desc_in_d._version, id(W), deep)
+        # (masked: frames with a query_image_mask run both streams through the masked instantiation of the layer kernel; their entry is built
+        #  with that instantiation, see ophip_encoder_object_x3w8)
+        ckey = (str(dev), Bo, N, kpts_d.data_ptr(), kpts_d._version, desc_in_d.data_ptr(), desc_in_d._version, id(W), deep, bool(masked) and deep)
         ent = self._obj_cache
         if ent is not None and ent["key"] == ckey:
             return ent
@@ -623,7 +625,7 @@ class OnePosePlus_model(nn.Module):
                 kv1 = torch.empty(Bo, lib.ophip_encoder_x3w8_kv_block_bytes(), device=dev, dtype=torch.uint8)
                 ws = torch.empty(lib.ophip_encoder_x3w8_workspace_bytes(Bo, N, 1), device=dev, dtype=torch.uint8)
                 lib_call("ophip_encoder_object_x3w8", P(x3d), Bo, N, P(W["coarse_x3"][0], None), P(W["coarse_x3"][1], None), P(ws, None),
-                         P(y3d0), P(kv1, None), hip.stream_handle())
+                         P(y3d0), P(kv1, None), 1 if masked else 0, hip.stream_handle())
             ev = torch.cuda.Event()
             ev.record(stream)
         self._obj_cache = ent = {"key": ckey, "x3d": x3d, "y3d0": y3d0, "kv1": kv1, "ev": ev, "keep": (kpts_d, desc_in_d, W)}      # the key's tensors stay alive with the entry
