@@ -736,12 +736,30 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(3, 3) void sim_frag3_kern
         for (int half = 0; half < 2; ++half) {
             stage_half(half);
             __syncthreads();
+            // (sixteen independent LDS reads at a time into registers, then their maximum resp. their exponentials: the loops are
+            //  latency-bound, and the edge tiles of the last column band are the LAST tiles an XCD walks -- a slow exact pass is the kernel's tail)
             if (tid < 2 * F3_HALF) {                  // 64 rows x 2 lanes
                 const int ncol = min(TN, p.M - j0);
+                const float* rowp = St + idx * FLD + par;
                 float mr = -INFINITY, er = 0.f;
-                for (int q = 0; q < TN / 2; ++q) if (2 * q + par < ncol) mr = fmaxf(mr, St[idx * FLD + 2 * q + par]);
-                if (mr != -INFINITY)
-                    for (int q = 0; q < TN / 2; ++q) if (2 * q + par < ncol) er += __expf(St[idx * FLD + 2 * q + par] - mr);
+#pragma unroll 1
+                for (int q0 = 0; q0 < TN / 2; q0 += 16) {
+                    float v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = (2 * (q0 + u) + par < ncol) ? rowp[2 * (q0 + u)] : -INFINITY;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) mr = fmaxf(mr, v[u]);
+                }
+                if (mr != -INFINITY) {
+#pragma unroll 1
+                    for (int q0 = 0; q0 < TN / 2; q0 += 16) {
+                        float v[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) v[u] = (2 * (q0 + u) + par < ncol) ? rowp[2 * (q0 + u)] : -INFINITY;
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) er += __expf(v[u] - mr);          // exp(-inf) = 0 for the masked tail
+                    }
+                }
                 const float m2 = __shfl_xor(mr, 1, 64), e2 = __shfl_xor(er, 1, 64);
                 float ma = par ? m2 : mr, ea = par ? e2 : er, mb = par ? mr : m2, eb = par ? er : e2;      // even lane's part first
                 merge_ms(ma, ea, mb, eb);
@@ -753,10 +771,26 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(3, 3) void sim_frag3_kern
             }
             {                                         // 128 columns x 2 lanes: rows par, par + 2, ... of this half
                 const int nrow = min(F3_HALF, p.N - i0 - F3_HALF * half);
+                const float* colp = St + par * FLD + idx;
                 float mc = -INFINITY, ec = 0.f;
-                for (int q = 0; q < F3_HALF / 2; ++q) if (2 * q + par < nrow) mc = fmaxf(mc, St[(2 * q + par) * FLD + idx]);
-                if (mc != -INFINITY)
-                    for (int q = 0; q < F3_HALF / 2; ++q) if (2 * q + par < nrow) ec += __expf(St[(2 * q + par) * FLD + idx] - mc);
+#pragma unroll 1
+                for (int q0 = 0; q0 < F3_HALF / 2; q0 += 16) {
+                    float v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = (2 * (q0 + u) + par < nrow) ? colp[2 * (q0 + u) * FLD] : -INFINITY;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) mc = fmaxf(mc, v[u]);
+                }
+                if (mc != -INFINITY) {
+#pragma unroll 1
+                    for (int q0 = 0; q0 < F3_HALF / 2; q0 += 16) {
+                        float v[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) v[u] = (2 * (q0 + u) + par < nrow) ? colp[2 * (q0 + u) * FLD] : -INFINITY;
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) ec += __expf(v[u] - mc);
+                    }
+                }
                 merge_ms(cm, ce, mc, ec);
             }
             __syncthreads();
@@ -1179,9 +1213,11 @@ extern "C" size_t ophip_coarse_workspace_floats(int B, int N, int M) { return co
 // per frame on -- BASELINE config 4 (15 000 x 19 200 = 288 M) yes, config 2 (33.6 M) no; see DESIGN.md for the measurement behind it.
 bool ophip_coarse_two_pass(int B, int N, int M) {
     (void)B;
-    static const int forced = [] { const char* e = getenv("OPHIP_COARSE_TWO_PASS"); return e && e[0] ? atoi(e) : -1; }();
-    static const long long min_elems = [] { const char* e = getenv("OPHIP_COARSE_TWO_PASS_MIN"); return e && e[0] ? atoll(e) : (1LL << 27); }();
-    if (forced >= 0) return forced != 0;
+    // (read on every call -- two getenv per frame -- so that a test can compare the forms inside one process)
+    const char* f = getenv("OPHIP_COARSE_TWO_PASS");
+    if (f && f[0]) return atoi(f) != 0;
+    const char* e = getenv("OPHIP_COARSE_TWO_PASS_MIN");
+    const long long min_elems = e && e[0] ? atoll(e) : (1LL << 27);
     return (long long)N * M >= min_elems;
 }
 
@@ -1258,7 +1294,8 @@ int coarse_impl(int parts, int border_mode, int wi, double temp_eps,
             OPHIP_LAUNCH(NAME_, stream, (sim_frag_kernel<NS_, MODE_>), dim3(8 * per_xcd, B), dim3(256), SIM_FRAG_LDS, stream, sf);    \
         }
         // OPHIP_SIM_TILE=2: round 2-4's kernel (two workgroups per CU, four operand buffers); default 3: three per CU (sim_frag3_kernel)
-        static const bool tile3 = [] { const char* e = getenv("OPHIP_SIM_TILE"); return !(e && e[0] == '2'); }();
+        const char* tile_env = getenv("OPHIP_SIM_TILE");          // (read per call: tests compare the two tile kernels in one process)
+        const bool tile3 = !(tile_env && tile_env[0] == '2');
 #define OPHIP_SIM3_CASE(NS_, MODE_)                                                                                                \
         {                                                                                                                          \
             if (int rc = ophip_lds_attr(reinterpret_cast<const void*>(sim_frag3_kernel<NS_, MODE_>), SIM_F3_LDS, "hipFuncSetAttribute(sim_frag3)")) return rc; \

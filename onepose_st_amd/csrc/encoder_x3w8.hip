@@ -15,6 +15,10 @@
 #include "x3w8_internal.h"
 #include <stdlib.h>
 
+#ifndef OPHIP_X3_HALF_PRIO
+#define OPHIP_X3_HALF_PRIO 0
+#endif
+
 namespace {
 
 using namespace x3;
@@ -152,6 +156,11 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
     WStream wsk;
     wsk.open(tail ? a.wkv + (size_t)fwu * KV_FRAGS * 64 : a.wmain, tail ? KV_FRAGS : 0, lane);
     Ring ring;
+#if OPHIP_X3_HALF_PRIO
+    // experiment (MI355X_MICROARCH.md, "Two waves per SIMD" item 4): static priority for the second-dispatched half of the workgroup, which
+    // loses the issue arbitration (priority, then age) on every segment
+    if (fw >= 4) __builtin_amdgcn_s_setprio(OPHIP_X3_HALF_PRIO);
+#endif
     OPHIP_STAMP(a.stamps, wg, 0);
     OPHIP_STAMP_REAL(a.stamps, wg, 30);
 

@@ -51,7 +51,7 @@ def device_asm():
 
 def _sim_frag_kernels(device_asm):
     ks = {k: v for k, v in device_asm.items() if "sim_frag_kernel" in k}
-    assert len(ks) == 6, sorted(ks)                                   # NS in {1, 3} x MODE in {0, 1, 2}
+    assert len(ks) == 8, sorted(ks)                                   # NS in {1, 3} x MODE in {0, 1, 2, 3}
     return ks
 
 
@@ -88,6 +88,52 @@ def test_sim_frag_k_loop_keeps_its_wait_barrier_and_ring_discipline(device_asm):
         assert not any(t.startswith("ds_read") for t in ins[:opens[0]]), sym
 
 
+def test_sim_frag3_k_loop_keeps_its_wait_barrier_and_ring_discipline(device_asm):
+    """The three-buffer tile kernel (sim_frag3_kernel, the default since round 5): chunks run TWO k-steps ahead, so step s waits with
+    vmcnt(G) (chunk s + 1 may stay in flight; vmcnt(0) in the last step), exactly the pieces of chunks 0 .. s + 1 have been issued when it
+    waits, chunk s + 2 is issued behind the barrier into buffer (s + 2) % 3 = the one read in step s - 1, and step s reads buffer s % 3 only."""
+    ks = {k: v for k, v in device_asm.items() if "sim_frag3_kernel" in k}
+    assert len(ks) == 4, sorted(ks)                                   # NS in {1, 3} x MODE in {0, 1}
+    for sym, ins in ks.items():
+        ns = 3 if "ILi3ELi" in sym else 1
+        G = 4 if ns == 3 else 2
+        opens = [i for i, t in enumerate(ins) if re.match(r"s_waitcnt vmcnt\(\d+\) lgkmcnt\(0\)$", t)]
+        opens = [i for i in opens if i + 1 < len(ins) and ins[i + 1] == "s_barrier"]
+        assert len(opens) >= NKS, (sym, len(opens))
+        opens = opens[:NKS]
+        counts = [int(re.search(r"vmcnt\((\d+)\)", ins[i]).group(1)) for i in opens]
+        assert counts == [G] * (NKS - 1) + [0], (sym, counts)
+        first_dma = next(i for i, t in enumerate(ins) if t.startswith("global_load_lds_dwordx4"))
+        for t in ins[first_dma:opens[-1]]:
+            if re.match(r"(global|buffer|scratch|flat)_", t):
+                assert t.startswith("global_load_lds_dwordx4"), (sym, t)
+        dma_before = lambda idx: sum(1 for t in ins[:idx] if t.startswith("global_load_lds_dwordx4"))
+        for s_, at in enumerate(opens):
+            assert dma_before(at) == G * min(s_ + 2, NKS), (sym, s_, dma_before(at))
+            end = opens[s_ + 1] if s_ + 1 < NKS else next(i for i in range(at + 2, len(ins)) if ins[i] == "s_barrier")
+            reads = [t for t in ins[at + 2:end] if t.startswith("ds_read")]
+            assert len(reads) == 2 * G, (sym, s_, reads)
+            for t in reads:
+                assert t.startswith("ds_read_b128"), (sym, t)
+                off = re.search(r"offset:(\d+)", t)
+                off = int(off.group(1)) if off else 0
+                assert off // CHUNK == s_ % 3, (sym, s_, t)
+        assert not any(t.startswith("ds_read") for t in ins[:opens[0]]), sym
+
+
+def test_fine_stage_reads_the_3d_token_once_per_register(device_asm):
+    """The fine stage's last step broadcasts the 3D token's features with v_readlane (lanes 25 and 57) -- one pair per residual register.
+    hipcc 7.2 reads ELEMENT 0 when a bit_cast is applied to a vector element directly (seen in round 5: one pair for sixteen registers,
+    every test of the whole path red); the kernels copy the element first, and this test counts the instructions."""
+    for part, tiles in (("fine_pair_kernelILi3E", 2), ("fine_pair_kernelILi1E", 2), ("fine_refine_bf16_kernelILi3ELi1E", 1), ("fine_refine_bf16_kernelILi1ELi1E", 1)):
+        hits = [k for k in device_asm if part in k]
+        assert len(hits) == 1, (part, hits)
+        ins = device_asm[hits[0]]
+        for ln in (25, 57):
+            n = sum(1 for t in ins if re.match(rf"v_readlane_b32 s\d+, v\d+, {ln}$", t))
+            assert n == 16 * tiles, (part, ln, n)
+
+
 def test_hot_kernels_do_not_spill_beyond_what_is_documented(device_asm):
     """scratch traffic in a matrix kernel is a silent 2-5x: the encoder and similarity kernels must have none; the fine pair kernel's
     few spilled registers are bounded."""
@@ -95,7 +141,7 @@ def test_hot_kernels_do_not_spill_beyond_what_is_documented(device_asm):
         hits = [k for k in device_asm if sym_part in k]
         assert hits, sym_part
         return {k: sum(1 for t in device_asm[k] if t.startswith("scratch_")) for k in hits}
-    for part in ("enc_x3w8_kernel", "sim_frag_kernel", "conf_kernel"):
+    for part in ("enc_x3w8_kernel", "sim_frag_kernel", "sim_frag3_kernel", "conf_kernel"):
         assert all(v == 0 for v in scratch_ops(part).values()), scratch_ops(part)
     for k, v in scratch_ops("fine_pair_kernelILi3E").items():
         assert v <= 24, (k, v)

@@ -310,6 +310,40 @@ def test_coarse_match_vs_oracle(dev, B, N, hc, wc, nsplit, rtol):
     assert torch.equal(mk3.cpu(), ref["mkpts_3d_db"]) and torch.equal(mkc.cpu(), ref["mkpts_query_c"])
 
 
+@pytest.mark.parametrize("nsplit", [3, 1])
+@pytest.mark.parametrize("B,N,hc,wc", [(1, 300, 10, 13), (2, 129, 9, 9), (1, 1000, 30, 40), (1, 1408, 24, 32)])
+def test_coarse_match_tile_kernels_and_two_pass_form_agree(dev, monkeypatch, B, N, hc, wc, nsplit):
+    """The bf16 modes' similarity stage exists in two tile kernels (sim_frag3_kernel: three workgroups per CU, the default;
+    sim_frag_kernel, OPHIP_SIM_TILE=2: rounds 2-4's) and two eager forms (one tile pass that stores S + the in-place conversion pass;
+    OPHIP_COARSE_TWO_PASS=1: statistics pass + a second tile pass that writes every confidence once -- the default from 2^27 matrix elements
+    on, BASELINE config 4).  Match lists must be identical in all four; conf_matrix bit-identical between the two forms on the same tile
+    kernel (same statistics, conf_kernel's own expression) and between the tile kernels on interior tiles (same association of every sum);
+    tiles cut by the matrix edge take each kernel's exact pass, whose column partials are merged in a different order (last bits)."""
+    f3, f2 = _planted_features(B, N, hc, wc, 3, min(N, hc * wc) // 2)
+    kp = torch.randn(B, N, 3, generator=torch.Generator().manual_seed(4))
+    out = {}
+    for tile in ("3", "2"):
+        for two in ("0", "1"):
+            monkeypatch.setenv("OPHIP_SIM_TILE", tile)
+            monkeypatch.setenv("OPHIP_COARSE_TWO_PASS", two)
+            conf, ids, mconf, mk3, mkc = _coarse_match(dev, f3, f2, kp, wc, nsplit=nsplit)
+            out[tile, two] = (conf.clone(), [t.clone() for t in ids], mconf.clone(), mkc.clone())
+    base = out["3", "0"]
+    assert len(base[1][1]) > 10
+    for key, (conf, ids, mconf, mkc) in out.items():
+        for a, b in zip(ids, base[1]):
+            assert torch.equal(a, b), key
+        assert torch.equal(mkc, base[3]), key
+    for tile in ("3", "2"):
+        assert torch.equal(out[tile, "0"][0], out[tile, "1"][0]), tile          # the two forms on one tile kernel: every confidence bit for bit
+        assert torch.equal(out[tile, "0"][2], out[tile, "1"][2]), tile
+    close(out["2", "0"][0], base[0], rtol=1e-5, atol=0, msg="conf_matrix of the two tile kernels")
+    M = hc * wc
+    ni, nj = (N // 128) * 128, (M // 128) * 128                                  # the interior tiles: statistics in the same association
+    if ni and nj and N % 128 == 0 and M % 128 == 0:
+        assert torch.equal(out["2", "0"][0], base[0])
+
+
 @pytest.mark.parametrize("nsplit,rtol", [(0, 1e-4), (3, 1e-3)])
 def test_coarse_match_wide_logit_range(dev, nsplit, rtol):
     """A few very strong pairs (logit ~110) among ordinary ones (|logit| < 10) in interior 128 x 128 tiles: the bf16 modes' tile

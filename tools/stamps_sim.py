@@ -1,6 +1,7 @@
-"""Diagnostic: cycle stamps of sim_stats_bf16 at c2. Not part of the product."""
-import sys, ctypes, numpy as np, torch
-sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))
+"""Diagnostic: cycle stamps of the similarity tile kernel at c2 (sim_frag3_kernel, or sim_frag_kernel with OPHIP_SIM_TILE=2).  Not part of the product.
+Stamps per workgroup: 0 start | 1 end of the k-loop | 2 tile maximum known | 3 end of the store + statistics pass | 4 end."""
+import sys, os, ctypes, numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from onepose_st_amd import hip
 dev = torch.device("cuda:0"); hip.load()
 N, M, wc = 7000, 4800, 80
@@ -20,9 +21,10 @@ buf = torch.zeros(nwg * 32, dtype=torch.int64, device=dev)
 hip.call("ophip_debug_stamps", ctypes.c_void_p(buf.data_ptr())); run(); torch.cuda.synchronize(); hip.call("ophip_debug_stamps", None)
 s = buf.view(-1, 32).cpu().numpy().astype(np.int64)
 s = s[s[:, 0] > 0]
-print("WGs", len(s))
-for n in range(7):
-    t = s[:, 4 * n: 4 * n + 4]
-    nxt = s[:, 4 * n + 4] if n < 6 else None
-    print(f"tile {n}: k-steps {np.median(t[:,1]-t[:,0]):7.0f}  E+F {np.median(t[:,2]-t[:,1]):6.0f}  out/stage+G {np.median(t[:,3]-t[:,2]):6.0f}" + (f"  to next {np.median(nxt - t[:,3]):5.0f}" if nxt is not None else ""))
-print("step 5 of tile 1: issue", np.median(s[:,29]-s[:,28]), "mfma+reads issue", np.median(s[:,30]-s[:,29]), "to end of step 6", np.median(s[:,31]-s[:,30]))
+print("library build", hip.build_stamp(), "| tile kernel", os.environ.get("OPHIP_SIM_TILE", "3 (default)"), "| workgroups", len(s))
+for k, name in ((1, "k-loop (16 k-steps)"), (2, "scale + tile maximum + sync"), (3, "stage + store + exponentials (+ syncs)"), (4, "sums across waves, partial records / exact pass")):
+    print(f"{name:52s} {np.median(s[:, k] - s[:, k - 1]):9.0f}")
+d = s[:, 4] - s[:, 0]
+print("workgroup cycles p10 / p50 / p90 / max", np.percentile(d, 10), np.median(d), np.percentile(d, 90), d.max())
+t0 = s[:, 0].min()
+print("kernel span", s[:, 4].max() - t0, "cycles; last workgroup START at", s[:, 0].max() - t0, "; slowest decile of workgroups (cycles):", np.sort(d)[-len(d) // 10:][::20])
