@@ -293,7 +293,10 @@ __device__ __forceinline__ bool xcd_tile(int ntr, int ntc, int& ti, int& tj) {
     const int q = ntr / 8, rem = ntr % 8;
     const int r0 = x * q + (x < rem ? x : rem), nr = q + (x < rem ? 1 : 0);
     if (nr == 0 || k >= nr * ntc) return false;
-    tj = k / nr;
+    // the LAST column band first: its tiles are cut by the matrix edge (M is rarely a multiple of 128) and take the exact statistics pass,
+    // 1.3-2x a plain tile (tools/stamps_sim.py) -- walked last they were each XCD's tail (round 5: the slowest decile of workgroups all ended
+    // the launch); walked first they sit under the other rounds
+    tj = ntc - 1 - k / nr;
     ti = r0 + k % nr;
     return true;
 }
