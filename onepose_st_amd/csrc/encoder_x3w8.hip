@@ -9,7 +9,7 @@
 //     ALU, its partner keeps the matrix pipe fed (tools/micro/gemm16_2w.hip: 257 against 293 us for the bare k-step loop);
 //   * the MLP's hidden layer goes in two 256-wide chunks through ONE hidden buffer (each wave produces 32 hidden features per
 //     chunk: with 128-wide chunks a wave would own a single feature tile and read 1 KiB of activations per 3 MFMAs);
-//   * per-wave streams are 256 + 64 KiB (packing.pack_coarse_layer_x3w8): Q | W0c1x | merge | W0c0x | W0c0m | W2c0 | W0c1m | W2c1, then
+//   * per-wave streams are 256 + 64 KiB (packing.pack_coarse_layer_x3w8): Q | W0c1x | merge | W0c0x | W0c0m | W0c1m | W2c0 | W2c1, then
 //     the next layer's K|V of head fw;
 //   * round 5: the two waves of a SIMD (fw and fw + 4) no longer run every phase in step.  Of the phases without matrix work, two have a
 //     GEMM next to them that needs nothing they produce -- the x-half k-steps of the MLP's first layer read the layer's INPUT rows only --
@@ -28,6 +28,12 @@
 #ifndef OPHIP_X3_PAIR_LN1
 #define OPHIP_X3_PAIR_LN1 0
 #endif
+#ifndef OPHIP_X3_FORCE_ORDER
+#define OPHIP_X3_FORCE_ORDER 0
+#endif
+#ifndef OPHIP_X3_PAIR_HSTORE
+#define OPHIP_X3_PAIR_HSTORE 0
+#endif
 
 namespace {
 
@@ -38,7 +44,7 @@ constexpr int NTT = 3, TOK = 16 * NTT;
 constexpr int ROWB = C * 2;                     // X / Y / hidden plane pitch (512 B, 32 chunks)
 constexpr int PLANE = TOK * ROWB;               // 24 576 B
 constexpr int MAIN_FRAGS = 256, KV_FRAGS = 64;  // per wave: eight stages of 32 fragments (below) ;  K|V 64
-constexpr int POS_Q = 0, POS_W0C1X = 32, POS_M = 64, POS_W0C0X = 96, POS_W0C0M = 128, POS_W2C0 = 160, POS_W0C1M = 192, POS_W2C1 = 224;      // packing.X3W8_STAGES x 2
+constexpr int POS_Q = 0, POS_W0C1X = 32, POS_M = 64, POS_W0C0X = 96, POS_W0C0M = 128, POS_W0C1M = 160, POS_W2C0 = 192, POS_W2C1 = 224;      // packing.X3W8_STAGES x 2
 constexpr int KV_PART_FLOATS = NH * 1024 + NH * 32;
 constexpr int KV_FRAG_BYTES = NH * 2 * 2 * 64 * 16;
 constexpr int KV_BLOCK_BYTES = KV_FRAG_BYTES + NH * 32 * 4;
@@ -64,6 +70,14 @@ struct EncW8Args {
 };
 
 __device__ __forceinline__ int stash_off(int row, int chunk) { return row * (C * 4) + ((chunk ^ (row & 15)) << 4); }
+
+// a copy of the lane index the compiler cannot see through: the addresses a late phase forms from it (plane offsets of its stores, the
+// output / residual / fragment pointers of the last phase) are then computed where they are used, instead of joining the values that are
+// live from the kernel's first instruction on (round 5: ~25 registers at the kernel's tightest point, which decided between 0 and 23 spills)
+__device__ __forceinline__ int opaque_lane(int lane) {
+    asm volatile("" : "+v"(lane));
+    return lane;
+}
 
 // merge the eight waves' moments of token 16 tt + c16 -> mean, 1 / sqrt(var + eps)   (biased variance over 256 features)
 __device__ __forceinline__ void merged_stats(const float* scratch, int tt, int c16, float& mean, float& rstd) {
@@ -97,6 +111,11 @@ __device__ __forceinline__ void publish_moments(float* scratch, const float (&s)
 // (mk: the stream's padding mask or NULL -- kv_mask: a padded cell's phi(K) row is zero, and with it its K^T V term)
 __device__ __forceinline__ void kv_tail(Ring& ring, const WStream& wsk, const char* XH, const char* XL, int tok0, int L, float* __restrict__ out,
                                         int fw, int lane, const unsigned char* mk = nullptr) {
+    // This function is inlined into two kernels (the fused tail of attn_apply and the stand-alone kv_reduce) whose slabs must agree bit for
+    // bit (test_encoder_x3_chain_with_fused_kv_tail).  Under hipcc's default -ffp-contract=fast the product `v * inv_len` below may or may
+    // not be fused into the subtraction of the (hi, lo) split that follows it, kernel by kernel (round 5: the re-ordered attn_apply took
+    // the other choice and the two slabs differed by an ulp of their inputs): no contraction of this function's own arithmetic
+#pragma clang fp contract(off)
     const int c16 = lane & 15, q = lane >> 4;
     f32x4 kk[4][NTT];            // D[token 4q + r][feature c16]: ft 0, 1 = K of head fw, ft 2, 3 = V
 #pragma unroll
@@ -212,7 +231,13 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
         ksm[0] = *reinterpret_cast<const f32x4*>(kp);
         ksm[1] = *reinterpret_cast<const f32x4*>(kp + 16);
     };
+#if OPHIP_X3_FORCE_ORDER == 1
+    const bool gemm_first = true;                    // (diagnostic builds: every wave in the same order)
+#elif OPHIP_X3_FORCE_ORDER == 2
+    const bool gemm_first = false;
+#else
     const bool gemm_first = fwu < 4;                 // waves 0-3 run a (GEMM, vector phase) pair in this order, their SIMD partners 4-7 in the other
+#endif
     if (!ONLY_KV && !gemm_first) load_kv();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -344,11 +369,8 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
 
     // ---- MLP: hidden = relu([x, msg] W0^T) in two 256-feature chunks (x-halves above), o += hidden_chunk W2[:, chunk]^T -----------------
     f32x4 o[2][NTT];
-#pragma unroll
-    for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) o[ft][tt] = zero4();
     auto store_hidden = [&](const f32x4 (&hd)[2][NTT]) {
+        const int ln = opaque_lane(lane), c16s = ln & 15, qs = ln >> 4;
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
@@ -356,16 +378,31 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
                 f32x4 v;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(hd[ft][tt][r], 0.f);
-                store_quad(v, HH, HL, ROWB, tt, c16, 32 * fw + 16 * ft + 4 * q);
+                store_quad(v, HH, HL, ROWB, tt, c16s, 32 * fwu + 16 * ft + 4 * qs);
             }
     };
     gemm_stage<NTT, 2, 8, true>(hd0, ring, wsm, POS_W0C0M + R, YH, YL, ROWB, 0, c16, q);
+    // store of hidden chunk 0 (vector work)  ||  msg-half of chunk 1 (reads Y, writes registers): opposite order on the two waves of a SIMD
+#if OPHIP_X3_PAIR_HSTORE
+    if (gemm_first) {
+        gemm_stage<NTT, 2, 8, true>(hd1, ring, wsm, POS_W0C1M + R, YH, YL, ROWB, 0, c16, q);
+        store_hidden(hd0);
+    } else {
+        store_hidden(hd0);
+        gemm_stage<NTT, 2, 8, true>(hd1, ring, wsm, POS_W0C1M + R, YH, YL, ROWB, 0, c16, q);
+    }
+#else
     store_hidden(hd0);
+    gemm_stage<NTT, 2, 8, true>(hd1, ring, wsm, POS_W0C1M + R, YH, YL, ROWB, 0, c16, q);
+#endif
     __syncthreads();
     OPHIP_STAMP(a.stamps, wg, 6);
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) o[ft][tt] = zero4();
     gemm_stage<NTT, 2, 8, true>(o, ring, wsm, POS_W2C0 + R, HH, HL, ROWB, 0, c16, q);
     OPHIP_STAMP(a.stamps, wg, 7);
-    gemm_stage<NTT, 2, 8, true>(hd1, ring, wsm, POS_W0C1M + R, YH, YL, ROWB, 0, c16, q);
     __syncthreads();                                 // every wave is done reading chunk 0 of the hidden planes
     store_hidden(hd1);
     __syncthreads();
@@ -413,8 +450,19 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft) {
             f32x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = xr[ft][tt][r] + ((o[ft][tt][r] - mean) * rstd * g2[ft][r] + b2[ft][r]);
+            {
+                // ONE evaluation of the output row: it goes to memory AND (hi, lo split) into the planes the fused K|V tail reads, and the
+                // next layer's stand-alone K / V half must see the very same bits in memory (test_encoder_x3_chain_with_fused_kv_tail: the
+                // fused tail == the stand-alone launch).  Under -ffp-contract=fast the compiler is free to evaluate the expression once
+                // per use with different fused multiply-adds (seen in round 5 after the phases were re-ordered: slabs off by an ulp of
+                // their inputs); the empty asm pins the four values
+                float e0 = xr[ft][tt][0] + ((o[ft][tt][0] - mean) * rstd * g2[ft][0] + b2[ft][0]);
+                float e1 = xr[ft][tt][1] + ((o[ft][tt][1] - mean) * rstd * g2[ft][1] + b2[ft][1]);
+                float e2 = xr[ft][tt][2] + ((o[ft][tt][2] - mean) * rstd * g2[ft][2] + b2[ft][2]);
+                float e3 = xr[ft][tt][3] + ((o[ft][tt][3] - mean) * rstd * g2[ft][3] + b2[ft][3]);
+                asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));
+                v = f32x4{e0, e1, e2, e3};
+            }
             if (tok < L) *reinterpret_cast<f32x4*>(yg + (size_t)tok * C + 32 * fw + 16 * ft + 4 * q) = v;
             else v = zero4();
             if (tail) store_quad(v, XH, XL, ROWB, tt, c16, 32 * fw + 16 * ft + 4 * q);

@@ -93,7 +93,7 @@ def test_mlp_chunk_order_of_the_stream():
     out_ref = hidden_ref @ mats["w2"].T
     S = packing.X3W8_STAGES
     order = sorted(S, key=S.get)
-    assert order == ["q", "w0c1x", "m", "w0c0x", "w0c0m", "w2c0", "w0c1m", "w2c1"] and [S[n] for n in order] == list(range(0, 128, 16))
+    assert order == ["q", "w0c1x", "m", "w0c0x", "w0c0m", "w0c1m", "w2c0", "w2c1"] and [S[n] for n in order] == list(range(0, 128, 16))
     streams = [packing.x3w8_program(fw)[0] for fw in range(8)]
     stage = lambda fw, name: streams[fw][S[name]:S[name] + 16]
     # the x-halves first (they only read the input rows), kept in the accumulators

@@ -15,6 +15,7 @@
 #                    comma-separated list of NAME=VALUE environment assignments (OPHIP_LIB=onepose_st_amd/lib/variants/lib....so picks a variant build)
 #   py:<script>[:<arg>...]   python3 <script> <args> > <out>/<script name>.txt   (tools/micro drivers, one-off timings)
 #   epy:<NAME=VALUE[,NAME=VALUE...]>:<script>[:<arg>...]   the same with environment assignments (kernel variants behind an environment switch)
+#   pt:<NAME=VALUE[,...] or ->:<pytest -k expression>   a selection of the GPU tests under environment assignments (diagnostic: does not stop the call)
 set -o pipefail
 cd ${GRAFT_REPO_ROOT:-$(dirname $0)/..}
 export TMPDIR=/tmp
@@ -106,6 +107,12 @@ for step in "$@"; do
       e="${A[0]//,/ }"; n=$(basename ${A[1]} .py)_$(echo "${A[0]}" | tr -c 'A-Za-z0-9\n' '_')
       env $e timeout -k 10 400 python3 "${A[@]:1}" > $O/$n.txt 2>&1 || { tail -8 $O/$n.txt; exit 1; }
       echo "[${A[0]}]"; tail -20 $O/$n.txt ;;
+    pt:*)
+      IFS=: read -r -a A <<< "${step#pt:}"
+      if [ "${A[0]}" = "-" ]; then e=""; else e="${A[0]//,/ }"; fi
+      n=pt_$(echo "${A[0]}_${A[1]}" | tr -c 'A-Za-z0-9\n' '_')
+      env $e timeout -k 10 600 python3 -m pytest tests -m gpu -q -k "${A[1]}" > $O/$n.log 2>&1; rc=$?
+      echo "[${A[0]}] -k '${A[1]}' rc=$rc"; tail -6 $O/$n.log ;;          # (a failing selection does not stop the call: these are diagnostic)
     *) echo "unknown step $step"; exit 2 ;;
   esac
 done
