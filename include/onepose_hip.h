@@ -112,6 +112,13 @@ int ophip_encoder_layer_x3w8_frag(const float* x3d, const float* x2d, float* y3d
 int ophip_encoder_layer_x3w8(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
                              const void* wpack, const void* wpack_next, int is_cross, int kv_from_prev, int slot,
                              void* workspace, void* stream);
+/* One layer on a SUBSET of the two streams' rows: streams bit 0 = the first stream (x3d -> y3d), bit 1 = the second (x2d -> y2d); the
+ * layer projects its own K / V (of the stream(s) the running rows attend to) and has no fused tail.  For LoFTR's sequential cross layers
+ * (feat0 = layer(feat0, feat1); feat1 = layer(feat1, feat0_new): one launch per image instead of two two-stream launches that each
+ * discard half their rows).  The rows that run equal the same rows of ophip_encoder_layer_x3w8 bit for bit; the pointers of a stream
+ * that neither runs nor is attended to may be NULL.  Replaces transformer.py:65-94 on one stream. */
+int ophip_encoder_layer_x3w8_streams(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
+                                     const void* wpack, int is_cross, int streams, void* workspace, void* stream);
 /* The K / V half of a layer that projects its own K, V (the FIRST layer of a frame; transformer.py:65-94 k_proj / v_proj +
  * linear_attention.py:49-57): K, V projections of both streams -> phi(K)^T V / Ksum slabs -> their fixed-order sum into the workspace.
  * It reads the layer's input rows only, so a frame pipeline issues it as soon as those exist -- beside whatever the previous frame

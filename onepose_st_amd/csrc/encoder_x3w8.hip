@@ -596,12 +596,16 @@ int layer_x3w8(const float* x3d, const float* x2d, float* y3d, float* y2d, int B
     const bool r3 = run & 1, r2 = run & 2;
     if ((!sum_only && ((r3 && !x3d) || (r2 && !x2d))) || !wpack || !workspace || (!only_kv && !sum_only && ((r3 && !y3d) || (r2 && !y2d))))
         return ophip_bad_arg(__func__, "null pointer");
+    if (is_cross && run != 3 && kv_mode == 0 && !sum_only && (!x3d || !x2d)) return ophip_bad_arg(__func__, "null pointer (a cross layer reads both streams)");
     if (B < 1 || L3d < 1 || L2d < 1) return ophip_bad_arg(__func__, "B, L3d, L2d must be >= 1");
     if (slot != 0 && slot != 1) return ophip_bad_arg(__func__, "slot must be 0 or 1");
     if (kv_mode < 0 || kv_mode > 2) return ophip_bad_arg(__func__, "kv_from_prev must be 0, 1 or 2");
     if (!only_kv && !sum_only && ((r3 && x3d == y3d) || (r2 && x2d == y2d))) return ophip_bad_arg(__func__, "in-place layer is not supported (cross layers read the pre-update streams)");
     if (reinterpret_cast<uintptr_t>(wpack) & 15) return ophip_bad_arg(__func__, "wpack must be 16-byte aligned");
-    if (is_cross && run != 3 && !only_kv && !sum_only) return ophip_bad_arg(__func__, "a cross layer needs both streams");
+    // a cross layer on ONE stream's rows (LoFTR's sequential cross: image 1 attends to the UPDATED image 0, so each image is its own launch):
+    // its K / V come from the OTHER stream, which this call must reduce itself (the previous layer's tail wrote no slabs for that case)
+    if (is_cross && run != 3 && !only_kv && !sum_only && kv_mode != 0) return ophip_bad_arg(__func__, "a one-stream cross layer projects its own K / V (kv_from_prev = 0)");
+    const int src = (kv_mode == 0 && is_cross && run != 3) ? (run ^ 3) : run;      // streams whose K / V this call reduces
     hipStream_t stream = (hipStream_t)stream_;
     const int t3 = (L3d + TOK - 1) / TOK, t2 = (L2d + TOK - 1) / TOK;
     // the workspace is sized for both streams (ophip_encoder_x3w8_workspace_bytes); a launch that leaves one out uses the head of each slab area
@@ -643,13 +647,15 @@ int layer_x3w8(const float* x3d, const float* x2d, float* y3d, float* y2d, int B
         ka.wkv = wkv_own;
         ka.partial = partial;
         ka.stamps = nullptr;
-        if (mask2d) { OPHIP_LAUNCH("kv_reduce", stream, (enc_x3w8_kernel<true, true>), dim3(rt3 + rt2, B), dim3(512), LDS_BYTES, stream, ka); }
-        else { OPHIP_LAUNCH("kv_reduce", stream, enc_x3w8_kernel<true>, dim3(rt3 + rt2, B), dim3(512), LDS_BYTES, stream, ka); }
+        ka.tiles[0] = (src & 1) ? t3 : 0; ka.tiles[1] = (src & 2) ? t2 : 0;
+        const int kt = ka.tiles[0] + ka.tiles[1];
+        if (mask2d) { OPHIP_LAUNCH("kv_reduce", stream, (enc_x3w8_kernel<true, true>), dim3(kt, B), dim3(512), LDS_BYTES, stream, ka); }
+        else { OPHIP_LAUNCH("kv_reduce", stream, enc_x3w8_kernel<true>, dim3(kt, B), dim3(512), LDS_BYTES, stream, ka); }
         OPHIP_CHECK_LAUNCH();
     }
     if (kv_mode != 2) {
-        // the slabs `partial` holds: written by this call's kv_reduce (the streams that run) or by the previous layer's tail (`have`)
-        const int hs = kv_mode == 0 ? run : have;
+        // the slabs `partial` holds: written by this call's kv_reduce (the source streams) or by the previous layer's tail (`have`)
+        const int hs = kv_mode == 0 ? src : have;
         KvSumArgs sa;
         sa.partial = partial; sa.kv = kv; sa.tiles[0] = (hs & 1) ? t3 : 0; sa.tiles[1] = (hs & 2) ? t2 : 0;
         sa.kv_bs = 2LL * KV_BLOCK_BYTES; sa.kv_ss = KV_BLOCK_BYTES;
@@ -769,4 +775,17 @@ int ophip_x3w8_layer_bs(const float* x3d, long long x3d_bs, const float* x2d, fl
     X3Opts o;
     o.x3d_bs = x3d_bs;
     return layer_x3w8(x3d, x2d, y3d, y2d, B, L3d, L2d, wpack, wpack_next, is_cross, kv_mode, slot, workspace, stream, frag3d, frag2d, mask2d, only_kv, o);
+}
+
+// One layer on a SUBSET of the two streams' rows (streams: bit 0 = the first stream, bit 1 = the second; 3 = ophip_encoder_layer_x3w8 with
+// kv_from_prev = 0 and no fused tail).  What it is for: LoFTR's cross layers are sequential -- feat0 = layer(feat0, feat1), then
+// feat1 = layer(feat1, feat0_NEW) (zju3dv/LoFTR loftr/loftr_module/transformer.py) -- so each image's update is a launch of its own;
+// issuing both with the two-stream entry point computed every cross layer twice and threw half of each result away (rounds 3-4,
+// onepose_st_amd/loftr.py).  The rows that run are bit-identical to the same rows of the two-stream call.
+extern "C" int ophip_encoder_layer_x3w8_streams(const float* x3d, const float* x2d, float* y3d, float* y2d, int B, int L3d, int L2d,
+                                                const void* wpack, int is_cross, int streams, void* workspace, void* stream) {
+    if (streams < 1 || streams > 3) return ophip_bad_arg(__func__, "streams must be 1, 2 or 3");
+    X3Opts o;
+    o.streams = streams;
+    return layer_x3w8(x3d, x2d, y3d, y2d, B, L3d, L2d, wpack, nullptr, is_cross, 0, 0, workspace, stream, nullptr, nullptr, nullptr, false, o);
 }

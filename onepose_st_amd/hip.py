@@ -85,6 +85,7 @@ _SIGNATURES = {
     "ophip_encoder_x3w8_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "ophip_encoder_x3w8_wpack_bytes": (ctypes.c_size_t, []),
     "ophip_encoder_layer_x3w8": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_i, c_i, c_i, c_f, ctypes.c_void_p]),
+    "ophip_encoder_layer_x3w8_streams": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_i, c_i, c_f, ctypes.c_void_p]),
     "ophip_encoder_kv_first_x3w8": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_i, c_f, c_f, ctypes.c_void_p]),
     "ophip_encoder_layer_x3w8_frag": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_i, c_i, c_i, c_f, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "ophip_coarse_frag_planes": (c_i, [c_f, c_i, c_i, c_i, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]),
