@@ -376,6 +376,9 @@ int ophip_coarse_match_2d(const float* feat0, const float* feat1, const float* p
                           float* mconf, float* mkpts0, float* mkpts1_c, long long* m_bids, unsigned char* gt_mask,
                           int* count, int nsplit, void* stream);
 int ophip_fine2_gather(const float* feat_cl, int hf, int wf, const long long* cell_ids, int K, int wc, int stride, int W, float* out, void* stream);
+/* the same over a batch of images [B][hf * wf][128]: match k reads image b_ids[k] (feat_bstride floats apart; 0: one image for every match) */
+int ophip_fine2_gather_b(const float* feat_cl, long long feat_bstride, const long long* b_ids, int hf, int wf, const long long* cell_ids,
+                         int K, int wc, int stride, int W, float* out, void* stream);
 size_t ophip_rows_linear_wpack_bytes(int kin, int nout);
 int ophip_rows_linear_x3(const float* xa, int ka, const float* xb, int kb, int T, const void* wpack, int nout, int relu, float* y, void* stream);
 int ophip_fine2_attention(const float* q, const float* k, const float* v, int K, int L, int S, float* msg, void* stream);

@@ -17,15 +17,18 @@ constexpr int CF = 128, NH = 8, DH = CF / NH;
 
 // ---- window gather: 9 x 9 (W x W) windows of a channels-last fine map around coarse cells, zero padding ----------------------
 struct GatherArgs {
-    const float* feat;          // [hf * wf][CF] channels-last (one image)
+    const float* feat;          // [hf * wf][CF] channels-last (one image; batched form: [B][hf * wf][CF])
     const long long* ids;       // [K] coarse cell index of every match (i_ids or j_ids)
     int hf, wf, wc, stride, W, K;
     float* out;                 // [K][W * W][CF]
+    const long long* b_ids;     // batched form: [K] image of every match; NULL: one image
+    long long feat_bs;          // floats between consecutive images (0: every match reads the same image)
 };
 
 __global__ __launch_bounds__(256) void fine2_gather_kernel(GatherArgs p) {
     const int k = blockIdx.x;
     const int cell = (int)p.ids[k];
+    if (p.b_ids) p.feat += (size_t)p.b_ids[k] * p.feat_bs;
     const int cy = p.stride * (cell / p.wc), cx = p.stride * (cell % p.wc), half = p.W / 2;
     const int items = p.W * p.W * (CF / 4);
     float* dst = p.out + (size_t)k * p.W * p.W * CF;
@@ -231,7 +234,21 @@ extern "C" int ophip_fine2_gather(const float* feat_cl, int hf, int wf, const lo
     if (K < 0 || W < 1 || (W & 1) == 0 || W * W > 128 || hf < 1 || wf < 1 || wc < 1 || stride < 1) return ophip_bad_arg(__func__, "bad sizes (odd window <= 11)");
     if (K == 0) return 0;
     hipStream_t stream = (hipStream_t)stream_;
-    GatherArgs a{feat_cl, cell_ids, hf, wf, wc, stride, W, K, out};
+    GatherArgs a{feat_cl, cell_ids, hf, wf, wc, stride, W, K, out, nullptr, 0};
+    OPHIP_LAUNCH("fine2_gather", stream, fine2_gather_kernel, dim3(K), dim3(256), 0, stream, a);
+    OPHIP_CHECK_LAUNCH();
+    return 0;
+}
+
+// the same gather over a BATCH of images: match k reads image b_ids[k] of feat_cl [B][hf * wf][128] (feat_bstride floats apart; 0 = one image
+// shared by every match: the detector's query frame).  For the detector's one batched matcher call over all reference views.
+extern "C" int ophip_fine2_gather_b(const float* feat_cl, long long feat_bstride, const long long* b_ids, int hf, int wf, const long long* cell_ids,
+                                    int K, int wc, int stride, int W, float* out, void* stream_) {
+    if (!feat_cl || !cell_ids || !out || !b_ids) return ophip_bad_arg(__func__, "null pointer");
+    if (K < 0 || W < 1 || (W & 1) == 0 || W * W > 128 || hf < 1 || wf < 1 || wc < 1 || stride < 1 || feat_bstride < 0) return ophip_bad_arg(__func__, "bad sizes (odd window <= 11)");
+    if (K == 0) return 0;
+    hipStream_t stream = (hipStream_t)stream_;
+    GatherArgs a{feat_cl, cell_ids, hf, wf, wc, stride, W, K, out, b_ids, feat_bstride};
     OPHIP_LAUNCH("fine2_gather", stream, fine2_gather_kernel, dim3(K), dim3(256), 0, stream, a);
     OPHIP_CHECK_LAUNCH();
     return 0;

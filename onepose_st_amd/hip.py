@@ -113,6 +113,7 @@ _SIGNATURES = {
     "ophip_coarse_match_2d": (c_i, [c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_i, c_i, ctypes.c_double, ctypes.c_float, c_i, ctypes.c_float,
                                     c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, ctypes.c_void_p]),
     "ophip_fine2_gather": (c_i, [c_f, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f, ctypes.c_void_p]),
+    "ophip_fine2_gather_b": (c_i, [c_f, c_ll, c_f, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f, ctypes.c_void_p]),
     "ophip_rows_linear_wpack_bytes": (ctypes.c_size_t, [c_i, c_i]),
     "ophip_rows_linear_x3": (c_i, [c_f, c_i, c_f, c_i, c_i, c_f, c_i, c_i, c_f, ctypes.c_void_p]),
     "ophip_fine2_attention": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f, ctypes.c_void_p]),

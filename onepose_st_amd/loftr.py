@@ -11,8 +11,10 @@ definition (``oracle/loftr_oracle.py`` restates it on the CPU; parity unpinned).
 
 * backbone ``ResNetFPN_8_2``: ``backbone_hip.HipBackbone`` (``ophip_conv2d_bf16``), positional encoding in the last epilogue;
 * 8 coarse layers ``[self, cross] x 4``: ``ophip_encoder_layer_x3w8``.  LoFTR's ``cross`` is sequential (image 1 attends to the
-  UPDATED image 0), so a cross layer is two launches of the two-stream kernel: the first yields the new image-0 rows, the second
-  -- fed with them -- the new image-1 rows;
+  UPDATED image 0), so a cross layer is two ONE-stream launches (``ophip_encoder_layer_x3w8_streams``): image 0's rows against image 1,
+  then image 1's rows against the new image 0 (rounds 3-4 ran the two-stream kernel twice and discarded half of each result);
+* batch: ``image0 [V, 1, H, W]`` against ``image1 [1 or V, 1, H, W]`` in ONE call -- the detector's ~15 reference views against one query
+  frame (the query's backbone features are computed once); ``b_ids`` names the pair of every match;
 * dual-softmax + mutual-nearest between the two grids: ``ophip_coarse_match_2d`` (temperature exactly 0.1, all-sides border);
 * fine stage, window 9 on both images, batched over all matches: ``csrc/loftr_fine.hip``.
 
@@ -96,7 +98,8 @@ class LoFTR_for_OnePose_Plus(nn.Module):
         self._packed = None
         self._pe = {}
         # optional ``hook(fc0 [1, L0, 256], ff0 [hf0 * wf0, 128], fc1, ff1) -> the same four``: the backbone-output boundary (coarse rows
-        # with the positional encoding added, fine maps channels-last) -- the counterpart of a forward hook on the reference's backbone
+        # with the positional encoding added, fine maps channels-last) -- the counterpart of a forward hook on the reference's backbone.
+        # (a batched call hands it ``fc0 [V, L0, 256], ff0 [V, hf0 * wf0, 128], fc1 [1 or V, ...], ff1`` and takes the same back)
         self.feature_hook = None
 
     # ------------------------------------------------------------------------------------------
@@ -141,12 +144,14 @@ class LoFTR_for_OnePose_Plus(nn.Module):
         img0, img1 = data["image0"], data["image1"]
         if not img0.is_cuda or not img1.is_cuda:
             raise hip.HipLibraryError("LoFTR_for_OnePose_Plus runs on the HIP device only (no CPU fallback)")
-        if img0.size(0) != 1 or img1.size(0) != 1:
-            raise NotImplementedError("batch size 1 (the detector matches one query against one reference view per call)")
+        V = img0.size(0)
+        if img1.size(0) not in (1, V):
+            raise ValueError(f"image1: batch {img1.size(0)} against image0's {V} (expected 1 -- one query for every pair -- or {V})")
+        shared1 = img1.size(0) == 1 and V > 1          # one query image against V views: its features are computed once
         hip.load()
         call, P, S = hip.call, hip.ptr, hip.stream_handle()
         dev = img0.device
-        data.update({"bs": 1, "hw0_i": img0.shape[2:], "hw1_i": img1.shape[2:]})
+        data.update({"bs": V, "hw0_i": img0.shape[2:], "hw1_i": img1.shape[2:]})
         Wb = self._blocks(dev)
         bbk = HipBackbone("bf16x3")
 
@@ -154,35 +159,42 @@ class LoFTR_for_OnePose_Plus(nn.Module):
             H, W = img.shape[2:]
             fc, ff = bbk.forward(Wb["backbone"], img, self._pe_table(H // 8, W // 8, dev))
             return fc, ff, (H // 8, W // 8), (H // 2, W // 2)
-        if img0.shape == img1.shape:
+        if img0.shape[2:] == img1.shape[2:]:
             fc, ff, hwc, hwf = features(torch.cat([img0, img1], 0))
-            fc0, fc1, ff0, ff1 = fc[0:1], fc[1:2], ff[0], ff[1]
+            fc0, fc1, ff0, ff1 = fc[:V], fc[V:], ff[:V], ff[V:]
             hw0_c = hw1_c = hwc
             hw0_f = hw1_f = hwf
         else:
             fc0, ff0, hw0_c, hw0_f = features(img0)
             fc1, ff1, hw1_c, hw1_f = features(img1)
-            ff0, ff1 = ff0[0], ff1[0]
         data.update({"hw0_c": torch.Size(hw0_c), "hw1_c": torch.Size(hw1_c), "hw0_f": torch.Size(hw0_f), "hw1_f": torch.Size(hw1_f)})
         if self.feature_hook is not None:
-            fc0, ff0, fc1, ff1 = self.feature_hook(fc0, ff0, fc1, ff1)
+            # one pair: the fine maps without the batch axis (the hook's form since round 3); a batch: everything with it
+            if V == 1:
+                fc0, f0h, fc1, f1h = self.feature_hook(fc0, ff0[0], fc1, ff1[0])
+            else:
+                fc0, f0h, fc1, f1h = self.feature_hook(fc0, ff0, fc1, ff1)
+            ff0, ff1 = (f0h[None] if f0h.dim() == 2 else f0h), (f1h[None] if f1h.dim() == 2 else f1h)
+            if fc0.shape[0] != V or fc1.shape[0] not in (1, V) or ff0.shape[0] != V or ff1.shape[0] != fc1.shape[0]:
+                raise ValueError("feature_hook: batch sizes of the returned features do not match the call")
+            shared1 = fc1.shape[0] == 1 and V > 1
         L0, L1 = hw0_c[0] * hw0_c[1], hw1_c[0] * hw1_c[1]
 
-        # ---- coarse transformer: self = one launch; cross = two (sequential semantics) ------------------------------------------
-        x0, x1 = fc0.contiguous(), fc1.contiguous()
-        ws = torch.empty(hip.load().ophip_encoder_x3w8_workspace_bytes(1, L0, L1), dtype=torch.uint8, device=dev)
-
-        def layer(a0, a1, w, cross):
-            b0, b1 = torch.empty_like(a0), torch.empty_like(a1)
-            call("ophip_encoder_layer_x3w8", P(a0), P(a1), P(b0), P(b1), 1, L0, L1, P(w, None), None, 1 if cross else 0, 0, 0, P(ws, None), S)
-            return b0, b1
+        # ---- coarse transformer: self = one two-stream launch; cross = two one-stream launches (sequential semantics) -------------------
+        x0 = fc0.contiguous()
+        x1 = (fc1.expand(V, -1, -1) if shared1 else fc1).contiguous()
+        ws = torch.empty(hip.load().ophip_encoder_x3w8_workspace_bytes(V, L0, L1), dtype=torch.uint8, device=dev)
         for li, name in enumerate(self.loftr_coarse.layer_names):
             w = Wb["coarse"][li]
             if name == "self":
-                x0, x1 = layer(x0, x1, w, False)
+                b0, b1 = torch.empty_like(x0), torch.empty_like(x1)
+                call("ophip_encoder_layer_x3w8", P(x0), P(x1), P(b0), P(b1), V, L0, L1, P(w, None), None, 0, 0, 0, P(ws, None), S)
+                x0, x1 = b0, b1
             else:
-                n0, _ = layer(x0, x1, w, True)              # image 0 against image 1
-                _, n1 = layer(n0, x1, w, True)              # image 1 against the UPDATED image 0
+                n0 = torch.empty_like(x0)              # image 0 against image 1
+                call("ophip_encoder_layer_x3w8_streams", P(x0), P(x1), P(n0), None, V, L0, L1, P(w, None), 1, 1, P(ws, None), S)
+                n1 = torch.empty_like(x1)              # image 1 against the UPDATED image 0
+                call("ophip_encoder_layer_x3w8_streams", P(n0), P(x1), None, P(n1), V, L0, L1, P(w, None), 1, 2, P(ws, None), S)
                 x0, x1 = n0, n1
 
         # ---- coarse matching between the two grids -----------------------------------------------------------------------------
@@ -190,14 +202,14 @@ class LoFTR_for_OnePose_Plus(nn.Module):
         scale = img0.shape[2] / hw0_c[0]
         ii = torch.arange(L0, device=dev)
         pts0 = torch.stack([(ii % hw0_c[1]).float() * scale, (ii // hw0_c[1]).float() * scale, torch.zeros(L0, device=dev)], 1)[None].contiguous()
-        cap = L0
-        conf = torch.empty(1, L0, L1, device=dev)
-        cws = torch.empty(hip.load().ophip_coarse_workspace_floats(1, L0, L1), device=dev)
+        cap = V * L0
+        conf = torch.empty(V, L0, L1, device=dev)
+        cws = torch.empty(hip.load().ophip_coarse_workspace_floats(V, L0, L1), device=dev)
         ids = [torch.empty(cap, dtype=torch.int64, device=dev) for _ in range(4)]
         mconf, mk0, mk1c = torch.empty(cap, device=dev), torch.empty(cap, 3, device=dev), torch.empty(cap, 2, device=dev)
         gt_mask = torch.empty(cap, dtype=torch.bool, device=dev)
         count = torch.zeros(4, dtype=torch.int32, device=dev)
-        call("ophip_coarse_match_2d", P(x0), P(x1), P(pts0), 0, 1, L0, L1, hw0_c[1], hw1_c[1], float(mc["dsmax_temperature"]), float(mc["thr"]),
+        call("ophip_coarse_match_2d", P(x0), P(x1), P(pts0), 0, V, L0, L1, hw0_c[1], hw1_c[1], float(mc["dsmax_temperature"]), float(mc["thr"]),
              int(mc["border_rm"]), float(scale), P(conf), P(cws), P(ids[0], torch.int64), P(ids[1], torch.int64), P(ids[2], torch.int64),
              P(mconf), P(mk0), P(mk1c), P(ids[3], torch.int64), P(gt_mask, torch.bool), P(count, torch.int32), 3, S)
         K = int(count[0].item())                           # the detector reads the matches on the host right after: one sync here
@@ -216,8 +228,11 @@ class LoFTR_for_OnePose_Plus(nn.Module):
         # ---- fine stage: windows on both images, two-stream fine transformer, correlation + soft-argmax ------------------------
         stride = hw0_f[0] // hw0_c[0]
         f0, f1 = torch.empty(K, WW, 128, device=dev), torch.empty(K, WW, 128, device=dev)
-        call("ophip_fine2_gather", P(ff0.contiguous()), hw0_f[0], hw0_f[1], P(i_ids, torch.int64), K, hw0_c[1], stride, Wf, P(f0), S)
-        call("ophip_fine2_gather", P(ff1.contiguous()), hw1_f[0], hw1_f[1], P(j_ids, torch.int64), K, hw1_c[1], hw1_f[0] // hw1_c[0], Wf, P(f1), S)
+        ff0c, ff1c = ff0.contiguous(), ff1.contiguous()          # [V or 1][hf * wf][128] channels-last
+        call("ophip_fine2_gather_b", P(ff0c), ff0c.stride(0) if ff0c.shape[0] > 1 else 0, P(b_ids, torch.int64), hw0_f[0], hw0_f[1],
+             P(i_ids, torch.int64), K, hw0_c[1], stride, Wf, P(f0), S)
+        call("ophip_fine2_gather_b", P(ff1c), ff1c.stride(0) if ff1c.shape[0] > 1 else 0, P(b_ids, torch.int64), hw1_f[0], hw1_f[1],
+             P(j_ids, torch.int64), K, hw1_c[1], hw1_f[0] // hw1_c[0], Wf, P(f1), S)
         T = K * WW
 
         def lin(xa, w, nout, xb=None, relu=False):

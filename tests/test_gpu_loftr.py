@@ -197,13 +197,21 @@ def test_detector_end_to_end_on_the_device(matcher, dev):
     calls = {"n": 0}
 
     def hook(fc0, ff0, fc1, ff1):
+        if fc0.shape[0] == 3:                        # the batched call: all three views at once, every pair with its own planted query
+            outs = [device_hook(pairs[k], dev)(None, None, None, None) for k in range(3)]
+            return (torch.cat([o[0] for o in outs]), torch.stack([o[1] for o in outs]), torch.cat([o[2] for o in outs]), torch.stack([o[3] for o in outs]))
         k = calls["n"] % 3
         calls["n"] += 1
         return device_hook(pairs[k], dev)(fc0, ff0, fc1, ff1)
     matcher.feature_hook = hook
     try:
         frame = np.zeros((H, W), dtype=np.uint8)
-        res = det.match_worker(torch.zeros(1, 1, H, W, device=dev))
+        res = det.match_worker(torch.zeros(1, 1, H, W, device=dev))           # ONE batched matcher call over the three views, one read-back
+        assert calls["n"] == 0
+        loop = det.match_worker(torch.zeros(1, 1, H, W, device=dev), batched=False)      # the reference's view-by-view form: the same votes
+        assert calls["n"] == 3
+        for k in range(3):
+            assert np.array_equal(res[k]["bbox"], loop[k]["bbox"]) and np.array_equal(np.asarray(res[k]["inliers"]), np.asarray(loop[k]["inliers"])), k
         assert res[1]["inliers"].sum() >= 40 and res[1]["inliers"].sum() > max(res[0]["inliers"].sum(), res[2]["inliers"].sum())
         assert np.abs(res[1]["bbox"] - np.array([16, 8, W + 16, H + 8])).max() <= 1
         calls["n"] = 0

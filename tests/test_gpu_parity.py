@@ -179,6 +179,32 @@ def test_encoder_layer_x3(sd, dev, cross, B, L3, L2, kern):
                  hip.ptr(ws, None), hip.stream_handle())
 
 
+@pytest.mark.parametrize("cross", [0, 1])
+@pytest.mark.parametrize("B,L3,L2", [(1, 64, 32), (2, 70, 145)])
+def test_encoder_layer_on_one_stream_equals_the_two_stream_rows(sd, dev, cross, B, L3, L2):
+    """ophip_encoder_layer_x3w8_streams: the layer on ONE stream's rows (LoFTR's sequential cross layers: one launch per image; a cross layer
+    then reduces the K / V of the OTHER stream itself) -- bit for bit the rows of the two-stream call, the other stream's output untouched."""
+    g = torch.Generator().manual_seed(12)
+    x3, x2 = torch.randn(B, L3, 256, generator=g).to(dev), torch.randn(B, L2, 256, generator=g).to(dev)
+    w = packing.pack_coarse_layer_x3w8(sd, "loftr_coarse.layers.1.").to(dev)
+    ws = torch.empty(hip.load().ophip_encoder_x3w8_workspace_bytes(B, L3, L2), dtype=torch.uint8, device=dev)
+    y3, y2 = torch.empty_like(x3), torch.empty_like(x2)
+    hip.call("ophip_encoder_layer_x3w8", hip.ptr(x3), hip.ptr(x2), hip.ptr(y3), hip.ptr(y2), B, L3, L2, hip.ptr(w, None), None, cross, 0, 0,
+             hip.ptr(ws, None), hip.stream_handle())
+    for streams, (ya, yb) in ((1, (y3, None)), (2, (None, y2))):
+        o3, o2 = torch.full_like(x3, float("nan")), torch.full_like(x2, float("nan"))
+        hip.call("ophip_encoder_layer_x3w8_streams", hip.ptr(x3), hip.ptr(x2), hip.ptr(o3) if streams & 1 else None, hip.ptr(o2) if streams & 2 else None,
+                 B, L3, L2, hip.ptr(w, None), cross, streams, hip.ptr(ws, None), hip.stream_handle())
+        torch.cuda.synchronize()
+        if streams & 1:
+            assert torch.equal(o3, y3) and bool(torch.isnan(o2).all())
+        else:
+            assert torch.equal(o2, y2) and bool(torch.isnan(o3).all())
+    with pytest.raises(ValueError):
+        hip.call("ophip_encoder_layer_x3w8_streams", hip.ptr(x3), hip.ptr(x2), hip.ptr(y3), hip.ptr(y2), B, L3, L2, hip.ptr(w, None), cross, 0,
+                 hip.ptr(ws, None), hip.stream_handle())
+
+
 @pytest.mark.parametrize("B,N,hc,wc", [(1, 100, 5, 15), (2, 333, 13, 20), (1, 1000, 30, 40)])
 def test_encoder_layer_writes_the_similarity_fragments(sd, dev, B, N, hc, wc):
     """ophip_encoder_layer_x3w8_frag: the layer's output rows, also as the similarity kernel's (hi, lo) operand fragments inside the

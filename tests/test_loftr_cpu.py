@@ -103,6 +103,14 @@ class _FakeMatcher(torch.nn.Module):
         self.per_view, self.calls = per_view, 0
 
     def forward(self, data):
+        V = data["image0"].shape[0]
+        if V > 1:                                    # the detector's batched call: every view's matches, b_ids = the view, ascending
+            self.calls += 1
+            self.batched_calls = getattr(self, "batched_calls", 0) + 1
+            data["b_ids"] = torch.cat([torch.full((len(self.per_view[v][0]),), v, dtype=torch.int64) for v in range(V)])
+            data["mkpts0_f"] = torch.cat([torch.tensor(self.per_view[v][0], dtype=torch.float32) for v in range(V)])
+            data["mkpts1_f"] = torch.cat([torch.tensor(self.per_view[v][1], dtype=torch.float32) for v in range(V)])
+            return
         m0, m1 = self.per_view[self.calls % len(self.per_view)]
         self.calls += 1
         data["mkpts0_f"], data["mkpts1_f"] = torch.tensor(m0, dtype=torch.float32), torch.tensor(m1, dtype=torch.float32)
@@ -118,7 +126,13 @@ def test_detector_control_flow_with_a_replayed_matcher():
     noisy = (src, rng.random((200, 2)) * np.array([W, H]))                           # no consistent affinity: few inliers
     det = detector.LocalFeatureObjectDetector(_FakeMatcher([few, noisy, good]), [np.zeros((H, W), np.uint8)] * 3, device="cpu")
     query = torch.zeros(1, 1, H, W)
-    res = det.match_worker(query)
+    res = det.match_worker(query)                        # ONE matcher call over the three views ...
+    assert det.matcher.calls == 1 and det.matcher.batched_calls == 1
+    det.matcher.calls = 0
+    loop = det.match_worker(query, batched=False)        # ... gives the votes of the reference's view-by-view loop
+    assert det.matcher.calls == 3
+    for k in range(3):
+        assert np.array_equal(res[k]["bbox"], loop[k]["bbox"]) and np.array_equal(np.asarray(res[k]["inliers"]), np.asarray(loop[k]["inliers"]))
     assert res[0]["bbox"].tolist() == [W // 2 - 500, H // 2 - 500, W // 2 + 500, H // 2 + 500] and res[0]["inliers"].sum() == 0
     assert res[2]["inliers"].sum() > 190 and res[1]["inliers"].sum() < 30
     want = lo.box_from_affine(lo.affine_lstsq(good[0], good[1]), (H, W))
