@@ -9,31 +9,11 @@
 //     ALU, its partner keeps the matrix pipe fed (tools/micro/gemm16_2w.hip: 257 against 293 us for the bare k-step loop);
 //   * the MLP's hidden layer goes in two 256-wide chunks through ONE hidden buffer (each wave produces 32 hidden features per
 //     chunk: with 128-wide chunks a wave would own a single feature tile and read 1 KiB of activations per 3 MFMAs);
-//   * per-wave streams are 256 + 64 KiB (packing.pack_coarse_layer_x3w8): Q | W0c1x | merge | W0c0x | W0c0m | W0c1m | W2c0 | W2c1, then
-//     the next layer's K|V of head fw;
-//   * round 5: the two waves of a SIMD (fw and fw + 4) no longer run every phase in step.  Of the phases without matrix work, two have a
-//     GEMM next to them that needs nothing they produce -- the x-half k-steps of the MLP's first layer read the layer's INPUT rows only --
-//     so chunk 1's x-half sits behind Q, beside the attention block, and chunk 0's behind merge, beside LayerNorm 1, and the two halves of
-//     the workgroup take the pair in OPPOSITE order (waves 0-3: GEMM then vector phase; waves 4-7: vector phase then GEMM): on every
-//     SIMD one wave's vector work runs under the other's matrix instructions instead of both queueing for the same pipe twice
-//     (MI355X_MICROARCH.md "Two waves per SIMD" item 9: split roles by wave number >= 4).  Every accumulator still sees its k-steps in the
-//     same order (x-half, then msg-half), so the layer's output is bit-identical to the in-step form of rounds 3-4.
+//   * per-wave streams are 256 + 64 KiB (packing.pack_coarse_layer_x3w8): Q | merge | W0c0 | W2c0 | W0c1 | W2c1, then the next
+//     layer's K|V of head fw.
 #include "tile_x3.h"
 #include "x3w8_internal.h"
 #include <stdlib.h>
-
-#ifndef OPHIP_X3_HALF_PRIO
-#define OPHIP_X3_HALF_PRIO 0
-#endif
-#ifndef OPHIP_X3_PAIR_LN1
-#define OPHIP_X3_PAIR_LN1 0
-#endif
-#ifndef OPHIP_X3_FORCE_ORDER
-#define OPHIP_X3_FORCE_ORDER 0
-#endif
-#ifndef OPHIP_X3_PAIR_HSTORE
-#define OPHIP_X3_PAIR_HSTORE 0
-#endif
 
 namespace {
 
@@ -43,8 +23,7 @@ constexpr int C = 256, NH = 8, NW = 8;
 constexpr int NTT = 3, TOK = 16 * NTT;
 constexpr int ROWB = C * 2;                     // X / Y / hidden plane pitch (512 B, 32 chunks)
 constexpr int PLANE = TOK * ROWB;               // 24 576 B
-constexpr int MAIN_FRAGS = 256, KV_FRAGS = 64;  // per wave: eight stages of 32 fragments (below) ;  K|V 64
-constexpr int POS_Q = 0, POS_W0C1X = 32, POS_M = 64, POS_W0C0X = 96, POS_W0C0M = 128, POS_W0C1M = 160, POS_W2C0 = 192, POS_W2C1 = 224;      // packing.X3W8_STAGES x 2
+constexpr int MAIN_FRAGS = 256, KV_FRAGS = 64;  // per wave: Q 32 | merge 32 | W0c0 64 | W2c0 32 | W0c1 64 | W2c1 32 ;  K|V 64
 constexpr int KV_PART_FLOATS = NH * 1024 + NH * 32;
 constexpr int KV_FRAG_BYTES = NH * 2 * 2 * 64 * 16;
 constexpr int KV_BLOCK_BYTES = KV_FRAG_BYTES + NH * 32 * 4;
@@ -70,14 +49,6 @@ struct EncW8Args {
 };
 
 __device__ __forceinline__ int stash_off(int row, int chunk) { return row * (C * 4) + ((chunk ^ (row & 15)) << 4); }
-
-// a copy of the lane index the compiler cannot see through: the addresses a late phase forms from it (plane offsets of its stores, the
-// output / residual / fragment pointers of the last phase) are then computed where they are used, instead of joining the values that are
-// live from the kernel's first instruction on (round 5: ~25 registers at the kernel's tightest point, which decided between 0 and 23 spills)
-__device__ __forceinline__ int opaque_lane(int lane) {
-    asm volatile("" : "+v"(lane));
-    return lane;
-}
 
 // merge the eight waves' moments of token 16 tt + c16 -> mean, 1 / sqrt(var + eps)   (biased variance over 256 features)
 __device__ __forceinline__ void merged_stats(const float* scratch, int tt, int c16, float& mean, float& rstd) {
@@ -186,11 +157,6 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
     WStream wsk;
     wsk.open(tail ? a.wkv + (size_t)fwu * KV_FRAGS * 64 : a.wmain, tail ? KV_FRAGS : 0, lane);
     Ring ring;
-#if OPHIP_X3_HALF_PRIO
-    // experiment (MI355X_MICROARCH.md, "Two waves per SIMD" item 4): static priority for the second-dispatched half of the workgroup, which
-    // loses the issue arbitration (priority, then age) on every segment
-    if (fw >= 4) __builtin_amdgcn_s_setprio(OPHIP_X3_HALF_PRIO);
-#endif
     OPHIP_STAMP(a.stamps, wg, 0);
     OPHIP_STAMP_REAL(a.stamps, wg, 30);
 
@@ -216,11 +182,10 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
 #pragma unroll
         for (int i = 0; i < R; ++i) ring.s[i] = wsm.load(i);
     }
-    // attention state of head fw: K^T V as (hi, lo) A-operand fragments + Ksum.  Waves 4-7 (attention block first, see below) fetch it here,
-    // under the row staging; waves 0-3 behind their first x-half GEMM, whose ring and operand buffers leave no room to hold it meanwhile
+    // attention state of head fw and the LayerNorm parameters of this lane's features
     bf16x8 kvh[2], kvl[2];
-    f32x4 ksm[2];
-    auto load_kv = [&]() {
+    f32x4 ksm[2], g1[2], b1[2], g2[2], b2[2];
+    if (!ONLY_KV) {
         const char* kvb = a.kv[s] + (size_t)b * a.kvbs[s];
 #pragma unroll
         for (int vt = 0; vt < 2; ++vt) {
@@ -230,15 +195,15 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
         const float* kp = reinterpret_cast<const float*>(kvb + KV_FRAG_BYTES) + fw * 32 + 4 * q;
         ksm[0] = *reinterpret_cast<const f32x4*>(kp);
         ksm[1] = *reinterpret_cast<const f32x4*>(kp + 16);
-    };
-#if OPHIP_X3_FORCE_ORDER == 1
-    const bool gemm_first = true;                    // (diagnostic builds: every wave in the same order)
-#elif OPHIP_X3_FORCE_ORDER == 2
-    const bool gemm_first = false;
-#else
-    const bool gemm_first = fwu < 4;                 // waves 0-3 run a (GEMM, vector phase) pair in this order, their SIMD partners 4-7 in the other
-#endif
-    if (!ONLY_KV && !gemm_first) load_kv();
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) {
+            const int f0 = 32 * fw + 16 * ft + 4 * q;
+            g1[ft] = *reinterpret_cast<const f32x4*>(a.ln + f0);
+            b1[ft] = *reinterpret_cast<const f32x4*>(a.ln + C + f0);
+            g2[ft] = *reinterpret_cast<const f32x4*>(a.ln + 2 * C + f0);
+            b2[ft] = *reinterpret_cast<const f32x4*>(a.ln + 3 * C + f0);
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
@@ -248,28 +213,32 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
         const int off = row * ROWB + ((ch ^ (row & 15)) << 4);
         *reinterpret_cast<bf16x8*>(XH + off) = vh;
         *reinterpret_cast<bf16x8*>(XL + off) = vl;
+        if (!ONLY_KV) {                               // exact f32 copy for the residual, parked in the idle hidden planes
+            *reinterpret_cast<f32x4*>(HH + stash_off(row, 2 * ch)) = v0[i];
+            *reinterpret_cast<f32x4*>(HH + stash_off(row, 2 * ch + 1)) = v1[i];
+        }
     }
     __syncthreads();
     if (ONLY_KV) {
         kv_tail(ring, wsk, XH, XL, tok0, L, slab, fw, lane, mk);
         return;
     }
+    f32x4 xr[2][NTT];
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) xr[ft][tt] = *reinterpret_cast<const f32x4*>(HH + stash_off(16 * tt + c16, 8 * fw + 4 * ft + q));
     OPHIP_STAMP(a.stamps, wg, 1);
 
-    // ---- Q projection of head fw ----------------------------------------------------------------------------------------
-    f32x4 qa[2][NTT], hd1[2][NTT];
+    // ---- Q projection of head fw, phi, linear attention from registers -> msg planes (Y) --------------------------------
+    {
+        f32x4 qa[2][NTT];
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft)
+        for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) qa[ft][tt] = zero4();
-    gemm_stage<NTT, 2, 8, true>(qa, ring, wsm, POS_Q + R, XH, XL, ROWB, 0, c16, q);
-    OPHIP_STAMP(a.stamps, wg, 2);
-#pragma unroll
-    for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) hd1[ft][tt] = zero4();
-    // ---- phi, linear attention from registers -> msg planes (Y)  ||  x-half of the MLP's hidden chunk 1 (reads X only) ----------------
-    auto attention = [&]() {
+            for (int tt = 0; tt < NTT; ++tt) qa[ft][tt] = zero4();
+        gemm_stage<NTT, 2, 8, true>(qa, ring, wsm, 0 + R, XH, XL, ROWB, 0, c16, q);
+        OPHIP_STAMP(a.stamps, wg, 2);
         const float S = a.srclen[s];
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) {
@@ -295,82 +264,56 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
                 store_quad(num, YH, YL, ROWB, tt, c16, 32 * fw + 16 * vt + 4 * q);
             }
         }
-    };
-    if (gemm_first) {
-        gemm_stage<NTT, 2, 8, true>(hd1, ring, wsm, POS_W0C1X + R, XH, XL, ROWB, 0, c16, q);
-        load_kv();
-        attention();
-    } else {
-        attention();
-        gemm_stage<NTT, 2, 8, true>(hd1, ring, wsm, POS_W0C1X + R, XH, XL, ROWB, 0, c16, q);
     }
     __syncthreads();
     OPHIP_STAMP(a.stamps, wg, 3);
 
-    // ---- merge; LayerNorm 1 -> Y  ||  x-half of hidden chunk 0 ----------------------------------------------------------------------
-    f32x4 hd0[2][NTT];
+    // ---- merge + LayerNorm 1 -> Y --------------------------------------------------------------------------------------
     {
         f32x4 m[2][NTT];
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
             for (int tt = 0; tt < NTT; ++tt) m[ft][tt] = zero4();
-        gemm_stage<NTT, 2, 8, true>(m, ring, wsm, POS_M + R, YH, YL, ROWB, 0, c16, q);
+        gemm_stage<NTT, 2, 8, true>(m, ring, wsm, 32 + R, YH, YL, ROWB, 0, c16, q);
         OPHIP_STAMP(a.stamps, wg, 4);
-        f32x4 g1[2], b1[2];
-#pragma unroll
-        for (int ft = 0; ft < 2; ++ft) {
-            const int f0 = 32 * fw + 16 * ft + 4 * q;
-            g1[ft] = *reinterpret_cast<const f32x4*>(a.ln + f0);
-            b1[ft] = *reinterpret_cast<const f32x4*>(a.ln + C + f0);
-        }
-        {
-            float sm[NTT], dm[NTT];
-            wave_moments<NTT, 2>(m, sm, dm);
-            publish_moments(scratch, sm, dm, fw, c16, q);
-        }
+        float sm[NTT], dm[NTT];
+        wave_moments<NTT, 2>(m, sm, dm);
+        publish_moments(scratch, sm, dm, fw, c16, q);
         __syncthreads();                             // moments visible; every wave is done reading the msg planes
 #pragma unroll
-        for (int ft = 0; ft < 2; ++ft)
+        for (int tt = 0; tt < NTT; ++tt) {
+            float mean, rstd;
+            merged_stats(scratch, tt, c16, mean, rstd);
 #pragma unroll
-            for (int tt = 0; tt < NTT; ++tt) hd0[ft][tt] = zero4();
-        auto ln1 = [&]() {
+            for (int ft = 0; ft < 2; ++ft) {
+                f32x4 v;
 #pragma unroll
-            for (int tt = 0; tt < NTT; ++tt) {
-                float mean, rstd;
-                merged_stats(scratch, tt, c16, mean, rstd);
-#pragma unroll
-                for (int ft = 0; ft < 2; ++ft) {
-                    f32x4 v;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = (m[ft][tt][r] - mean) * rstd * g1[ft][r] + b1[ft][r];
-                    store_quad(v, YH, YL, ROWB, tt, c16, 32 * fw + 16 * ft + 4 * q);
-                }
+                for (int r = 0; r < 4; ++r) v[r] = (m[ft][tt][r] - mean) * rstd * g1[ft][r] + b1[ft][r];
+                store_quad(v, YH, YL, ROWB, tt, c16, 32 * fw + 16 * ft + 4 * q);
             }
-        };
-#if OPHIP_X3_PAIR_LN1
-        if (gemm_first) {
-            gemm_stage<NTT, 2, 8, true>(hd0, ring, wsm, POS_W0C0X + R, XH, XL, ROWB, 0, c16, q);
-            ln1();
-        } else {
-            ln1();
-            gemm_stage<NTT, 2, 8, true>(hd0, ring, wsm, POS_W0C0X + R, XH, XL, ROWB, 0, c16, q);
         }
-#else
-        // (the LayerNorm 1 / chunk-0 x-half pair in opposite orders as well needs m, hd0 AND hd1 live beside a GEMM's ring and operand
-        //  buffers: 49 spilled registers.  Built with -DOPHIP_X3_PAIR_LN1=1 for the measurement in DESIGN.md; the shipped kernel pairs the
-        //  attention block only and runs this phase in step)
-        ln1();
-        gemm_stage<NTT, 2, 8, true>(hd0, ring, wsm, POS_W0C0X + R, XH, XL, ROWB, 0, c16, q);
-#endif
     }
     __syncthreads();
     OPHIP_STAMP(a.stamps, wg, 5);
 
-    // ---- MLP: hidden = relu([x, msg] W0^T) in two 256-feature chunks (x-halves above), o += hidden_chunk W2[:, chunk]^T -----------------
+    // ---- MLP: hidden = relu([x, msg] W0^T) in two 256-feature chunks, o += hidden_chunk W2[:, chunk]^T ------------------------
     f32x4 o[2][NTT];
-    auto store_hidden = [&](const f32x4 (&hd)[2][NTT]) {
-        const int ln = opaque_lane(lane), c16s = ln & 15, qs = ln >> 4;
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) o[ft][tt] = zero4();
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        f32x4 hd[2][NTT];
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt) hd[ft][tt] = zero4();
+        const int pos = 64 + 96 * c;                 // W0 chunk c: 64 fragments (x half 32, msg half 32), then W2 chunk c: 32
+        gemm_stage<NTT, 2, 8, true>(hd, ring, wsm, pos + R, XH, XL, ROWB, 0, c16, q);
+        gemm_stage<NTT, 2, 8, true>(hd, ring, wsm, pos + 32 + R, YH, YL, ROWB, 0, c16, q);
+        if (c == 1) __syncthreads();                 // every wave is done reading chunk 0 of the hidden planes
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
@@ -378,51 +321,15 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
                 f32x4 v;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(hd[ft][tt][r], 0.f);
-                store_quad(v, HH, HL, ROWB, tt, c16s, 32 * fwu + 16 * ft + 4 * qs);
+                store_quad(v, HH, HL, ROWB, tt, c16, 32 * fw + 16 * ft + 4 * q);
             }
-    };
-    gemm_stage<NTT, 2, 8, true>(hd0, ring, wsm, POS_W0C0M + R, YH, YL, ROWB, 0, c16, q);
-    // store of hidden chunk 0 (vector work)  ||  msg-half of chunk 1 (reads Y, writes registers): opposite order on the two waves of a SIMD
-#if OPHIP_X3_PAIR_HSTORE
-    if (gemm_first) {
-        gemm_stage<NTT, 2, 8, true>(hd1, ring, wsm, POS_W0C1M + R, YH, YL, ROWB, 0, c16, q);
-        store_hidden(hd0);
-    } else {
-        store_hidden(hd0);
-        gemm_stage<NTT, 2, 8, true>(hd1, ring, wsm, POS_W0C1M + R, YH, YL, ROWB, 0, c16, q);
+        __syncthreads();
+        OPHIP_STAMP(a.stamps, wg, 6 + 2 * c);
+        // W2 chunk c; the main stream ends inside chunk 1: its last 16 refills pull the head of the next layer's K|V stream
+        if (c == 0) gemm_stage<NTT, 2, 8, true>(o, ring, wsm, pos + 64 + R, HH, HL, ROWB, 0, c16, q);
+        else gemm_stage<NTT, 2, 8, true>(o, ring, wsm, pos + 64 + R, HH, HL, ROWB, 0, c16, q, 32 - R, &wsk, 0);
+        OPHIP_STAMP(a.stamps, wg, 7 + 2 * c);
     }
-#else
-    store_hidden(hd0);
-    gemm_stage<NTT, 2, 8, true>(hd1, ring, wsm, POS_W0C1M + R, YH, YL, ROWB, 0, c16, q);
-#endif
-    __syncthreads();
-    OPHIP_STAMP(a.stamps, wg, 6);
-#pragma unroll
-    for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) o[ft][tt] = zero4();
-    gemm_stage<NTT, 2, 8, true>(o, ring, wsm, POS_W2C0 + R, HH, HL, ROWB, 0, c16, q);
-    OPHIP_STAMP(a.stamps, wg, 7);
-    __syncthreads();                                 // every wave is done reading chunk 0 of the hidden planes
-    store_hidden(hd1);
-    __syncthreads();
-    OPHIP_STAMP(a.stamps, wg, 8);
-    // LayerNorm 2's parameters and the residual rows (exact f32, straight from the layer's input: L2-resident) travel under the last GEMM
-    f32x4 g2[2], b2[2], xr[2][NTT];
-#pragma unroll
-    for (int ft = 0; ft < 2; ++ft) {
-        const int f0 = 32 * fw + 16 * ft + 4 * q;
-        g2[ft] = *reinterpret_cast<const f32x4*>(a.ln + 2 * C + f0);
-        b2[ft] = *reinterpret_cast<const f32x4*>(a.ln + 3 * C + f0);
-#pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) {
-            const int tok = tok0 + 16 * tt + c16;
-            xr[ft][tt] = tok < L ? *reinterpret_cast<const f32x4*>(xg + (size_t)tok * C + f0) : zero4();
-        }
-    }
-    // W2 chunk 1; the main stream ends inside it: its last 16 refills pull the head of the next layer's K|V stream
-    gemm_stage<NTT, 2, 8, true>(o, ring, wsm, POS_W2C1 + R, HH, HL, ROWB, 0, c16, q, 32 - R, &wsk, 0);
-    OPHIP_STAMP(a.stamps, wg, 9);
 
     // ---- LayerNorm 2, residual, output rows (and their planes for the fused K|V tail) -----------------------------------
     {
@@ -450,19 +357,8 @@ __global__ __launch_bounds__(512) OPHIP_WAVES_PER_SIMD(2, 2) void enc_x3w8_kerne
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft) {
             f32x4 v;
-            {
-                // ONE evaluation of the output row: it goes to memory AND (hi, lo split) into the planes the fused K|V tail reads, and the
-                // next layer's stand-alone K / V half must see the very same bits in memory (test_encoder_x3_chain_with_fused_kv_tail: the
-                // fused tail == the stand-alone launch).  Under -ffp-contract=fast the compiler is free to evaluate the expression once
-                // per use with different fused multiply-adds (seen in round 5 after the phases were re-ordered: slabs off by an ulp of
-                // their inputs); the empty asm pins the four values
-                float e0 = xr[ft][tt][0] + ((o[ft][tt][0] - mean) * rstd * g2[ft][0] + b2[ft][0]);
-                float e1 = xr[ft][tt][1] + ((o[ft][tt][1] - mean) * rstd * g2[ft][1] + b2[ft][1]);
-                float e2 = xr[ft][tt][2] + ((o[ft][tt][2] - mean) * rstd * g2[ft][2] + b2[ft][2]);
-                float e3 = xr[ft][tt][3] + ((o[ft][tt][3] - mean) * rstd * g2[ft][3] + b2[ft][3]);
-                asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));
-                v = f32x4{e0, e1, e2, e3};
-            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = xr[ft][tt][r] + ((o[ft][tt][r] - mean) * rstd * g2[ft][r] + b2[ft][r]);
             if (tok < L) *reinterpret_cast<f32x4*>(yg + (size_t)tok * C + 32 * fw + 16 * ft + 4 * q) = v;
             else v = zero4();
             if (tail) store_quad(v, XH, XL, ROWB, tt, c16, 32 * fw + 16 * ft + 4 * q);

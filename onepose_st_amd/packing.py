@@ -146,24 +146,15 @@ def pack_fine_layers_bf16(sd: dict, prefix: str, n_layers: int) -> torch.Tensor:
     return out
 
 
-# where each GEMM stage of a wave's main stream starts, in program ENTRIES (one entry = one 16-feature tile of one k-step = a (hi, lo)
-# fragment pair; a stage is 8 k-steps x 2 tiles = 16 entries = 32 fragments).  Round 5 order: the two x-halves of the MLP's first layer
-# depend on the layer's INPUT rows only, so they sit right behind the two phases without matrix work they can run beside -- W0 chunk 1's
-# behind Q (beside the attention block), chunk 0's behind merge (beside LayerNorm 1) -- and chunk 1's msg-half, which reads LayerNorm 1's
-# output only, runs beside the store of hidden chunk 0 -- see csrc/encoder_x3w8.hip.
-X3W8_STAGES = {"q": 0, "w0c1x": 16, "m": 32, "w0c0x": 48, "w0c0m": 64, "w0c1m": 80, "w2c0": 96, "w2c1": 112}
-
-
 def x3w8_program(fw: int):
     """(main, kv) entries for wave ``fw`` (= head fw) of the 8-wave kernel csrc/encoder_x3w8.hip: each wave owns 32 output features
-    (two tiles) of every stage; the MLP's hidden layer goes in two 256-wide chunks through one hidden buffer:
-    Q | W0c1 x-half | merge | W0c0 x-half | W0c0 msg-half | W0c1 msg-half | W2c0 | W2c1 (``X3W8_STAGES``)."""
+    (two tiles) of every stage; the MLP's hidden layer goes in two 256-wide chunks: Q | merge | W0c0 | W2c0 | W0c1 | W2c1."""
     def gemm(mat, rows, k0, ksteps):
         return [(mat, r0, k0 + 32 * ks) for ks in range(ksteps) for r0 in rows]
     rows = [32 * fw + 16 * ft for ft in range(2)]
-    rows_c = [[256 * c + r0 for r0 in rows] for c in range(2)]
-    main = (gemm("q", rows, 0, 8) + gemm("w0", rows_c[1], 0, 8) + gemm("m", rows, 0, 8) + gemm("w0", rows_c[0], 0, 8)
-            + gemm("w0", rows_c[0], 256, 8) + gemm("w0", rows_c[1], 256, 8) + gemm("w2", rows, 0, 8) + gemm("w2", rows, 256, 8))
+    main = gemm("q", rows, 0, 8) + gemm("m", rows, 0, 8)
+    for c in range(2):
+        main += gemm("w0", [256 * c + r0 for r0 in rows], 0, 16) + gemm("w2", rows, 256 * c, 8)
     kv = [(("k" if ft < 2 else "v"), 32 * fw + 16 * (ft & 1), 32 * ks) for ks in range(8) for ft in range(4)]
     assert 2 * len(main) == 256 and 2 * len(kv) == 64
     return main, kv

@@ -75,15 +75,13 @@ def test_stream_gemm_weights_as_a_and_quad_store_roundtrip():
     np.testing.assert_allclose(out, ref, atol=1e-9)
     back = np.stack([np.concatenate([dst.read16(E.plane_off(row, ch, 512)) for ch in range(32)]) for row in range(48)])
     np.testing.assert_allclose(back, ref, atol=1e-9)
-    # merge stage of the same stream
-    m0 = packing.X3W8_STAGES["m"]
-    acc = gemm_stage(packing.x3w8_program(5)[0][m0:m0 + 16], mats, px, 2, 8, True)
+    # merge stage = entries 16..31 of the same stream
+    acc = gemm_stage(packing.x3w8_program(5)[0][16:32], mats, px, 2, 8, True)
     np.testing.assert_allclose(acc[1][2][:, 0], (x @ mats["m"].T)[32 + C16, 32 * 5 + 16 + 4 * Q], atol=1e-9)
 
 
 def test_mlp_chunk_order_of_the_stream():
-    """256-wide hidden chunks through ONE hidden buffer; a chunk's x-half k-steps run ahead of its msg-half k-steps (same accumulators:
-    chunk 1's x-half right behind Q, chunk 0's behind merge), W2 chunk c follows the store of hidden chunk c (packing.X3W8_STAGES)"""
+    """W0c0 | W2c0 | W0c1 | W2c1: 256-wide hidden chunks through ONE hidden buffer, x-half then msg-half k-steps"""
     mats = mats_random(2)
     g = np.random.default_rng(3)
     x, msg = g.normal(size=(48, 256)), g.normal(size=(48, 256))
@@ -91,28 +89,25 @@ def test_mlp_chunk_order_of_the_stream():
     px.load_rows(x), py.load_rows(msg)
     hidden_ref = np.maximum(np.concatenate([x, msg], 1) @ mats["w0"].T, 0.0)
     out_ref = hidden_ref @ mats["w2"].T
-    S = packing.X3W8_STAGES
-    order = sorted(S, key=S.get)
-    assert order == ["q", "w0c1x", "m", "w0c0x", "w0c0m", "w0c1m", "w2c0", "w2c1"] and [S[n] for n in order] == list(range(0, 128, 16))
-    streams = [packing.x3w8_program(fw)[0] for fw in range(8)]
-    stage = lambda fw, name: streams[fw][S[name]:S[name] + 16]
-    # the x-halves first (they only read the input rows), kept in the accumulators
-    hd = [[gemm_stage(stage(fw, f"w0c{c}x"), mats, px, 2, 8, True) for fw in range(8)] for c in range(2)]
+    streams = [packing.x3w8_program(fw)[0][32:] for fw in range(8)]
     o = [[[np.zeros((64, 4)) for _ in range(NTT)] for _ in range(2)] for _ in range(8)]
     for c in range(2):
         hbuf = E.Plane(48, 512)
+        pos = 48 * c
         for fw in range(8):
-            b = gemm_stage(stage(fw, f"w0c{c}m"), mats, py, 2, 8, True)
+            prog = streams[fw][pos:pos + 32]
+            a = gemm_stage(prog[:16], mats, px, 2, 8, True)
+            b = gemm_stage(prog[16:], mats, py, 2, 8, True)
             for ft in range(2):
                 for tt in range(NTT):
                     for l in range(64):
-                        store_quad(hbuf, np.maximum(hd[c][fw][ft][tt][l] + b[ft][tt][l], 0), tt, l, 32 * fw + 16 * ft + 4 * Q[l])
+                        store_quad(hbuf, np.maximum(a[ft][tt][l] + b[ft][tt][l], 0), tt, l, 32 * fw + 16 * ft + 4 * Q[l])
         for fw in range(8):
-            a = gemm_stage(stage(fw, f"w2c{c}"), mats, hbuf, 2, 8, True)
+            a = gemm_stage(streams[fw][pos + 32:pos + 48], mats, hbuf, 2, 8, True)
             for ft in range(2):
                 for tt in range(NTT):
                     o[fw][ft][tt] += a[ft][tt]
-    assert all(len(st) == 128 for st in streams)
+    assert all(len(st) == 96 for st in streams)
     out = np.zeros((48, 256))
     for fw in range(8):
         for ft in range(2):

@@ -10,6 +10,7 @@
 #   stamps           in-kernel cycle stamps of attn_apply, the fine stage (two and one workgroup per CU) and the similarity tiles
 #   stats            rocprofv3 --kernel-trace --stats of the contract's region alone (c2) and of config 4, + the timeline
 #   pmc              counter passes, each in its own run (FETCH_SIZE | WRITE_SIZE | matrix-pipe busy | L2 hit / miss) + the summaries
+#   counters         the counter names rocprofv3 offers on the box (gpurun_out/<out>/counters.txt)
 #   ranks            the N > 1 code path on this one-GPU box: two gloo ranks sharing the device; RCCL with one rank
 #   ab:<rounds>:<steps>:<variant>[:<variant>...]   interleaved A/B of bench.py (main region only); a variant is "-" (shipped build) or a
 #                    comma-separated list of NAME=VALUE environment assignments (OPHIP_LIB=onepose_st_amd/lib/variants/lib....so picks a variant build)
@@ -107,6 +108,9 @@ for step in "$@"; do
       e="${A[0]//,/ }"; n=$(basename ${A[1]} .py)_$(echo "${A[0]}" | tr -c 'A-Za-z0-9\n' '_')
       env $e timeout -k 10 400 python3 "${A[@]:1}" > $O/$n.txt 2>&1 || { tail -8 $O/$n.txt; exit 1; }
       echo "[${A[0]}]"; tail -20 $O/$n.txt ;;
+    counters)
+      rocprofv3 --list-avail > $O/counters_all.txt 2>&1 || rocprofv3 -L > $O/counters_all.txt 2>&1 || true
+      grep -o -E "\b(SQ|TCC|TCP|GRBM|TA|TD)_[A-Z0-9_]+" $O/counters_all.txt | sort -u > $O/counters.txt; wc -l $O/counters.txt; grep -E "SQ_INSTS|SQ_ACTIVE_INST|SQ_INST_CYCLES|SQ_VALU|SQ_WAIT_INST|SQ_BUSY_CY" $O/counters.txt | tr '\n' ' ' ;;
     pt:*)
       IFS=: read -r -a A <<< "${step#pt:}"
       if [ "${A[0]}" = "-" ]; then e=""; else e="${A[0]//,/ }"; fi

@@ -35,8 +35,8 @@ buf = torch.zeros(nwg * 32, dtype=torch.int64, device=dev)
 for _ in range(50): run()
 hip.call("ophip_debug_stamps", ctypes.c_void_p(buf.data_ptr())); run(); torch.cuda.synchronize(); hip.call("ophip_debug_stamps", None)
 s = buf.view(-1, 32)[:nwg].cpu().numpy().astype(np.int64)
-names = ["start", "rows in + ring fill + stage + sync", "Q gemm", "W0c1 x-half gemm || attention + msg store, sync", "merge gemm", "LN1 + store, W0c0 x-half gemm, sync",
-         "W0c0 msg-half + hidden store + sync", "W2c0", "W0c1 msg-half + sync + hidden store + sync", "W2c1", "LN2 + residual + store", "K|V tail"]
+names = ["start", "rows in + ring fill + stage + sync", "Q gemm", "attention + msg store + sync", "merge gemm", "LN1 + store + sync",
+         "W0c0 + hidden store + sync", "W2c0", "W0c1 + sync + hidden store + sync", "W2c1", "LN2 + residual + store", "K|V tail"]
 last = len(names) - 1
 d = s[:, last] - s[:, 0]
 print("library build", hip.build_stamp())
