@@ -552,7 +552,7 @@ __global__ __launch_bounds__(256) OPHIP_WAVES_PER_SIMD(1, 2) void sim_frag_kerne
 }
 
 
-// ---- round 5: the same tile with THREE workgroups per CU ------------------------------------------------------------------------------
+// ---- round 5: the same tile with THREE workgroups per CU (opt-in: OPHIP_SIM_TILE=3; see the measurement at its launch site) --------------
 // sim_frag_kernel holds 69.7 KB of LDS (four 16 KiB operand buffers, overlaid by the 67.6 KB staging image of the whole tile): two
 // workgroups per CU.  Its stamps (profiles/r02-r04) show a k-loop at the matrix pipe's rate and an epilogue of the same length that no
 // matrix work covers, and 2 090 tiles on 512 slots are 4.08 rounds that cost 5.  This form keeps the tile, the wave split and the
@@ -1296,9 +1296,13 @@ int coarse_impl(int parts, int border_mode, int wi, double temp_eps,
             if (int rc = ophip_lds_attr(reinterpret_cast<const void*>(sim_frag_kernel<NS_, MODE_>), SIM_FRAG_LDS, "hipFuncSetAttribute(sim_frag)")) return rc; \
             OPHIP_LAUNCH(NAME_, stream, (sim_frag_kernel<NS_, MODE_>), dim3(8 * per_xcd, B), dim3(256), SIM_FRAG_LDS, stream, sf);    \
         }
-        // OPHIP_SIM_TILE=2: round 2-4's kernel (two workgroups per CU, four operand buffers); default 3: three per CU (sim_frag3_kernel)
+        // Default: sim_frag_kernel (two workgroups per CU, four operand buffers).  OPHIP_SIM_TILE=3: sim_frag3_kernel (three per CU).  Measured in
+        // round 5: the three-per-CU form moves a tile ~10 % faster (stage kernels of BASELINE config 4: 422 against 441 us,
+        // 523 against 563 us) and LOSES in the pipeline -- config 2: -1 %, config 4: 319 against 394 frames/s -- because three of its
+        // workgroups take 154 of a CU's 160 KB of LDS and 480 of 512 registers per lane: the next frame's input kernels (the fine map's
+        // transpose needs 17 KB of LDS), which used to run BESIDE the similarity tiles, now wait for them.
         const char* tile_env = getenv("OPHIP_SIM_TILE");          // (read per call: tests compare the two tile kernels in one process)
-        const bool tile3 = !(tile_env && tile_env[0] == '2');
+        const bool tile3 = tile_env && tile_env[0] == '3';
 #define OPHIP_SIM3_CASE(NS_, MODE_)                                                                                                \
         {                                                                                                                          \
             if (int rc = ophip_lds_attr(reinterpret_cast<const void*>(sim_frag3_kernel<NS_, MODE_>), SIM_F3_LDS, "hipFuncSetAttribute(sim_frag3)")) return rc; \

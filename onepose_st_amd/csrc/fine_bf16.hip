@@ -72,6 +72,19 @@ struct FineBArgs {
 // strip like k3 / v3 below) -- one reciprocal per head and token instead of one per element.  The reference's v / v_length ... * v_length
 // (an fp16 overflow guard, linear_attention.py:52,59) cancels in f32 and is not applied.
 //   3D set: ONE source token, so KV = phi(k3)^T v3 has rank one and the message is v3 * a / (a + eps) with a[token][head] = phi(q) . phi(k3).
+// sum over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15), result in all of them
+__device__ __forceinline__ float row16_sum_dpp(float v) {
+    v += dpp_f<0xB1>(v);
+    v += dpp_f<0x4E>(v);
+    v += dpp_f<0x141>(v);
+    v += dpp_f<0x140>(v);
+    return v;
+}
+
+// Round 5, "cross" layers: the window set is attended to by ONE token (the 3D point), so the two small matrix products above -- 29 exact-f32
+// matrix instructions = 1 856 pipe cycles per match and layer, a tenth of the stage's matrix work -- shrink to a matrix-vector chain on the
+// vector ALU: a[t][head] = phi(q3) . phi(k_t) (13 products per lane, summed over the 16 lanes of a head by DPP), message[f] = sum_t a_t v_t[f] /
+// (sum_t a_t + eps).  phi(q3) reaches the lanes by feature and the message reaches the 3D token's lanes through the wave's LDS strip.
 template <int NS>
 __device__ __forceinline__ f32x16 attend_match(f32x16& qt, const f32x16& kt, const f32x16& vt, bool cross, float* strip, int lane) {
 #pragma clang fp contract(off)                    // every fused multiply-add below is written out: the one-match and the pair kernel stay bit-identical
@@ -87,45 +100,72 @@ __device__ __forceinline__ f32x16 attend_match(f32x16& qt, const f32x16& kt, con
     for (int t = 0; t < 12; ++t) kw[t] = elu_plus_one_fast(kt[t]);
     kw[12] = h == 0 ? elu_plus_one_fast(kt[12]) : 0.f;
     // strip (96 floats of this wave): [0, 32) phi(k3), [32, 64) v3 (row 25 = register 13 of lanes 0..31, one feature per lane), [64, 96) Ksum
+    // ("cross": phi(q3) by feature, then the 3D token's message by feature)
     if (h == 0) {
         strip[r] = elu_plus_one_fast(kt[13]);
         strip[32 + r] = vt[13];
     }
-    f32x16 kvw = zero16();
-    float ks = 0.f;
-#pragma unroll
-    for (int t = 0; t < 13; ++t) {
-        kvw = __builtin_amdgcn_mfma_f32_32x32x2f32(kw[t], vt[t], kvw, 0, 0, 0);
-        ks += kw[t];
-    }
-    ks += __shfl_xor(ks, 32, 64);
-    if (h == 0) strip[64 + r] = ks;
     f32x16 n0 = zero16(), n1 = zero16();
+    float d0 = 0.f, d1 = 0.f;
+    if (!cross) {
+        f32x16 kvw = zero16();
+        float ks = 0.f;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {                 // (two independent chains: the second head's instruction issues behind the first's)
-        n0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kvw[t], qt[t], n0, 0, 0, 0);
-        n1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kvw[8 + t], qt[8 + t], n1, 0, 0, 0);
+        for (int t = 0; t < 13; ++t) {
+            kvw = __builtin_amdgcn_mfma_f32_32x32x2f32(kw[t], vt[t], kvw, 0, 0, 0);
+            ks += kw[t];
+        }
+        ks += __shfl_xor(ks, 32, 64);
+        if (h == 0) strip[64 + r] = ks;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {             // (two independent chains: the second head's instruction issues behind the first's)
+            n0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kvw[t], qt[t], n0, 0, 0, 0);
+            n1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kvw[8 + t], qt[8 + t], n1, 0, 0, 0);
+        }
+    } else {
+        if (is3d) {                               // lanes 25 and 57: phi(q3) of feature acc_row(reg, h) sits in register reg
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) strip[64 + acc_row(reg, h)] = qt[reg];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float q3r = strip[64 + r];          // of THIS lane's feature (K, V tiles: one feature per lane)
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int t = 0; t < 13; ++t) {
+            const float a_t = row16_sum_dpp(kw[t] * q3r);      // phi(q3) . phi(k_t) over the 16 features of this lane's head
+            num = __builtin_fmaf(a_t, vt[t], num);
+            den += a_t;
+        }
+        num = swap32_sum(num);                    // the two halves hold different tokens
+        den = swap32_sum(den);
+        const float m3 = num * rcp_fast(den + 1e-6f);
+        __builtin_amdgcn_wave_barrier();
+        if (h == 0) strip[64 + r] = m3;           // (behind every lane's read of phi(q3): LDS operations of one wave complete in order)
     }
     // this lane's 16 features (acc_row(reg, h) = 8 (reg >> 2) + 4 h + (reg & 3): four 16-byte reads per table) of Ksum, phi(k3), v3
     __builtin_amdgcn_wave_barrier();              // (LDS operations of one wave complete in order: only the compiler needs the fence)
-    float d0 = 0.f, d1 = 0.f, a0 = 0.f, a1 = 0.f;
+    float a0 = 0.f, a1 = 0.f;
+    f32x4 third[4];                               // "self": Ksum, "cross": the 3D token's message -- this lane's 16 features of the strip's last table
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const f32x4 k3 = *reinterpret_cast<const f32x4*>(strip + 8 * g + 4 * h);
-        const f32x4 kq = *reinterpret_cast<const f32x4*>(strip + 64 + 8 * g + 4 * h);
+        third[g] = *reinterpret_cast<const f32x4*>(strip + 64 + 8 * g + 4 * h);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (g < 2) { a0 = __builtin_fmaf(qt[4 * g + j], k3[j], a0); d0 = __builtin_fmaf(qt[4 * g + j], kq[j], d0); }      // features 0..15 of the tile: its first head
-            else { a1 = __builtin_fmaf(qt[4 * g + j], k3[j], a1); d1 = __builtin_fmaf(qt[4 * g + j], kq[j], d1); }
+            if (g < 2) { a0 = __builtin_fmaf(qt[4 * g + j], k3[j], a0); if (!cross) d0 = __builtin_fmaf(qt[4 * g + j], third[g][j], d0); }      // features 0..15 of the tile: its first head
+            else { a1 = __builtin_fmaf(qt[4 * g + j], k3[j], a1); if (!cross) d1 = __builtin_fmaf(qt[4 * g + j], third[g][j], d1); }
         }
     }
     a0 += __shfl_xor(a0, 32, 64);
     a1 += __shfl_xor(a1, 32, 64);
-    d0 += __shfl_xor(d0, 32, 64);
-    d1 += __shfl_xor(d1, 32, 64);
-    // per token and head: Z of the set this token attends to (use_w: 1 / (phi(q).Ksum + eps) on the matrix result; else a / (a + eps) on v3)
-    const float z0 = use_w ? rcp_fast(d0 + 1e-6f) : a0 * rcp_fast(a0 + 1e-6f);
-    const float z1 = use_w ? rcp_fast(d1 + 1e-6f) : a1 * rcp_fast(a1 + 1e-6f);
+    if (!cross) {
+        d0 += __shfl_xor(d0, 32, 64);
+        d1 += __shfl_xor(d1, 32, 64);
+    }
+    // per token and head: Z of the set this token attends to ("self" window tokens: 1 / (phi(q).Ksum + eps) on the matrix result; a token that
+    // attends to the 3D point: a / (a + eps) on v3; the 3D token of a "cross" layer: its message is complete)
+    const float z0 = (use_w && !cross) ? rcp_fast(d0 + 1e-6f) : a0 * rcp_fast(a0 + 1e-6f);
+    const float z1 = (use_w && !cross) ? rcp_fast(d1 + 1e-6f) : a1 * rcp_fast(a1 + 1e-6f);
     f32x16 out;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -134,7 +174,8 @@ __device__ __forceinline__ f32x16 attend_match(f32x16& qt, const f32x16& kt, con
         for (int j = 0; j < 4; ++j) {
             const int reg = 4 * g + j;
             const float nm = g < 2 ? n0[reg] : n1[reg];
-            out[reg] = (use_w ? nm : v3[j]) * (g < 2 ? z0 : z1);
+            const float viaw = cross ? third[g][j] : nm * (g < 2 ? z0 : z1);
+            out[reg] = use_w ? viaw : v3[j] * (g < 2 ? z0 : z1);
         }
     }
     __builtin_amdgcn_wave_barrier();              // the strip is rewritten by this wave's next match

@@ -384,13 +384,17 @@ class OnePosePlus_model(nn.Module):
                 and (self.kpt_3d_pos_encoding is not None or B == 1 or desc_in_d.shape[0] == B)
                 and len(self.loftr_coarse.layer_names) <= 16):
             x3d_ext = None
-            if self.cache_object:
+            shared_batch = B > 1 and kpts_d.shape[0] == 1 and desc_in_d.shape[0] == 1
+            if self.cache_object or shared_batch:
                 # the reference keeps the object block resident across frames (OnePosePlus_inference_dataset.py:157-169): what depends on it
                 # and the weights alone is computed once per (object tensors, weights) and handed to the frame call -- the keypoint encoding
                 # (rows a2 + a3) and, with a first layer of kind "self", that layer's 3D rows and the K^T V | Ksum block of those rows as the
                 # second layer's source (transformer.py:148-159; ophip_encoder_object_x3w8: the frame's own launches on the 3D stream's
                 # workgroups, so a cached frame is bit-identical).  One entry serves the whole batch when it shares one object (config 3).
-                x3d_ext = self._object_cache_entry(kpts_d, desc_in_d, W, dev, B, N, main, masked=qmask is not None)
+                # A batch whose frames share ONE object block (stride-0 expand: BASELINE config 3) takes the same route WITHOUT the cache flag:
+                # the object-only work is then done once per CALL instead of once per frame of the batch -- nothing is kept for the next call
+                # (`keep=False`), so a forward still does all of its own work.
+                x3d_ext = self._object_cache_entry(kpts_d, desc_in_d, W, dev, B, N, main, masked=qmask is not None, keep=self.cache_object)
             return self._enqueue_frame_call(data, feat_c, feat_f, kpts_d, desc_in_d, desc_fine_d, x3d_ext, W, dev, main, fkey,
                                             B, N, M, hc, wc, hf, wf, host_copy, inputs_ready, lazy, rerun, qmask, qscale)
         if fkey in self._frame_call_pending:                          # order this frame's encoder behind the C path's last fine stage
@@ -592,7 +596,7 @@ class OnePosePlus_model(nn.Module):
         return pend
 
 
-    def _object_cache_entry(self, kpts_d, desc_in_d, W, dev, B, N, stream, masked=False):
+    def _object_cache_entry(self, kpts_d, desc_in_d, W, dev, B, N, stream, masked=False, keep=True):
         """The object's cache entry ``{"x3d", "y3d0", "kv1", "ev"}`` (``ophip_object_cache``), built on a miss on ``stream`` with the kernels a
         frame would run.  Keyed on the object tensors' storage + version and the packed weights; ``Bo`` = 1 rows when the batch shares one
         object block (stride-0 expand / batch-1 tensors under a larger query batch), else B."""
@@ -606,7 +610,7 @@ class OnePosePlus_model(nn.Module):
         #  with that instantiation, see ophip_encoder_object_x3w8)
         ckey = (str(dev), Bo, N, kpts_d.data_ptr(), kpts_d._version, desc_in_d.data_ptr(), desc_in_d._version, id(W), deep, bool(masked) and deep)
         ent = self._obj_cache
-        if ent is not None and ent["key"] == ckey:
+        if keep and ent is not None and ent["key"] == ckey:
             return ent
         f32 = dict(device=dev, dtype=torch.float32)
         with torch.cuda.stream(stream):
@@ -628,7 +632,9 @@ class OnePosePlus_model(nn.Module):
                          P(y3d0), P(kv1, None), 1 if masked else 0, hip.stream_handle())
             ev = torch.cuda.Event()
             ev.record(stream)
-        self._obj_cache = ent = {"key": ckey, "x3d": x3d, "y3d0": y3d0, "kv1": kv1, "ev": ev, "keep": (kpts_d, desc_in_d, W)}      # the key's tensors stay alive with the entry
+        ent = {"key": ckey, "x3d": x3d, "y3d0": y3d0, "kv1": kv1, "ev": ev, "keep": (kpts_d, desc_in_d, W)}      # the key's tensors stay alive with the entry
+        if keep:
+            self._obj_cache = ent
         return ent
 
     def flush(self):

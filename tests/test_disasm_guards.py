@@ -89,7 +89,7 @@ def test_sim_frag_k_loop_keeps_its_wait_barrier_and_ring_discipline(device_asm):
 
 
 def test_sim_frag3_k_loop_keeps_its_wait_barrier_and_ring_discipline(device_asm):
-    """The three-buffer tile kernel (sim_frag3_kernel, the default since round 5): chunks run TWO k-steps ahead, so step s waits with
+    """The three-buffer tile kernel (sim_frag3_kernel, OPHIP_SIM_TILE=3): chunks run TWO k-steps ahead, so step s waits with
     vmcnt(G) (chunk s + 1 may stay in flight; vmcnt(0) in the last step), exactly the pieces of chunks 0 .. s + 1 have been issued when it
     waits, chunk s + 2 is issued behind the barrier into buffer (s + 2) % 3 = the one read in step s - 1, and step s reads buffer s % 3 only."""
     ks = {k: v for k, v in device_asm.items() if "sim_frag3_kernel" in k}

@@ -339,8 +339,8 @@ def test_coarse_match_vs_oracle(dev, B, N, hc, wc, nsplit, rtol):
 @pytest.mark.parametrize("nsplit", [3, 1])
 @pytest.mark.parametrize("B,N,hc,wc", [(1, 300, 10, 13), (2, 129, 9, 9), (1, 1000, 30, 40), (1, 1408, 24, 32)])
 def test_coarse_match_tile_kernels_and_two_pass_form_agree(dev, monkeypatch, B, N, hc, wc, nsplit):
-    """The bf16 modes' similarity stage exists in two tile kernels (sim_frag3_kernel: three workgroups per CU, the default;
-    sim_frag_kernel, OPHIP_SIM_TILE=2: rounds 2-4's) and two eager forms (one tile pass that stores S + the in-place conversion pass;
+    """The bf16 modes' similarity stage exists in two tile kernels (sim_frag_kernel, the default; sim_frag3_kernel, OPHIP_SIM_TILE=3: three
+    workgroups per CU, faster per tile and slower in the pipeline, kept as the measured alternative) and two eager forms (one tile pass that stores S + the in-place conversion pass;
     OPHIP_COARSE_TWO_PASS=1: statistics pass + a second tile pass that writes every confidence once -- the default from 2^27 matrix elements
     on, BASELINE config 4).  Match lists must be identical in all four; conf_matrix bit-identical between the two forms on the same tile
     kernel (same statistics, conf_kernel's own expression) and between the tile kernels on interior tiles (same association of every sum);
@@ -1019,6 +1019,7 @@ def test_object_cache_is_bit_identical(sd, cfg, dev, monkeypatch):
     cached.to(dev)
     from onepose_st_amd import ops
     n_calls = ops.CALLS["frame_enqueue"]
+    singles = []
     for f in frames:
         a, b = dict(obj), dict(obj)
         plain.forward_features(a, f["feat_c"].to(dev), f["feat_f"].to(dev), f["image_hw"])
@@ -1026,6 +1027,7 @@ def test_object_cache_is_bit_identical(sd, cfg, dev, monkeypatch):
         assert len(a["i_ids"]) > 200
         for k in keys:
             assert torch.equal(a[k], b[k]), k
+        singles.append({k: a[k].clone() for k in keys})
     assert ops.CALLS["frame_enqueue"] == n_calls + 6            # the cache MISS (first frame) takes the one-call frame path like the hits
     entry = cached._obj_cache
     assert entry is not None and entry["y3d0"] is not None and entry["kv1"] is not None       # first layer "self": the deep entry
@@ -1074,6 +1076,12 @@ def test_object_cache_is_bit_identical(sd, cfg, dev, monkeypatch):
     assert cached._obj_cache["y3d0"].shape[0] == 1 and len(a["i_ids"]) > 600
     for k in keys + ("b_ids",):
         assert torch.equal(a[k], b[k]), ("shared", k)
+    assert plain._obj_cache is None                             # the plain model does a shared batch's object-only work once per CALL and keeps nothing
+    for bi in range(B):                                         # ... and every frame of the batch equals its own single-frame run
+        sel = a["b_ids"] == bi
+        for k in ("i_ids", "j_ids", "mconf", "mkpts_query_f", "expec_f"):
+            assert torch.equal(a[k][sel], singles[bi][k]), ("shared vs single", bi, k)
+        assert torch.equal(a["conf_matrix"][bi], singles[bi]["conf_matrix"][0])
     other = make_synthetic_inputs(sd, n_points=1100, image_hw=(128, 192), n_plant=400, seed=77, config=cfg, frame=0)
     two = {k: torch.cat([frames[0][k], other[k]]).to(dev) for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db")}
     fc2 = torch.cat([frames[0]["feat_c"], other["feat_c"]]).to(dev)

@@ -105,7 +105,8 @@ for step in "$@"; do
       tail -40 $O/$n.txt ;;
     epy:*)
       IFS=: read -r -a A <<< "${step#epy:}"
-      e="${A[0]//,/ }"; n=$(basename ${A[1]} .py)_$(echo "${A[0]}" | tr -c 'A-Za-z0-9\n' '_')
+      e="${A[0]//,/ }"; n=$(basename ${A[1]} .py)_$(echo "${A[0]}_${A[*]:2}" | tr -c 'A-Za-z0-9\n' '_' | cut -c1-120)
+      [ "${A[0]}" = "-" ] && e=""
       env $e timeout -k 10 400 python3 "${A[@]:1}" > $O/$n.txt 2>&1 || { tail -8 $O/$n.txt; exit 1; }
       echo "[${A[0]}]"; tail -20 $O/$n.txt ;;
     counters)

@@ -1,4 +1,4 @@
-"""Diagnostic: cycle stamps of the similarity tile kernel at c2 (sim_frag3_kernel, or sim_frag_kernel with OPHIP_SIM_TILE=2).  Not part of the product.
+"""Diagnostic: cycle stamps of the similarity tile kernel at c2 (sim_frag_kernel, or sim_frag3_kernel with OPHIP_SIM_TILE=3).  Not part of the product.
 Stamps per workgroup: 0 start | 1 end of the k-loop | 2 tile maximum known | 3 end of the store + statistics pass | 4 end."""
 import sys, os, ctypes, numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -21,7 +21,7 @@ buf = torch.zeros(nwg * 32, dtype=torch.int64, device=dev)
 hip.call("ophip_debug_stamps", ctypes.c_void_p(buf.data_ptr())); run(); torch.cuda.synchronize(); hip.call("ophip_debug_stamps", None)
 s = buf.view(-1, 32).cpu().numpy().astype(np.int64)
 s = s[s[:, 0] > 0]
-print("library build", hip.build_stamp(), "| tile kernel", os.environ.get("OPHIP_SIM_TILE", "3 (default)"), "| workgroups", len(s))
+print("library build", hip.build_stamp(), "| tile kernel", os.environ.get("OPHIP_SIM_TILE", "2 (default)"), "| workgroups", len(s))
 for k, name in ((1, "k-loop (16 k-steps)"), (2, "scale + tile maximum + sync"), (3, "stage + store + exponentials (+ syncs)"), (4, "sums across waves, partial records / exact pass")):
     print(f"{name:52s} {np.median(s[:, k] - s[:, k - 1]):9.0f}")
 d = s[:, 4] - s[:, 0]
