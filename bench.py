@@ -99,7 +99,7 @@ def main():
                     help="matrix arithmetic of the encoder kernels (see DESIGN.md section 4)")
     ap.add_argument("--main-region-only", action="store_true",
                     help="skip the side measurements (other PnP policy, matcher only, object cache): the process then runs the contract's region "
-                         "alone -- what tools/run_profile_r02.sh traces, so that the rocprofv3 averages describe the same conditions as the line")
+                         "alone -- what `tools/box.sh stats` traces, so that the rocprofv3 averages describe the same conditions as the line")
     ap.add_argument("--inputs-behind", action="store_true",
                     help="queue the input kernels (PE, transposes, keypoint encoding) behind the previous frame on the compute stream instead of "
                          "on a side stream (the feature maps and the object block are resident and complete here, so the side stream is legitimate)")
@@ -598,7 +598,7 @@ def main():
         pnp_ceiling = rate * world
 
     # HBM bytes and matrix-pipe busy cycles per launch of the roofline kernel: from the committed counter passes (separate
-    # rocprofv3 --pmc runs, tools/run_profile_r03.sh), not live -- and quoted ONLY when those passes ran on the build that is
+    # rocprofv3 --pmc runs, tools/box.sh pmc), not live -- and quoted ONLY when those passes ran on the build that is
     # running now (the pmc file records ophip_build_stamp): a kernel change without a re-profile prints null, never a stale number
     traffic, mfma_busy, pmc_note, coarse_stage = None, None, None, None
     stem = {"bf16x3": "enc_x3w8_kernel<false,", "bf16": "attn_apply_bf16_kernel<1", "f32": "attn_apply_kernel"}[args.precision]
@@ -726,7 +726,7 @@ def main():
             "library_build_stamp": hip.build_stamp(),
             # SQ_VALU_MFMA_BUSY_CYCLES of the committed counter pass over (1024 SIMDs x this run's launch time x the 2.4 GHz the
             # 2.5 PFLOP/s peak is quoted at): the matrix pipe's busy share at PEAK clock.  The clock the chip really holds in this
-            # kernel is the in-kernel s_memtime / s_memrealtime ratio in profiles/r04_stamps_enc_x3w8.txt
+            # kernel is the in-kernel s_memtime / s_memrealtime ratio in profiles/r05_stamps_enc_x3w8.txt
             "mfma_busy_frac_at_peak_clock": (mfma_busy / (1024.0 * avg_ms * 1e-3 * 2.4e9)) if (mfma_busy and launches) else None,
             "launches": launches,
             "launches_sampled_every": time_every,

@@ -24,7 +24,7 @@ def _cpu_has_avx2_fma() -> bool:
 def load():
     global _lib
     if _lib is None:
-        path = os.environ.get("OPPNP_LIB") or _LIB_PATH                  # OPPNP_LIB: exactly this build (A/B runs, tools/ab_bench.sh)
+        path = os.environ.get("OPPNP_LIB") or _LIB_PATH                  # OPPNP_LIB: exactly this build (A/B runs, tools/box.sh ab:...)
         fast = os.path.join(_LIB_DIR, "libonepose_pnp_avx2.so")          # same source built with -mavx2 -mfma
         if path == os.path.join(_LIB_DIR, "libonepose_pnp.so") and os.path.exists(fast) and _cpu_has_avx2_fma():
             path = fast

@@ -10,6 +10,7 @@
 #   stamps           in-kernel cycle stamps of attn_apply, the fine stage (two and one workgroup per CU) and the similarity tiles
 #   stats            rocprofv3 --kernel-trace --stats of the contract's region alone (c2) and of config 4, + the timeline
 #   pmc              counter passes, each in its own run (FETCH_SIZE | WRITE_SIZE | matrix-pipe busy | L2 hit / miss) + the summaries
+#   issue            instruction counts per kernel (SQ_INSTS_VALU / _MFMA / _LDS / _SALU, own pass): what loads the SIMD's issue port
 #   counters         the counter names rocprofv3 offers on the box (gpurun_out/<out>/counters.txt)
 #   ranks            the N > 1 code path on this one-GPU box: two gloo ranks sharing the device; RCCL with one rank
 #   ab:<rounds>:<steps>:<variant>[:<variant>...]   interleaved A/B of bench.py (main region only); a variant is "-" (shipped build) or a
@@ -80,6 +81,12 @@ for step in "$@"; do
       python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_summary.json "rocprofv3 --pmc <one counter set per pass> --kernel-trace --output-format csv -- $B (c2, bf16x3, B=1; tools/box.sh pmc)" $O/pmc_mfma > $O/pmc_summary.txt || exit 1
       python3 tools/l2_summary.py $O/pmc_l2 > $O/l2_summary.txt 2>&1 || true
       cat $O/pmc_summary.txt; cat $O/l2_summary.txt
+      find $O -name "*.csv" -size +3M -delete ;;
+    issue)
+      B="python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-pnp --main-region-only"
+      rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU --kernel-trace --output-format csv -d $O/pmc_issue -- $B > /dev/null 2> $O/pmc_i.err || { tail -5 $O/pmc_i.err; exit 1; }
+      python3 tools/issue_summary.py $O/pmc_issue enc_x3w8 fine_pair sim_frag conf_kernel > $O/issue_summary.txt 2>&1 || true
+      cat $O/issue_summary.txt
       find $O -name "*.csv" -size +3M -delete ;;
     ranks)
       python3 bench.py --gpus 2 --share-device --dist-backend gloo --steps 40 --warmup 5 --no-cpu-baseline > $O/bench_2ranks_gloo_shared.json 2> $O/bench_2ranks.err || { tail -5 $O/bench_2ranks.err; exit 1; }

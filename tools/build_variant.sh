@@ -2,7 +2,7 @@
 # Build an A/B variant of libonepose_hip.so:  tools/build_variant.sh <name> <git rev> <csrc file> [<csrc file> ...]
 # = the working tree's csrc with the listed files taken from <git rev>; result: onepose_st_amd/lib/variants/libonepose_hip_<name>.so
 # EXTRA="-D..." in the environment adds compiler flags; <git rev> may be "-" with no files (working tree + EXTRA only).
-# (load it with OPHIP_LIB=<path>; tools/ab_bench.sh runs variants interleaved on one box).  Variants are scratch: git-ignored like every .so.
+# (load it with OPHIP_LIB=<path>; `tools/box.sh <name> ab:R:S:variants` runs variants interleaved on one box).  Variants are scratch: git-ignored like every .so.
 set -e
 name=$1; rev=$2; shift 2
 root=$(cd $(dirname $0)/.. && pwd)
