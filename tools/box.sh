@@ -12,6 +12,7 @@
 #   pmc              counter passes, each in its own run (FETCH_SIZE | WRITE_SIZE | matrix-pipe busy | L2 hit / miss) + the summaries
 #   issue            instruction counts per kernel (SQ_INSTS_VALU / _MFMA / _LDS / _SALU, own pass): what loads the SIMD's issue port
 #   counters         the counter names rocprofv3 offers on the box (gpurun_out/<out>/counters.txt)
+#   many:<n>         the contract's region n times (python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --main-region-only): the 20-step line's spread
 #   ranks            the N > 1 code path on this one-GPU box: two gloo ranks sharing the device; RCCL with one rank
 #   ab:<rounds>:<steps>:<variant>[:<variant>...]   interleaved A/B of bench.py (main region only); a variant is "-" (shipped build) or a
 #                    comma-separated list of NAME=VALUE environment assignments (OPHIP_LIB=onepose_st_amd/lib/variants/lib....so picks a variant build)
@@ -88,6 +89,19 @@ for step in "$@"; do
       python3 tools/issue_summary.py $O/pmc_issue enc_x3w8 fine_pair sim_frag conf_kernel > $O/issue_summary.txt 2>&1 || true
       cat $O/issue_summary.txt
       find $O -name "*.csv" -size +3M -delete ;;
+    many:*)
+      n=${step#many:}
+      for i in $(seq 1 $n); do
+        timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --main-region-only > $O/many_$i.json 2> $O/many_$i.err || { tail -3 $O/many_$i.err; exit 1; }
+      done
+      python3 - $O $n > $O/bench20_distribution.txt <<'PY'
+import json, sys, statistics
+vals = [json.loads(open(f"{sys.argv[1]}/many_{i}.json").read().strip().splitlines()[-1])["value"] for i in range(1, int(sys.argv[2]) + 1)]
+print(f"{len(vals)} runs of `python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --main-region-only` on one box")
+print("values:", " ".join(f"{v:.0f}" for v in vals))
+print(f"median {statistics.median(vals):.1f}  min {min(vals):.1f}  max {max(vals):.1f}  mean {statistics.mean(vals):.1f}  stdev {statistics.pstdev(vals):.1f}")
+PY
+      cat $O/bench20_distribution.txt ;;
     ranks)
       python3 bench.py --gpus 2 --share-device --dist-backend gloo --steps 40 --warmup 5 --no-cpu-baseline > $O/bench_2ranks_gloo_shared.json 2> $O/bench_2ranks.err || { tail -5 $O/bench_2ranks.err; exit 1; }
       tail -c 600 $O/bench_2ranks_gloo_shared.json; echo
