@@ -681,7 +681,8 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA, f32 accumulate)", "bf16": "bf16 (f32 accumulate)"}[args.precision],
+        "dtype": {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA, f32 accumulate)", "bf16": "bf16 (f32 accumulate)"}[args.precision]
+                 + ("; fine stage: plain bf16 (OPHIP_FINE_PRECISION)" if args.precision == "bf16x3" and os.environ.get("OPHIP_FINE_PRECISION") == "bf16" else ""),
         "data": "synthetic",
         "config": {
             "workload": f"{args.workload}: {n_points} 3D points x {M} 2D cells ({H}x{W} image), d256 coarse / d128 fine, "
@@ -780,11 +781,11 @@ def main():
     if rank == 0 and world == 1 and not args.main_region_only and not args.no_side_legs and args.workload == "c2" and B == 1:
         import subprocess
 
-        def side_leg(extra, timeout=240):
+        def side_leg(extra, timeout=240, env=None):
             cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-cpu-baseline", "--main-region-only", "--no-side-legs",
                    "--precision", args.precision] + extra
             try:
-                p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+                p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=(dict(os.environ) | env) if env else None)
                 line = [ln for ln in p.stdout.splitlines() if ln.lstrip().startswith("{")]
                 if p.returncode != 0 or not line:
                     return {"error": (p.stderr or p.stdout)[-400:]}
@@ -797,10 +798,19 @@ def main():
         # the low-margin / outlier variant of c2 (synthetic.HARD_PROFILE: confidences all over (0, 1), ~40 % of the matches wrong): what
         # the matcher and -- above all -- the reference-policy RANSAC cost when frames are not clean (pose parity on it: tests/test_gpu_parity.py)
         ch = side_leg(["--workload", "c2_hard", "--steps", "40", "--warmup", "5"])
+        # the same c2 region (same steps, same PnP policy) with the FINE stage on plain bf16 operands (config["hip_fine_precision"] = "bf16" /
+        # OPHIP_FINE_PRECISION=bf16): indices bit-exact, pose within 1e-5 of the default's, keypoints within 0.05 px (test_fine_stage_in_plain_bf16...).
+        # A side value: the headline keeps the arithmetic whose keypoints stay within 1e-4 relative of the reference's
+        fb = side_leg(["--workload", "c2", "--steps", str(args.steps), "--warmup", str(args.warmup)], env={"OPHIP_FINE_PRECISION": "bf16"}) if args.precision == "bf16x3" else {}
+        result["value_fine_bf16"] = fb.get("value")
         result["value_c3_b32"] = c3.get("value")
         result["value_c4"] = c4.get("value")
         result["value_c2_hard"] = ch.get("value")
         result["side_legs"] = {
+            "fine_bf16": {k: fb.get(k) for k in ("value", "ms_per_step", "steps", "dtype", "error") if k in fb}
+                         | {"what": "c2 with the fine stage alone on plain bf16 operands (one matrix instruction per product); coarse stage unchanged: match "
+                                    "indices bit-exact, pose |dR|, |dt|/|t| <= 7e-6 against the reference's / the oracle's matches on c1, c1_hard, c2, c2_hard, "
+                                    "keypoints within 0.05 px (tests/test_gpu_parity.py::test_fine_stage_in_plain_bf16_keeps_indices_and_pose)"},
             "c2_hard": {k: ch.get(k) for k in ("value", "ms_per_step", "steps", "error") if k in ch}
                        | {"workload": (ch.get("config") or {}).get("workload"), "matches_per_frame": (ch.get("config") or {}).get("matches_per_frame"),
                           "pnp_inliers_per_frame": (ch.get("config") or {}).get("pnp_inliers_per_frame"),

@@ -841,6 +841,11 @@ int fine_bf16(const float* feat_f, long long fs_b, long long fs_c, long long fs_
         return ophip_bad_arg(__func__, "channels-last feat_f needs 16-byte aligned pixels (strides multiples of 4 floats)");
     if ((dbg_win == nullptr) != (dbg_f3 == nullptr)) return ophip_bad_arg(__func__, "dbg_win and dbg_f3 go together");
     if (max_matches <= 0) return 0;
+    // OPHIP_FINE_PRECISION=bf16 (model config `hip_fine_precision`): the fine stage alone on PLAIN bf16 operands (one matrix instruction per product
+    // instead of three) while the coarse stage keeps the split form.  The fine stage only moves a match's sub-pixel offset: match indices cannot
+    // change; keypoints move by <= 0.05 px, the pose stays within north_star's 1e-4 (tests/test_gpu_parity.py::test_fine_stage_in_plain_bf16...).
+    // Not the default: the default keeps every keypoint within 1e-4 relative of the reference's.  (Read per call: a test compares both forms.)
+    if (nsplit == 3) { const char* e = getenv("OPHIP_FINE_PRECISION"); if (e && e[0] == 'b' && e[1] == 'f' && e[2] == '1' && e[3] == '6' && e[4] == 0) nsplit = 1; }
     FineBArgs a;
     a.feat_f = feat_f; a.fs_b = fs_b; a.fs_c = fs_c; a.fs_y = fs_y; a.fs_x = fs_x; a.hf = hf; a.wf = wf;
     a.desc_f = desc3d_f; a.ds_b = ds_b; a.ds_c = ds_c;

@@ -135,6 +135,16 @@ class OnePosePlus_model(nn.Module):
         self.precision = str(config.get("hip_precision", os.environ.get("OPHIP_PRECISION", "bf16x3")))
         if self.precision not in ("f32", "bf16x3", "bf16"):
             raise ValueError(f"hip_precision {self.precision!r}: expected 'f32', 'bf16x3' or 'bf16'")
+        # the FINE stage's arithmetic when the path runs in "bf16x3": "bf16x3" (default: every keypoint within 1e-4 relative of the reference's)
+        # or "bf16" -- plain bf16 operands, a third of the stage's matrix work: match indices unchanged (the fine stage only moves a match's
+        # sub-pixel offset), keypoints within 0.05 px, pose within 1e-5 of the default's (tests/test_gpu_parity.py::test_fine_stage_in_plain_bf16...).
+        # The library reads the switch from the environment on every fine-stage launch, so the key is PROCESS-WIDE: giving it sets
+        # OPHIP_FINE_PRECISION for every model of the process; leaving it out keeps whatever the environment says (default "bf16x3").
+        fp = config.get("hip_fine_precision")
+        if fp is not None:
+            if str(fp) not in ("bf16x3", "bf16"):
+                raise ValueError(f"hip_fine_precision {fp!r}: expected 'bf16x3' or 'bf16'")
+            os.environ["OPHIP_FINE_PRECISION"] = str(fp)
         # backbone on the HIP convolution kernels (bf16 pipe modes only; exact-f32 mode keeps MIOpen's fp32 convolutions)
         self.hip_backbone = bool(config.get("hip_backbone", True)) and self.precision != "f32"
         self.lazy_reruns = 0          # lazy conf_matrix: frames re-run eagerly because of an exact row tie (PendingFrame.finish)

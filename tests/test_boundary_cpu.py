@@ -47,6 +47,24 @@ def test_unsupported_config_raises_like_reference(path, value, exc):
         OnePosePlus_model(cfg)
 
 
+def test_fine_precision_key_is_validated_and_process_wide(cfg, monkeypatch):
+    """config["hip_fine_precision"]: "bf16x3" | "bf16" (the fine stage alone on plain bf16 operands); the library reads OPHIP_FINE_PRECISION on every
+    fine-stage launch, so giving the key sets it for the process, leaving it out touches nothing."""
+    import copy
+    import os
+    monkeypatch.delenv("OPHIP_FINE_PRECISION", raising=False)
+    OnePosePlus_model(copy.deepcopy(cfg))
+    assert "OPHIP_FINE_PRECISION" not in os.environ
+    c = copy.deepcopy(cfg)
+    c["hip_fine_precision"] = "fp8"
+    with pytest.raises(ValueError):
+        OnePosePlus_model(c)
+    c["hip_fine_precision"] = "bf16"
+    monkeypatch.setenv("OPHIP_FINE_PRECISION", "bf16x3")          # (so that monkeypatch restores the variable after the test)
+    OnePosePlus_model(c)
+    assert os.environ["OPHIP_FINE_PRECISION"] == "bf16"
+
+
 def test_cabi_exports_every_declared_symbol():
     header = open(os.path.join(REPO, "include", "onepose_hip.h")).read()
     declared = set(re.findall(r"\b(ophip_\w+)\s*\(", header))

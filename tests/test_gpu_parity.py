@@ -548,13 +548,15 @@ BORDERLINE = {}
 BORDER_WINDOW = {"f32": 0.0, "bf16x3": 2e-4}
 
 
-def _check_against(data, want, precision="f32", thr=0.1, label=None, want_rowmax=None):
+def _check_against(data, want, precision="f32", thr=0.1, label=None, want_rowmax=None, kp_tol=None):
     """Indices bit-exact wherever that is well defined: a match whose confidence sits within BORDER_WINDOW of the (strict) threshold
     may fall on either side of it in another arithmetic ("hard parts"); such borderline matches -- and only
     those -- are set aside, COUNTED (returned and recorded under `label`), and everything else must agree exactly.  Exact-f32 mode
     has no window: any difference fails.  `want_rowmax` (the oracle's / reference's row maxima of conf_matrix) lets the check also
     require that the other side's value of a set-aside row lies inside the window."""
     rt, at, rt_conf = TOL[precision]
+    if kp_tol is not None:                        # (keypoint tolerances of a run whose fine stage is in another arithmetic; indices and confidences as usual)
+        rt, at = kp_tol
     win = BORDER_WINDOW.get(precision, 0.0) * thr
     got_bi = torch.stack([data["b_ids"], data["i_ids"]], 1).cpu().numpy()
     want_bi = np.stack([np.asarray(want["b_ids"]), np.asarray(want["i_ids"])], 1)
@@ -587,7 +589,7 @@ def _check_against(data, want, precision="f32", thr=0.1, label=None, want_rowmax
     np.testing.assert_allclose(data["mconf"].cpu().numpy(), np.asarray(want["mconf"]), rtol=rt_conf, atol=1e-6, err_msg="mconf")
     np.testing.assert_allclose(data["mkpts_query_f"].cpu().numpy(), np.asarray(want["mkpts_query_f"]), rtol=rt, atol=at, err_msg="mkpts_query_f")
     np.testing.assert_allclose(data["expec_f"][:, :2].cpu().numpy(), np.asarray(want["expec_f"])[:, :2], rtol=rt, atol=at)
-    np.testing.assert_allclose(data["expec_f"][:, 2].cpu().numpy(), np.asarray(want["expec_f"])[:, 2], rtol=1e-3, atol=2e-3)
+    np.testing.assert_allclose(data["expec_f"][:, 2].cpu().numpy(), np.asarray(want["expec_f"])[:, 2], rtol=1e-3, atol=2e-3 if kp_tol is None else max(2e-3, at))
     err_px = float(np.abs(data["mkpts_query_f"].cpu().numpy() - np.asarray(want["mkpts_query_f"])).max()) if len(want["mconf"]) else 0.0
     err_conf = float(np.abs(data["mconf"].cpu().numpy() / np.asarray(want["mconf"]) - 1).max()) if len(want["mconf"]) else 0.0
     print(f"[{precision}] K={len(want['mconf'])}: max |mkpts_query_f err| = {err_px:.2e} px, max mconf rel err = {err_conf:.2e}")
@@ -1356,6 +1358,36 @@ def test_c2_hard_full_size_against_oracle(model, sd, cfg, dev):
     v = conf[i, j]
     assert torch.equal(v, data["mconf"]) and bool((v > 0.1).all())
     assert torch.equal(v, conf.max(dim=1)[0][i]) and torch.equal(v, conf.max(dim=0)[0][j])          # mutual nearest, on the device's own matrix
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["c1", "c1_hard", "c2", "c2_hard"])
+def test_fine_stage_in_plain_bf16_keeps_indices_and_pose(sd, cfg, dev, golden_dir, monkeypatch, case):
+    """`hip_fine_precision = "bf16"` / OPHIP_FINE_PRECISION=bf16: the fine stage on plain bf16 operands (one matrix instruction per product), the
+    coarse stage unchanged.  What north_star names must hold exactly as in the default mode -- match indices bit-exact, pose R|t within 1e-4 of
+    the pose from the reference's (golden) / the oracle's matches -- while the sub-pixel keypoints are allowed 0.08 px (measured: <= 0.05) instead
+    of the default mode's 1e-4 relative.  The frames are the reference-generated goldens (c1, c1_hard) and the full-size oracle cases (c2, c2_hard)."""
+    monkeypatch.setenv("OPHIP_FINE_PRECISION", "bf16")
+    m = _model(sd, cfg, dev, "bf16x3")
+    if case in ("c1", "c1_hard"):
+        g = dict(np.load(os.path.join(golden_dir, f"{case}_feature_boundary.npz")))
+        inp = (make_synthetic_inputs(sd, n_points=1000, image_hw=(240, 320), n_plant=600, seed=1, config=cfg) if case == "c1" else _hard_inputs(sd, cfg, "c1_hard"))
+        rowmax = g["conf_rowmax"]
+    else:
+        inp = (make_synthetic_inputs(sd, n_points=7000, image_hw=(480, 640), n_plant=3000, seed=1, config=cfg) if case == "c2" else _hard_inputs(sd, cfg, "c2_hard"))
+        torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+        with torch.no_grad():
+            ref = orc.forward_from_features(sd, cfg, inp, inp["feat_c"], inp["feat_f"], inp["image_hw"])
+        g = {k: ref[k].numpy() for k in ("b_ids", "i_ids", "j_ids", "m_bids", "mconf", "mkpts_3d_db", "mkpts_query_c", "mkpts_query_f", "expec_f")}
+        rowmax = ref["conf_matrix"].max(dim=2)[0][0].numpy()
+    data = _run_features(m, inp, dev)
+    n_sa = _check_against(data, g, "bf16x3", label=f"{case}_fine_bf16", want_rowmax=rowmax, kp_tol=(0.0, 0.08))
+    err = float(np.abs(data["mkpts_query_f"].cpu().numpy() - np.asarray(g["mkpts_query_f"])[:len(data["mkpts_query_f"])]).max()) if n_sa == 0 else float("nan")
+    print(f"[{case}, fine stage in plain bf16] K = {len(data['i_ids'])}, max |mkpts_query_f - reference| = {err:.3e} px")
+    _pose_parity(data, g["mkpts_3d_db"], g["mkpts_query_f"], inp, f"{case}, fine stage in plain bf16", n_sa)
+    monkeypatch.delenv("OPHIP_FINE_PRECISION")
+    again = _run_features(m, inp, dev)                                   # the knob is read per call: the default form is back
+    assert float(np.abs(again["mkpts_query_f"].cpu().numpy() - np.asarray(g["mkpts_query_f"])[:len(again["mkpts_query_f"])]).max()) < 2e-3 or n_sa
 
 
 @pytest.mark.gpu

@@ -33,7 +33,7 @@ print(sys.argv[2] if len(sys.argv) > 2 else "", "value", f(d["value"]), "ms/step
       "no_hot", f(d.get("value_no_hot_steps")), "dependent", f(d.get("value_dependent_sequence")), "lat", (d.get("latency_ms") or {}).get("median"),
       "| attn us", f(r.get("avg_launch_ms", 0) * 1e3), "frac", f(r.get("frac"), 4), "alone us", f(((r.get("alone") or {}).get("avg_launch_ms") or 0) * 1e3),
       "| c3", f(d.get("value_c3_b32")), "c4", f(d.get("value_c4")), "c4 stage_frac", f((((d.get("side_legs") or {}).get("c4") or {}).get("conf_kernel") or {}).get("stage_frac"), 4),
-      "hard", f(d.get("value_c2_hard")), "| pnp ceil", f(h.get("pnp_ceiling_fps")), "cpu", f((d.get("cpu_baseline") or {}).get("value"), 2))
+      "hard", f(d.get("value_c2_hard")), "fine_bf16", f(d.get("value_fine_bf16")), "| pnp ceil", f(h.get("pnp_ceiling_fps")), "cpu", f((d.get("cpu_baseline") or {}).get("value"), 2))
 PY
 }
 for step in "$@"; do
