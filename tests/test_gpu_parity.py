@@ -1361,7 +1361,7 @@ def test_c2_hard_full_size_against_oracle(model, sd, cfg, dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["c1", "c1_hard", "c2", "c2_hard"])
+@pytest.mark.parametrize("case", ["c1", "c1_hard", "c2", "c2_hard", "b2"])
 def test_fine_stage_in_plain_bf16_keeps_indices_and_pose(sd, cfg, dev, golden_dir, monkeypatch, case):
     """`hip_fine_precision = "bf16"` / OPHIP_FINE_PRECISION=bf16: the fine stage on plain bf16 operands (one matrix instruction per product), the
     coarse stage unchanged.  What north_star names must hold exactly as in the default mode -- match indices bit-exact, pose R|t within 1e-4 of
@@ -1369,6 +1369,15 @@ def test_fine_stage_in_plain_bf16_keeps_indices_and_pose(sd, cfg, dev, golden_di
     of the default mode's 1e-4 relative.  The frames are the reference-generated goldens (c1, c1_hard) and the full-size oracle cases (c2, c2_hard)."""
     monkeypatch.setenv("OPHIP_FINE_PRECISION", "bf16")
     m = _model(sd, cfg, dev, "bf16x3")
+    if case == "b2":                              # the ragged two-frame batch of the reference goldens: indices and keypoints (no pose: two frames, one list)
+        g = np.load(os.path.join(golden_dir, "b2_ragged_feature_boundary.npz"))
+        i0 = make_synthetic_inputs(sd, n_points=333, image_hw=(96, 136), n_plant=120, seed=3, config=cfg, frame=0)
+        i1 = make_synthetic_inputs(sd, n_points=333, image_hw=(96, 136), n_plant=120, seed=3, config=cfg, frame=1)
+        both = {k: torch.cat([i0[k], i1[k]], 0) for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db", "feat_c", "feat_f")}
+        both["image_hw"] = i0["image_hw"]
+        data = _run_features(m, both, dev)
+        assert _check_against(data, g, "bf16x3", label="b2_fine_bf16", kp_tol=(0.0, 0.08)) == 0
+        return
     if case in ("c1", "c1_hard"):
         g = dict(np.load(os.path.join(golden_dir, f"{case}_feature_boundary.npz")))
         inp = (make_synthetic_inputs(sd, n_points=1000, image_hw=(240, 320), n_plant=600, seed=1, config=cfg) if case == "c1" else _hard_inputs(sd, cfg, "c1_hard"))
